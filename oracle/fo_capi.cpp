@@ -1,0 +1,385 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see fo_common.hpp). extern "C" surface over the CPU
+// restatement so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can drive it
+// through ctypes. Never linked into, loaded by, or called from the product library.
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "fo_assemble.hpp"
+#include "fo_colamd.hpp"
+#include "fo_expressions.hpp"
+#include "fo_lm.hpp"
+#include "fo_qr.hpp"
+#include "fo_rand.hpp"
+#include "fo_sparse.hpp"
+#include "fo_symbolic.hpp"
+
+using namespace fo;
+
+namespace {
+
+SparseColMatStructure make_structure(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowidx) {
+    SparseColMatStructure s;
+    s.nrows = static_cast<size_t>(nrows);
+    s.ncols = static_cast<size_t>(ncols);
+    s.column_pointers.assign(colptr, colptr + ncols + 1);
+    s.row_indices.assign(rowidx, rowidx + colptr[ncols]);
+    return s;
+}
+
+constexpr uint16_t NO_COMPONENT = 0xFFFF;
+
+// Build the oracle's FlatSystem for system `s` of a flat batch (same array layout as
+// include/fiksi_amd.h's fx_batch, restated here so the oracle stays self-contained).
+FlatSystem make_system(uint32_t s, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                       const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                       const double* expr_param, const uint16_t* var_comp, const uint16_t* expr_comp) {
+    FlatSystem sys;
+    uint32_t v0 = var_off[s], v1 = var_off[s + 1], e0 = expr_off[s], e1 = expr_off[s + 1];
+    sys.variables.assign(vars + v0, vars + v1);
+    sys.fixed.assign(var_fixed + v0, var_fixed + v1);
+    sys.expressions.resize(e1 - e0);
+    for (uint32_t e = e0; e < e1; ++e) {
+        Expression& x = sys.expressions[e - e0];
+        x.tag = expr_tag[e];
+        for (int k = 0; k < 4; ++k) x.idx[k] = expr_idx[4 * static_cast<size_t>(e) + k];
+        x.param = expr_param[e];
+    }
+    uint32_t ncomp = 0;
+    for (uint32_t v = v0; v < v1; ++v) {
+        uint16_t c = var_comp ? var_comp[v] : 0;
+        if (c != NO_COMPONENT && c + 1u > ncomp) ncomp = c + 1u;
+    }
+    for (uint32_t e = e0; e < e1; ++e) {
+        uint16_t c = expr_comp ? expr_comp[e] : 0;
+        if (c != NO_COMPONENT && c + 1u > ncomp) ncomp = c + 1u;
+    }
+    sys.components.resize(ncomp);
+    for (uint32_t v = v0; v < v1; ++v) {
+        uint16_t c = var_comp ? var_comp[v] : 0;
+        if (c != NO_COMPONENT) sys.components[c].variables.push_back(v - v0);
+    }
+    for (uint32_t e = e0; e < e1; ++e) {
+        uint16_t c = expr_comp ? expr_comp[e] : 0;
+        if (c != NO_COMPONENT) sys.components[c].expressions.push_back(e - e0);
+    }
+    return sys;
+}
+
+template <typename F>
+void parallel_for(uint32_t n, uint32_t nthreads, F&& f) {
+    if (nthreads <= 1 || n < 2) {
+        for (uint32_t i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < nthreads; ++t) {
+        pool.emplace_back([&] {
+            for (;;) {
+                uint32_t begin = next.fetch_add(64);
+                if (begin >= n) return;
+                uint32_t end = begin + 64 < n ? begin + 64 : n;
+                for (uint32_t i = begin; i < end; ++i) f(i);
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+struct fo_result {
+    uint32_t accepted;  // accepted LM steps (Gauss-Newton iterations), summed over components
+    uint32_t trials;    // factorizations, summed over components
+    uint32_t exit;      // LmExit of the last component
+    uint32_t ncomp;     // components solved
+    double scale;       // system scale (1 when scaling is off)
+    double sse0;        // initial SSE (scaled space), summed over components
+    double sse;         // final SSE (scaled space), summed over components
+};
+
+// fiksi/src/rand.rs
+void fo_rng_u32(uint32_t seed, uint32_t n, uint32_t* out) {
+    Rng rng = Rng::from_seed(seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.next_u32();
+}
+void fo_rng_f64(uint32_t seed, uint32_t n, double* out) {
+    Rng rng = Rng::from_seed(seed);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.next_f64();
+}
+
+// expressions.rs: one expression on gathered values. Returns the variable count.
+int fo_expr_eval(uint8_t tag, const double* vars8, double param, double* residual, double* grad8) {
+    Expression e{tag, {0, 2, 4, 6}, param};
+    uint32_t idx[8];
+    int k = variable_indices(e, idx);
+    double g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double v[8];
+    for (int i = 0; i < 8; ++i) v[i] = vars8[i];
+    *residual = compute_residual_and_gradient(e, v, g);
+    for (int i = 0; i < 8; ++i) grad8[i] = g[i];
+    return k;
+}
+
+// colamd_rs::colamd. `colptr` (ncols+1) is overwritten with the permutation in [0, ncols).
+int fo_colamd(int nrows, int ncols, const int* rowidx, int* colptr, int aggressive) {
+    std::vector<int> p(colptr, colptr + ncols + 1);
+    std::vector<int> rows(rowidx, rowidx + p[ncols]);
+    ColamdOptions opt;
+    opt.aggressive_row_absorption = aggressive != 0;
+    if (!colamd(nrows, ncols, rows, p, opt)) return -1;
+    for (int i = 0; i < ncols; ++i) colptr[i] = p[i];
+    colptr[ncols] = -1;
+    return 0;
+}
+
+// solvi symbolic phase on a CSC structure (natural ordering): etree, post-order, counts, R structure.
+// l_rowidx must have room for sum(col_counts) entries (<= ncols*(ncols+1)/2).
+int fo_symbolic(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowidx, int64_t* parents,
+                int64_t* post, int64_t* row_counts, int64_t* col_counts, int64_t* l_colptr, int64_t* l_rowidx) {
+    SparseColMatStructure a = make_structure(nrows, ncols, colptr, rowidx);
+    auto par = elimination_tree<false>(a);
+    auto po = post_order(par);
+    auto counts = CholeskyCounts::build(a, par, po);
+    auto cs = CholeskyStructure::build(a, par, po, counts);
+    for (int64_t j = 0; j < ncols; ++j) {
+        parents[j] = par[j] == NONE ? -1 : static_cast<int64_t>(par[j]);
+        post[j] = static_cast<int64_t>(po[j]);
+        row_counts[j] = static_cast<int64_t>(counts.row_counts[j]);
+        col_counts[j] = static_cast<int64_t>(counts.col_counts[j]);
+    }
+    for (int64_t j = 0; j <= ncols; ++j) l_colptr[j] = static_cast<int64_t>(cs.l_structure.column_pointers[j]);
+    for (size_t k = 0; k < cs.l_structure.row_indices.size(); ++k) l_rowidx[k] = static_cast<int64_t>(cs.l_structure.row_indices[k]);
+    return 0;
+}
+
+// solvi sparse QR: factorize the CSC matrix and solve min |A x - b| in place (b has nrows entries,
+// x is returned in b[0..ncols)). ordering: 0 natural, 1 colamd. R is returned in CSC form.
+int fo_qr_factor_solve(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowidx,
+                       const double* values, int ordering, double* b, int64_t* r_colptr, int64_t* r_rowidx,
+                       double* r_values, int64_t r_cap, int* solved) {
+    SparseColMat a;
+    a.structure = make_structure(nrows, ncols, colptr, rowidx);
+    a.values.assign(values, values + colptr[ncols]);
+    SymbolicQr sym = SymbolicQr::build(a.structure, ordering ? QrOrdering::Colamd : QrOrdering::Natural);
+    Qr qr(sym);
+    qr.factorize(a);
+    if (b) *solved = qr.solve_mut(b) ? 1 : 0;
+    int64_t nnz = static_cast<int64_t>(qr.r.values.size());
+    if (r_colptr) {
+        if (nnz > r_cap) return -1;
+        for (int64_t j = 0; j <= ncols; ++j) r_colptr[j] = static_cast<int64_t>(qr.r.structure.column_pointers[j]);
+        for (int64_t k = 0; k < nnz; ++k) {
+            r_rowidx[k] = static_cast<int64_t>(qr.r.structure.row_indices[k]);
+            r_values[k] = qr.r.values[k];
+        }
+    }
+    return 0;
+}
+
+// TripletMat -> SparseColMat::from_triplet_mat (sorted, duplicates summed). Returns nnz.
+int64_t fo_from_triplets(int64_t nrows, int64_t ncols, int64_t ntrip, const int64_t* rows, const int64_t* cols,
+                         const double* vals, int64_t* colptr, int64_t* rowidx, double* values) {
+    TripletMat t(static_cast<size_t>(nrows), static_cast<size_t>(ncols));
+    for (int64_t k = 0; k < ntrip; ++k) t.push_triplet(static_cast<size_t>(rows[k]), static_cast<size_t>(cols[k]), vals[k]);
+    SparseColMat m = SparseColMat::from_triplet_mat(t);
+    for (size_t j = 0; j <= m.ncols(); ++j) colptr[j] = static_cast<int64_t>(m.structure.column_pointers[j]);
+    for (size_t k = 0; k < m.values.size(); ++k) {
+        rowidx[k] = static_cast<int64_t>(m.structure.row_indices[k]);
+        values[k] = m.values[k];
+    }
+    return static_cast<int64_t>(m.values.size());
+}
+
+// SparseColMat::solve_upper_triangular_mut
+int fo_solve_upper(int64_t n, const int64_t* colptr, const int64_t* rowidx, const double* values, double* b) {
+    SparseColMat a;
+    a.structure = make_structure(n, n, colptr, rowidx);
+    a.values.assign(values, values + colptr[n]);
+    return a.solve_upper_triangular_mut(b) ? 1 : 0;
+}
+
+// Subsystem::calculate_residuals_and_sparse_jacobian (subsystem.rs:126-166) for every system of
+// a flat batch at the given variable values, followed by the reference's COO -> CSC conversion
+// (duplicates summed) and a transposition to the row-major layout the GPU path emits:
+//   r[expr_off[s] + row], jrow_ptr[total_exprs + 1] (global rows), jcol (system-local free
+//   column), jval. Columns = ascending rank of non-fixed variables that belong to a component.
+// Returns total nnz, or -1 if `cap` is too small.
+int64_t fo_eval_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                      const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                      const double* expr_param, const uint16_t* var_comp, double* r, int64_t* jrow_ptr,
+                      int32_t* jcol, double* jval, int64_t cap) {
+    int64_t nnz_total = 0;
+    jrow_ptr[0] = 0;
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, nullptr);
+        Subsystem sub;
+        sub.system_variables = sys.variables.data();
+        sub.all_expressions = sys.expressions.data();
+        sub.free_index.assign(sys.variables.size(), -1);
+        for (uint32_t v = 0; v < sys.variables.size(); ++v) {
+            uint16_t c = var_comp ? var_comp[var_off[s] + v] : 0;
+            if (!sys.fixed[v] && c != NO_COMPONENT) {
+                sub.free_index[v] = static_cast<int32_t>(sub.free_variables.size());
+                sub.free_variables.push_back(v);
+            }
+        }
+        for (uint32_t e = 0; e < sys.expressions.size(); ++e) sub.expressions.push_back(e);
+        std::vector<double> x(sub.free_variables.size());
+        for (size_t k = 0; k < x.size(); ++k) x[k] = sys.variables[sub.free_variables[k]];
+        size_t m = sub.expressions.size(), nv = x.size();
+        TripletMat coo(m, nv);
+        sub.calculate_residuals_and_sparse_jacobian(x.data(), r + expr_off[s], coo);
+        coo.nrows = m;
+        coo.ncols = nv;
+        SparseColMat csc = SparseColMat::from_triplet_mat(coo);
+        // CSC -> CSR (entries of a row end up in ascending column order)
+        std::vector<int64_t> count(m, 0);
+        for (size_t row : csc.structure.row_indices) count[row] += 1;
+        int64_t base = nnz_total;
+        for (size_t row = 0; row < m; ++row) {
+            jrow_ptr[expr_off[s] + row + 1] = jrow_ptr[expr_off[s] + row] + count[row];
+        }
+        nnz_total = jrow_ptr[expr_off[s] + m];
+        if (nnz_total > cap) return -1;
+        std::vector<int64_t> fill(m, 0);
+        for (size_t col = 0; col < nv; ++col) {
+            for (size_t p = csc.structure.column_pointers[col]; p < csc.structure.column_pointers[col + 1]; ++p) {
+                size_t row = csc.structure.row_indices[p];
+                int64_t dst = jrow_ptr[expr_off[s] + row] + fill[row]++;
+                jcol[dst] = static_cast<int32_t>(col);
+                jval[dst] = csc.values[p];
+            }
+        }
+        (void)base;
+    }
+    return nnz_total;
+}
+
+// assemble::solve (Decomposer::None + LM) over a flat batch, `nthreads` worker threads over
+// disjoint system ranges (the reference itself is single-threaded; systems are independent).
+// mode bit0: scale by the system RMS (assemble/mod.rs:58-79); bit1: LCG perturbation (:113-124).
+// mode 0 == levenberg_marquardt(Subsystem) on the values as given (L2 boundary).
+// first_delta (optional, mode 0 only): per system, receives the first LM step of component 0 at
+// var-offset positions of the free variables (others untouched).
+int fo_solve_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, double* vars,
+                   const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                   const double* expr_param, const uint16_t* var_comp, const uint16_t* expr_comp, uint32_t mode,
+                   int ordering, uint32_t trial_cap, uint32_t nthreads, fo_result* results) {
+    QrOrdering ord = ordering ? QrOrdering::Colamd : QrOrdering::Natural;
+    parallel_for(n_systems, nthreads, [&](uint32_t s) {
+        FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, expr_comp);
+        fo_result res{};
+        if (mode & 1u) {
+            SolveStats st = solve(sys, (mode & 2u) != 0, ord, trial_cap);
+            res.scale = st.scale;
+            for (const LmStats& c : st.components) {
+                res.accepted += c.accepted;
+                res.trials += c.trials;
+                res.exit = c.exit;
+                res.sse0 += c.sse_initial;
+                res.sse += c.sse_final;
+                res.ncomp += 1;
+            }
+        } else {
+            // L2: no scaling; optional perturbation is not meaningful here. Each component is
+            // solved against the snapshot of the incoming values (quirk Q2).
+            res.scale = 1.;
+            std::vector<double> snapshot = sys.variables;
+            for (const Component& comp : sys.components) {
+                if (comp.variables.empty()) continue;
+                Subsystem sub;
+                sub.system_variables = snapshot.data();
+                sub.all_expressions = sys.expressions.data();
+                sub.expressions = comp.expressions;
+                sub.free_index.assign(sys.variables.size(), -1);
+                for (uint32_t v : comp.variables) {
+                    if (!sys.fixed[v]) {
+                        sub.free_index[v] = static_cast<int32_t>(sub.free_variables.size());
+                        sub.free_variables.push_back(v);
+                    }
+                }
+                std::vector<double> x(sub.free_variables.size());
+                for (size_t k = 0; k < x.size(); ++k) x[k] = snapshot[sub.free_variables[k]];
+                LmStats c = levenberg_marquardt(sub, x.data(), ord, trial_cap);
+                for (size_t k = 0; k < x.size(); ++k) sys.variables[sub.free_variables[k]] = x[k];
+                res.accepted += c.accepted;
+                res.trials += c.trials;
+                res.exit = c.exit;
+                res.sse0 += c.sse_initial;
+                res.sse += c.sse_final;
+                res.ncomp += 1;
+            }
+        }
+        std::memcpy(vars + var_off[s], sys.variables.data(), sys.variables.size() * sizeof(double));
+        if (results) results[s] = res;
+    });
+    return 0;
+}
+
+// First LM step only (lambda = 0.5) of component 0 for every system, on the values as given:
+// delta for the free variables (ascending order) written to delta[var_off[s] + k], k < nfree.
+int fo_first_step_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                        const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                        const double* expr_param, const uint16_t* var_comp, const uint16_t* expr_comp, int ordering,
+                        double* delta) {
+    QrOrdering ord = ordering ? QrOrdering::Colamd : QrOrdering::Natural;
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, expr_comp);
+        if (sys.components.empty()) continue;
+        const Component& comp = sys.components[0];
+        Subsystem sub;
+        sub.system_variables = sys.variables.data();
+        sub.all_expressions = sys.expressions.data();
+        sub.expressions = comp.expressions;
+        sub.free_index.assign(sys.variables.size(), -1);
+        for (uint32_t v : comp.variables) {
+            if (!sys.fixed[v]) {
+                sub.free_index[v] = static_cast<int32_t>(sub.free_variables.size());
+                sub.free_variables.push_back(v);
+            }
+        }
+        std::vector<double> x(sub.free_variables.size());
+        for (size_t k = 0; k < x.size(); ++k) x[k] = sys.variables[sub.free_variables[k]];
+        std::vector<double> d(x.size(), 0.);
+        levenberg_marquardt(sub, x.data(), ord, 1, d.data());
+        for (size_t k = 0; k < d.size(); ++k) delta[var_off[s] + k] = d[k];
+    }
+    return 0;
+}
+
+// calculate_system_scale (assemble/mod.rs:32-44) per system.
+void fo_system_scale_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                           const uint8_t* expr_tag, const double* expr_param, double* scale) {
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        FlatSystem sys;
+        sys.variables.assign(vars + var_off[s], vars + var_off[s + 1]);
+        for (uint32_t e = expr_off[s]; e < expr_off[s + 1]; ++e) {
+            Expression x{expr_tag[e], {0, 0, 0, 0}, expr_param[e]};
+            sys.expressions.push_back(x);
+        }
+        scale[s] = calculate_system_scale(sys);
+    }
+}
+
+// Post-solve check: residual of every expression on the (unscaled) variables as given
+// (constraints/mod.rs:144-168 for valency-1 constraints).
+void fo_residuals_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                        const uint8_t* expr_tag, const uint32_t* expr_idx, const double* expr_param, double* r) {
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        for (uint32_t e = expr_off[s]; e < expr_off[s + 1]; ++e) {
+            Expression x;
+            x.tag = expr_tag[e];
+            for (int k = 0; k < 4; ++k) x.idx[k] = expr_idx[4 * static_cast<size_t>(e) + k];
+            x.param = expr_param[e];
+            r[e] = expression_residual(x, vars + var_off[s]);
+        }
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes loader for ``oracle/libfiksi_oracle.so`` (the C++ CPU restatement of the reference's hot
+path, see ``oracle/fo_common.hpp``). Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import this module; nothing under ``fiksi_amd/`` does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfiksi_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with g++ (seconds)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class FoResult(C.Structure):
+    _fields_ = [
+        ("accepted", C.c_uint32),
+        ("trials", C.c_uint32),
+        ("exit", C.c_uint32),
+        ("ncomp", C.c_uint32),
+        ("scale", C.c_double),
+        ("sse0", C.c_double),
+        ("sse", C.c_double),
+    ]
+
+
+RESULT_DTYPE = np.dtype(
+    [("accepted", "<u4"), ("trials", "<u4"), ("exit", "<u4"), ("ncomp", "<u4"),
+     ("scale", "<f8"), ("sse0", "<f8"), ("sse", "<f8")]
+)
+
+EXIT_SSE, EXIT_STEP, EXIT_FTOL, EXIT_MAX_OUTER, EXIT_TRIAL_CAP = range(5)
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.fo_eval_batch.restype = C.c_int64
+        _lib.fo_from_triplets.restype = C.c_int64
+    return _lib
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def rng_u32(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.uint32)
+    lib().fo_rng_u32(C.c_uint32(seed), C.c_uint32(n), _p(out))
+    return out
+
+
+def rng_f64(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.float64)
+    lib().fo_rng_f64(C.c_uint32(seed), C.c_uint32(n), _p(out))
+    return out
+
+
+def expr_eval(tag: int, vars8, param: float):
+    """Residual and gradient of one expression on gathered values (expressions.rs)."""
+    v = np.zeros(8, dtype=np.float64)
+    vv = np.asarray(vars8, dtype=np.float64)
+    v[: len(vv)] = vv
+    g = np.zeros(8, dtype=np.float64)
+    r = C.c_double(0.0)
+    k = lib().fo_expr_eval(C.c_uint8(tag), _p(v), C.c_double(param), C.byref(r), _p(g))
+    return r.value, g[:k].copy()
+
+
+def colamd(nrows: int, ncols: int, rowidx, colptr, aggressive: bool = True) -> np.ndarray:
+    r = np.ascontiguousarray(rowidx, dtype=np.int32)
+    p = np.ascontiguousarray(colptr, dtype=np.int32).copy()
+    rc = lib().fo_colamd(C.c_int(nrows), C.c_int(ncols), _p(r), _p(p), C.c_int(1 if aggressive else 0))
+    if rc != 0:
+        raise ValueError("colamd rejected the matrix")
+    return p
+
+
+def symbolic(nrows: int, ncols: int, colptr, rowidx):
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int64)
+    parents = np.zeros(ncols, dtype=np.int64)
+    post = np.zeros(ncols, dtype=np.int64)
+    rc = np.zeros(ncols, dtype=np.int64)
+    cc = np.zeros(ncols, dtype=np.int64)
+    lcp = np.zeros(ncols + 1, dtype=np.int64)
+    lri = np.zeros(ncols * (ncols + 1) // 2 + 1, dtype=np.int64)
+    lib().fo_symbolic(C.c_int64(nrows), C.c_int64(ncols), _p(cp), _p(ri), _p(parents), _p(post), _p(rc), _p(cc),
+                      _p(lcp), _p(lri))
+    return dict(parents=parents, post=post, row_counts=rc, col_counts=cc, l_colptr=lcp, l_rowidx=lri[: lcp[-1]].copy())
+
+
+def qr_factor_solve(nrows: int, ncols: int, colptr, rowidx, values, b=None, ordering: str = "natural"):
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int64)
+    va = np.ascontiguousarray(values, dtype=np.float64)
+    cap = ncols * (ncols + 1) // 2 + 1
+    rcp = np.zeros(ncols + 1, dtype=np.int64)
+    rri = np.zeros(cap, dtype=np.int64)
+    rva = np.zeros(cap, dtype=np.float64)
+    solved = C.c_int(0)
+    bb = None
+    if b is not None:
+        bb = np.zeros(nrows, dtype=np.float64)
+        bb[: len(b)] = np.asarray(b, dtype=np.float64)
+    rc = lib().fo_qr_factor_solve(C.c_int64(nrows), C.c_int64(ncols), _p(cp), _p(ri), _p(va),
+                                  C.c_int(1 if ordering == "colamd" else 0), _p(bb), _p(rcp), _p(rri), _p(rva),
+                                  C.c_int64(cap), C.byref(solved))
+    if rc != 0:
+        raise RuntimeError("R capacity too small")
+    nnz = int(rcp[-1])
+    return dict(r_colptr=rcp, r_rowidx=rri[:nnz].copy(), r_values=rva[:nnz].copy(),
+                x=None if bb is None else bb[:ncols].copy(), solved=bool(solved.value))
+
+
+def from_triplets(nrows: int, ncols: int, rows, cols, vals):
+    r = np.ascontiguousarray(rows, dtype=np.int64)
+    c = np.ascontiguousarray(cols, dtype=np.int64)
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    cp = np.zeros(ncols + 1, dtype=np.int64)
+    ri = np.zeros(len(v), dtype=np.int64)
+    va = np.zeros(len(v), dtype=np.float64)
+    nnz = lib().fo_from_triplets(C.c_int64(nrows), C.c_int64(ncols), C.c_int64(len(v)), _p(r), _p(c), _p(v), _p(cp),
+                                 _p(ri), _p(va))
+    return cp, ri[:nnz].copy(), va[:nnz].copy()
+
+
+def solve_upper(n: int, colptr, rowidx, values, b):
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int64)
+    va = np.ascontiguousarray(values, dtype=np.float64)
+    bb = np.ascontiguousarray(b, dtype=np.float64).copy()
+    ok = lib().fo_solve_upper(C.c_int64(n), _p(cp), _p(ri), _p(va), _p(bb))
+    return bool(ok), bb
+
+
+# ---- flat batches (dict of numpy arrays with the fx_batch field names) ----------------------
+
+def _batch_args(b):
+    n = int(len(b["var_off"]) - 1)
+    return n, [
+        C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(b["vars"]), _p(b["var_fixed"]), _p(b["expr_tag"]),
+        _p(b["expr_idx"]), _p(b["expr_param"]),
+    ]
+
+
+def eval_batch(b):
+    """r, (jrow_ptr, jcol, jval): reference sparse Jacobian assembly, row-major."""
+    n, args = _batch_args(b)
+    total_e = int(b["expr_off"][-1])
+    r = np.zeros(total_e, dtype=np.float64)
+    cap = 8 * total_e + 8
+    jrow = np.zeros(total_e + 1, dtype=np.int64)
+    jcol = np.zeros(cap, dtype=np.int32)
+    jval = np.zeros(cap, dtype=np.float64)
+    nnz = lib().fo_eval_batch(*args, _p(b.get("var_comp")), _p(r), _p(jrow), _p(jcol), _p(jval), C.c_int64(cap))
+    assert nnz >= 0
+    return r, (jrow, jcol[:nnz].copy(), jval[:nnz].copy())
+
+
+def solve_batch(b, mode: int = 3, ordering: str = "colamd", trial_cap: int = 0, nthreads: int = 1):
+    """assemble::solve (mode 3 = scale+perturb, the reference default) or the bare LM (mode 0).
+
+    Returns (solved variables, per-system results); the input batch is not modified.
+    """
+    n, args = _batch_args(b)
+    vars_out = b["vars"].copy()
+    args[3] = _p(vars_out)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    lib().fo_solve_batch(*args, _p(b.get("var_comp")), _p(b.get("expr_comp")), C.c_uint32(mode),
+                         C.c_int(1 if ordering == "colamd" else 0), C.c_uint32(trial_cap), C.c_uint32(nthreads),
+                         _p(res))
+    return vars_out, res
+
+
+def first_step_batch(b, ordering: str = "colamd"):
+    n, args = _batch_args(b)
+    delta = np.zeros_like(b["vars"])
+    lib().fo_first_step_batch(*args, _p(b.get("var_comp")), _p(b.get("expr_comp")),
+                              C.c_int(1 if ordering == "colamd" else 0), _p(delta))
+    return delta
+
+
+def system_scale_batch(b):
+    n = int(len(b["var_off"]) - 1)
+    scale = np.zeros(n, dtype=np.float64)
+    lib().fo_system_scale_batch(C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(b["vars"]), _p(b["expr_tag"]),
+                                _p(b["expr_param"]), _p(scale))
+    return scale
+
+
+def residuals_batch(b, vars_=None):
+    n = int(len(b["var_off"]) - 1)
+    v = b["vars"] if vars_ is None else np.ascontiguousarray(vars_, dtype=np.float64)
+    r = np.zeros(int(b["expr_off"][-1]), dtype=np.float64)
+    lib().fo_residuals_batch(C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(v), _p(b["expr_tag"]),
+                             _p(b["expr_idx"]), _p(b["expr_param"]), _p(r))
+    return r
