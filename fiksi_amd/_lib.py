@@ -1,0 +1,146 @@
+"""ctypes binding of ``libfiksi_amd.so`` (C ABI: ``include/fiksi_amd.h``, ``include/fiksi_amd_builder.h``).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (``make -C fiksi_amd/csrc``). There is no
+fallback: if it is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfiksi_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C fiksi_amd/csrc`). fiksi_amd has no pure-Python or CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+u8p, u16p, u32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64))
+f64p = C.POINTER(C.c_double)
+
+
+class FxBatch(C.Structure):
+    _fields_ = [
+        ("n_systems", C.c_uint32),
+        ("var_off", C.c_void_p),
+        ("expr_off", C.c_void_p),
+        ("vars", C.c_void_p),
+        ("var_fixed", C.c_void_p),
+        ("expr_tag", C.c_void_p),
+        ("expr_idx", C.c_void_p),
+        ("expr_param", C.c_void_p),
+        ("var_comp", C.c_void_p),
+        ("expr_comp", C.c_void_p),
+    ]
+
+
+class FxLmOpts(C.Structure):
+    _fields_ = [
+        ("lambda0", C.c_double), ("sse_tol", C.c_double), ("step_tol", C.c_double), ("ftol", C.c_double),
+        ("accept_factor", C.c_double), ("reject_factor", C.c_double), ("singular_factor", C.c_double),
+        ("lambda_min", C.c_double), ("max_outer", C.c_uint32), ("max_trials", C.c_uint32),
+        ("solver", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class FxSolvingOpts(C.Structure):
+    _fields_ = [
+        ("optimizer", C.c_uint32), ("decomposer", C.c_uint32), ("perturb", C.c_uint32), ("reserved", C.c_uint32),
+        ("lm", FxLmOpts),
+    ]
+
+
+class FxResult(C.Structure):
+    _fields_ = [
+        ("accepted", C.c_uint32), ("trials", C.c_uint32), ("exit", C.c_uint32), ("ncomp", C.c_uint32),
+        ("scale", C.c_double), ("sse0", C.c_double), ("sse", C.c_double), ("sse_unscaled", C.c_double),
+    ]
+
+
+# every entry point the headers declare: (name, restype, argtypes)
+_vp = C.c_void_p
+SIGNATURES = [
+    ("fx_abi_version", C.c_int, []),
+    ("fx_last_error", C.c_char_p, []),
+    ("fx_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("fx_ctx_create", C.c_int, [C.POINTER(_vp), C.c_int]),
+    ("fx_ctx_destroy", None, [_vp]),
+    ("fx_ctx_synchronize", C.c_int, [_vp]),
+    ("fx_ctx_device_name", C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    ("fx_lm_opts_default", None, [C.POINTER(FxLmOpts)]),
+    ("fx_solving_opts_default", None, [C.POINTER(FxSolvingOpts)]),
+    ("fx_batch_validate", C.c_int, [C.POINTER(FxBatch)]),
+    ("fx_jacobian_structure", C.c_int, [C.POINTER(FxBatch), u64p, _vp, _vp]),
+    ("fx_batch_upload", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(_vp)]),
+    ("fx_batch_free", None, [_vp, _vp]),
+    ("fx_batch_set_vars", C.c_int, [_vp, _vp, _vp]),
+    ("fx_batch_get_vars", C.c_int, [_vp, _vp, _vp]),
+    ("fx_batch_get_results", C.c_int, [_vp, _vp, _vp]),
+    ("fx_batch_nnz", C.c_uint64, [_vp]),
+    ("fx_system_solve_device", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts)]),
+    ("fx_lm_solve_device", C.c_int, [_vp, _vp, C.POINTER(FxLmOpts)]),
+    ("fx_eval_residual_jacobian_device", C.c_int, [_vp, _vp, C.c_int]),
+    ("fx_eval_residual_device", C.c_int, [_vp, _vp, C.c_int]),
+    ("fx_batch_get_residuals", C.c_int, [_vp, _vp, _vp]),
+    ("fx_batch_get_jacobian_values", C.c_int, [_vp, _vp, _vp]),
+    ("fx_timer_begin", C.c_int, [_vp]),
+    ("fx_timer_end", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("fx_system_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxSolvingOpts), _vp]),
+    ("fx_lm_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
+    ("fx_eval_residual_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp]),
+    ("fx_constraint_residuals", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
+    # builder
+    ("fxs_system_new", C.c_int, [C.POINTER(_vp)]),
+    ("fxs_system_free", None, [_vp]),
+    ("fxs_system_id", C.c_uint32, [_vp]),
+    ("fxs_num_elements", C.c_uint32, [_vp]),
+    ("fxs_num_constraints", C.c_uint32, [_vp]),
+    ("fxs_num_variables", C.c_uint32, [_vp]),
+    ("fxs_num_expressions", C.c_uint32, [_vp]),
+    ("fxs_length_create", C.c_int64, [_vp, C.c_double]),
+    ("fxs_point_create", C.c_int64, [_vp, C.c_double, C.c_double]),
+    ("fxs_line_create", C.c_int64, [_vp, C.c_uint32, C.c_uint32]),
+    ("fxs_circle_create", C.c_int64, [_vp, C.c_uint32, C.c_uint32]),
+    ("fxs_element_tag_of", C.c_int, [_vp, C.c_uint32]),
+    ("fxs_element_fix", C.c_int, [_vp, C.c_uint32]),
+    ("fxs_element_unfix", C.c_int, [_vp, C.c_uint32]),
+    ("fxs_element_get_value", C.c_int, [_vp, C.c_uint32, f64p]),
+    ("fxs_point_update_value", C.c_int, [_vp, C.c_uint32, C.c_double, C.c_double]),
+    ("fxs_length_update_value", C.c_int, [_vp, C.c_uint32, C.c_double]),
+    ("fxs_constraint_create", C.c_int64, [_vp, C.c_int, u32p, C.c_uint32, C.c_double]),
+    ("fxs_constraint_tag_of", C.c_int, [_vp, C.c_uint32]),
+    ("fxs_constraint_valency", C.c_int, [C.c_int]),
+    ("fxs_constraint_update_parameter", C.c_int, [_vp, C.c_uint32, C.c_double]),
+    ("fxs_components", C.c_int, [_vp, u32p, _vp, _vp]),
+    ("fxs_flatten", C.c_int, [C.POINTER(_vp), C.c_uint32, C.POINTER(_vp)]),
+    ("fxs_flat_batch", C.POINTER(FxBatch), [_vp]),
+    ("fxs_flat_free", None, [_vp]),
+    ("fxs_flat_scatter", C.c_int, [_vp, C.POINTER(_vp), C.c_uint32]),
+    ("fxs_system_solve", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts), C.POINTER(FxResult)]),
+    ("fxs_systems_solve", C.c_int, [C.POINTER(_vp), C.c_uint32, _vp, C.POINTER(FxSolvingOpts), _vp]),
+    ("fxs_system_constraint_residuals", C.c_int, [_vp, _vp, _vp]),
+]
+
+for _name, _res, _args in SIGNATURES:
+    _fn = getattr(lib, _name)  # AttributeError here == the library does not export a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class FiksiError(RuntimeError):
+    """A C-ABI call returned a negative fx_status."""
+
+    def __init__(self, code: int, where: str):
+        msg = lib.fx_last_error()
+        super().__init__(f"{where} failed with fx_status {code}: {msg.decode() if msg else ''}")
+        self.code = code
+
+
+def check(code: int, where: str) -> int:
+    if code < 0:
+        raise FiksiError(int(code), where)
+    return int(code)

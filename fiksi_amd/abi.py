@@ -1,0 +1,250 @@
+"""Thin Python objects over the C ABI (``include/fiksi_amd.h``): flat batches, device contexts,
+HBM-resident batches. All numerics happen in the HIP kernels behind the ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import FxBatch, FxLmOpts, FxResult, FxSolvingOpts, check, lib
+
+RESULT_DTYPE = np.dtype(
+    [("accepted", "<u4"), ("trials", "<u4"), ("exit", "<u4"), ("ncomp", "<u4"),
+     ("scale", "<f8"), ("sse0", "<f8"), ("sse", "<f8"), ("sse_unscaled", "<f8")]
+)
+assert RESULT_DTYPE.itemsize == C.sizeof(FxResult)
+
+EXIT_SSE, EXIT_STEP, EXIT_FTOL, EXIT_MAX_OUTER, EXIT_TRIAL_CAP, EXIT_NAN = range(6)
+NO_COMPONENT = 0xFFFF
+
+# fx_tag
+(VARIABLE_VARIABLE_EQUALITY, POINT_POINT_DISTANCE, POINT_POINT_POINT_ANGLE, POINT_LINE_INCIDENCE,
+ POINT_LINE_DISTANCE, POINT_CIRCLE_INCIDENCE, SEGMENT_SEGMENT_LENGTH_EQUALITY, LINE_LINE_ANGLE,
+ LINE_LINE_PARALLELISM, LINE_LINE_PERPENDICULARITY, LINE_CIRCLE_TANGENCY) = range(11)
+
+_FIELDS = {
+    "var_off": np.uint32, "expr_off": np.uint32, "vars": np.float64, "var_fixed": np.uint8,
+    "expr_tag": np.uint8, "expr_idx": np.uint32, "expr_param": np.float64,
+    "var_comp": np.uint16, "expr_comp": np.uint16,
+}
+
+
+def normalize_batch(arrays: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Contiguous arrays of the ABI dtypes, keyed by the fx_batch field names."""
+    out = {}
+    for k, dt in _FIELDS.items():
+        a = arrays.get(k)
+        if a is None:
+            if k in ("var_comp", "expr_comp"):
+                continue
+            raise KeyError(f"batch is missing {k}")
+        out[k] = np.ascontiguousarray(a, dtype=dt)
+    return out
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+def as_struct(arrays: Dict[str, np.ndarray]) -> FxBatch:
+    """fx_batch struct pointing into the (kept alive by the caller) numpy arrays."""
+    b = FxBatch()
+    b.n_systems = len(arrays["var_off"]) - 1
+    for k in _FIELDS:
+        setattr(b, k, _ptr(arrays.get(k)))
+    return b
+
+
+def lm_opts(**kw) -> FxLmOpts:
+    o = FxLmOpts()
+    lib.fx_lm_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def solving_opts(perturb: bool = True, **lm_kw) -> FxSolvingOpts:
+    o = FxSolvingOpts()
+    lib.fx_solving_opts_default(C.byref(o))
+    o.perturb = 1 if perturb else 0
+    for k, v in lm_kw.items():
+        setattr(o.lm, k, v)
+    return o
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = lib.fx_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def validate(arrays) -> None:
+    a = normalize_batch(arrays)
+    check(lib.fx_batch_validate(C.byref(as_struct(a))), "fx_batch_validate")
+
+
+def jacobian_structure(arrays):
+    """(row_ptr, col_idx) of the CSR Jacobian the device fills (host-side, no GPU needed)."""
+    a = normalize_batch(arrays)
+    st = as_struct(a)
+    nnz = C.c_uint64(0)
+    ne = int(a["expr_off"][-1]) if len(a["expr_off"]) else 0
+    row_ptr = np.zeros(ne + 1, dtype=np.uint32)
+    check(lib.fx_jacobian_structure(C.byref(st), C.byref(nnz), _ptr(row_ptr), None), "fx_jacobian_structure")
+    col = np.zeros(nnz.value, dtype=np.uint32)
+    check(lib.fx_jacobian_structure(C.byref(st), C.byref(nnz), _ptr(row_ptr), _ptr(col)), "fx_jacobian_structure")
+    return row_ptr, col
+
+
+class Context:
+    """fx_ctx: one HIP device + stream. Raises FiksiError(FX_ERR_NO_DEVICE) without a gfx950 GPU."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.fx_ctx_create(C.byref(h), device), "fx_ctx_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.fx_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(lib.fx_ctx_device_name(self._h, buf, 256), "fx_ctx_device_name")
+        return buf.value.decode()
+
+    def synchronize(self):
+        check(lib.fx_ctx_synchronize(self._h), "fx_ctx_synchronize")
+
+    def timer_begin(self):
+        check(lib.fx_timer_begin(self._h), "fx_timer_begin")
+
+    def timer_end(self) -> float:
+        ms = C.c_float(0)
+        check(lib.fx_timer_end(self._h, C.byref(ms)), "fx_timer_end")
+        return float(ms.value)
+
+    def upload(self, arrays) -> "DeviceBatch":
+        return DeviceBatch(self, arrays)
+
+    # ---- host-buffer entry points -------------------------------------------------------
+    def system_solve_batch(self, arrays, opts: Optional[FxSolvingOpts] = None):
+        """assemble::solve on host buffers; returns (solved vars, results)."""
+        a = normalize_batch(arrays)
+        a["vars"] = a["vars"].copy()
+        res = np.zeros(len(a["var_off"]) - 1, dtype=RESULT_DTYPE)
+        o = opts if opts is not None else solving_opts()
+        check(lib.fx_system_solve_batch(self._h, C.byref(as_struct(a)), C.byref(o), _ptr(res)), "fx_system_solve_batch")
+        return a["vars"], res
+
+    def lm_solve_batch(self, arrays, opts: Optional[FxLmOpts] = None):
+        a = normalize_batch(arrays)
+        a["vars"] = a["vars"].copy()
+        res = np.zeros(len(a["var_off"]) - 1, dtype=RESULT_DTYPE)
+        o = opts if opts is not None else lm_opts()
+        check(lib.fx_lm_solve_batch(self._h, C.byref(as_struct(a)), C.byref(o), _ptr(res)), "fx_lm_solve_batch")
+        return a["vars"], res
+
+    def eval_residual_jacobian(self, arrays, want_jacobian: bool = True):
+        a = normalize_batch(arrays)
+        st = as_struct(a)
+        ne = int(a["expr_off"][-1])
+        r = np.zeros(ne, dtype=np.float64)
+        if not want_jacobian:
+            check(lib.fx_eval_residual_jacobian(self._h, C.byref(st), _ptr(r), None), "fx_eval_residual_jacobian")
+            return r, None
+        row_ptr, col = jacobian_structure(a)
+        vals = np.zeros(len(col), dtype=np.float64)
+        check(lib.fx_eval_residual_jacobian(self._h, C.byref(st), _ptr(r), _ptr(vals)), "fx_eval_residual_jacobian")
+        return r, (row_ptr, col, vals)
+
+    def constraint_residuals(self, arrays):
+        a = normalize_batch(arrays)
+        r = np.zeros(int(a["expr_off"][-1]), dtype=np.float64)
+        check(lib.fx_constraint_residuals(self._h, C.byref(as_struct(a)), _ptr(r)), "fx_constraint_residuals")
+        return r
+
+
+class DeviceBatch:
+    """fx_dbatch: a batch resident in HBM, solved repeatedly from its start values."""
+
+    def __init__(self, ctx: Context, arrays):
+        self.ctx = ctx
+        a = normalize_batch(arrays)
+        self.n_systems = len(a["var_off"]) - 1
+        self.n_vars = int(a["var_off"][-1]) if self.n_systems else 0
+        self.n_exprs = int(a["expr_off"][-1]) if self.n_systems else 0
+        h = C.c_void_p()
+        check(lib.fx_batch_upload(ctx.handle, C.byref(as_struct(a)), C.byref(h)), "fx_batch_upload")
+        self._h = h
+        self.nnz = int(lib.fx_batch_nnz(h))
+
+    def free(self):
+        if self._h and self.ctx.handle:
+            lib.fx_batch_free(self.ctx.handle, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def system_solve(self, opts: Optional[FxSolvingOpts] = None):
+        o = opts if opts is not None else solving_opts()
+        check(lib.fx_system_solve_device(self.ctx.handle, self._h, C.byref(o)), "fx_system_solve_device")
+
+    def lm_solve(self, opts: Optional[FxLmOpts] = None):
+        o = opts if opts is not None else lm_opts()
+        check(lib.fx_lm_solve_device(self.ctx.handle, self._h, C.byref(o)), "fx_lm_solve_device")
+
+    def eval_residual_jacobian(self, which: int = 0):
+        check(lib.fx_eval_residual_jacobian_device(self.ctx.handle, self._h, which), "fx_eval_residual_jacobian_device")
+
+    def eval_residual(self, which: int = 0):
+        check(lib.fx_eval_residual_device(self.ctx.handle, self._h, which), "fx_eval_residual_device")
+
+    def set_vars(self, vars_):
+        v = np.ascontiguousarray(vars_, dtype=np.float64)
+        assert v.size == self.n_vars
+        check(lib.fx_batch_set_vars(self.ctx.handle, self._h, _ptr(v)), "fx_batch_set_vars")
+
+    def get_vars(self) -> np.ndarray:
+        v = np.zeros(self.n_vars, dtype=np.float64)
+        check(lib.fx_batch_get_vars(self.ctx.handle, self._h, _ptr(v)), "fx_batch_get_vars")
+        return v
+
+    def get_results(self) -> np.ndarray:
+        r = np.zeros(self.n_systems, dtype=RESULT_DTYPE)
+        check(lib.fx_batch_get_results(self.ctx.handle, self._h, _ptr(r)), "fx_batch_get_results")
+        return r
+
+    def get_residuals(self) -> np.ndarray:
+        r = np.zeros(self.n_exprs, dtype=np.float64)
+        check(lib.fx_batch_get_residuals(self.ctx.handle, self._h, _ptr(r)), "fx_batch_get_residuals")
+        return r
+
+    def get_jacobian_values(self) -> np.ndarray:
+        v = np.zeros(self.nnz, dtype=np.float64)
+        check(lib.fx_batch_get_jacobian_values(self.ctx.handle, self._h, _ptr(v)), "fx_batch_get_jacobian_values")
+        return v

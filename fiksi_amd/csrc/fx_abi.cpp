@@ -1,0 +1,567 @@
+// C ABI of libfiksi_amd.so (include/fiksi_amd.h): validation, Jacobian structure, HBM residency,
+// kernel launches. Host logic only; every numeric result comes from the HIP kernels in
+// fx_kernels.hip. There is deliberately no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fx_device.h"
+#include "fx_expr.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define FX_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) return fail(FX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// Host-side analysis of a batch: everything the device needs besides the raw arrays.
+struct HostPlan {
+    uint32_t n_systems = 0, n_vars = 0, n_exprs = 0;
+    uint64_t nnz = 0;
+    uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0;
+    std::vector<uint16_t> sys_ncomp;
+    std::vector<uint16_t> var_info;
+    std::vector<uint16_t> expr_comp;
+    std::vector<uint16_t> expr_idx16;
+    std::vector<uint32_t> expr_sys;
+    std::vector<uint32_t> jrow_ptr, jcol, jslot;
+};
+
+// Checks the batch and (optionally) builds the plan. Mirrors the data invariants the reference
+// enforces by construction (handles of the same System, indices < variables.len()).
+int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
+    if (!b) return fail(FX_ERR_INVALID, "batch is NULL");
+    const uint32_t n = b->n_systems;
+    if (n > 0 && (!b->var_off || !b->expr_off)) return fail(FX_ERR_INVALID, "var_off/expr_off is NULL");
+    if (n == 0) {
+        if (plan) *plan = HostPlan();
+        if (plan) plan->jrow_ptr.assign(1, 0);
+        return FX_OK;
+    }
+    if (b->var_off[0] != 0 || b->expr_off[0] != 0) return fail(FX_ERR_INVALID, "offset arrays must start at 0");
+    for (uint32_t s = 0; s < n; ++s) {
+        if (b->var_off[s + 1] < b->var_off[s] || b->expr_off[s + 1] < b->expr_off[s])
+            return fail(FX_ERR_INVALID, "offsets of system %u decrease", s);
+    }
+    const uint32_t nv = b->var_off[n], ne = b->expr_off[n];
+    if (nv > 0 && (!b->vars || !b->var_fixed)) return fail(FX_ERR_INVALID, "vars/var_fixed is NULL");
+    if (ne > 0 && (!b->expr_tag || !b->expr_idx || !b->expr_param)) return fail(FX_ERR_INVALID, "expr_* is NULL");
+
+    HostPlan local;
+    HostPlan& p = plan ? *plan : local;
+    p = HostPlan();
+    p.n_systems = n;
+    p.n_vars = nv;
+    p.n_exprs = ne;
+    p.sys_ncomp.assign(n, 0);
+    p.var_info.assign(nv, 0);
+    p.expr_comp.assign(ne, 0);
+    p.expr_idx16.assign(4 * (size_t)ne, 0);
+    p.expr_sys.assign(ne, 0);
+    if (want_structure) {
+        p.jrow_ptr.assign((size_t)ne + 1, 0);
+        p.jslot.assign(ne, 0xFFFFFFFFu);
+        p.jcol.reserve((size_t)ne * 5);
+    }
+
+    std::vector<int32_t> free_rank;     // per variable of the current system: system-wide free rank
+    std::vector<uint32_t> comp_free, comp_rows;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
+        const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
+        if (nvt > FX_MAX_SYSTEM_VARS)
+            return fail(FX_ERR_TOO_LARGE, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_SYSTEM_VARS);
+        p.max_vars = std::max(p.max_vars, nvt);
+        p.max_exprs = std::max(p.max_exprs, net);
+
+        uint32_t ncomp = 0;
+        free_rank.assign(nvt, -1);
+        int32_t rank = 0;
+        for (uint32_t i = 0; i < nvt; ++i) {
+            uint16_t c = b->var_comp ? b->var_comp[v0 + i] : 0;
+            bool fixed = b->var_fixed[v0 + i] != 0;
+            uint16_t info;
+            if (c == FX_NO_COMPONENT) {
+                info = fx::VAR_COMP_NONE;
+            } else {
+                if (c >= fx::VAR_COMP_NONE) return fail(FX_ERR_INVALID, "system %u: component id %u too large", s, c);
+                info = c;
+                ncomp = std::max<uint32_t>(ncomp, c + 1u);
+                if (!fixed) free_rank[i] = rank++;
+            }
+            if (fixed) info |= fx::VAR_FIXED_BIT;
+            p.var_info[v0 + i] = info;
+        }
+        for (uint32_t i = 0; i < net; ++i) {
+            uint16_t c = b->expr_comp ? b->expr_comp[e0 + i] : 0;
+            if (c == FX_NO_COMPONENT) {
+                c = fx::VAR_COMP_NONE;  // never selected by any component loop
+            } else {
+                if (c >= fx::VAR_COMP_NONE) return fail(FX_ERR_INVALID, "system %u: component id %u too large", s, c);
+                ncomp = std::max<uint32_t>(ncomp, c + 1u);
+            }
+            p.expr_comp[e0 + i] = c;
+        }
+        p.sys_ncomp[s] = (uint16_t)ncomp;
+
+        comp_free.assign(ncomp, 0);
+        comp_rows.assign(ncomp, 0);
+        for (uint32_t i = 0; i < nvt; ++i) {
+            uint16_t info = p.var_info[v0 + i];
+            uint16_t c = info & fx::VAR_COMP_MASK;
+            if (c != fx::VAR_COMP_NONE && !(info & fx::VAR_FIXED_BIT)) comp_free[c] += 1;
+        }
+
+        for (uint32_t i = 0; i < net; ++i) {
+            const uint32_t e = e0 + i;
+            const int tag = b->expr_tag[e];
+            if (tag < 0 || tag >= FX_NTAGS) return fail(FX_ERR_INVALID, "expression %u of system %u: bad tag %d", i, s, tag);
+            const uint32_t* f = b->expr_idx + 4 * (size_t)e;
+            uint32_t vars8[8];
+            int k = fx::expand_vars(tag, f, vars8);
+            for (int q = 0; q < k; ++q) {
+                if (vars8[q] >= nvt)
+                    return fail(FX_ERR_INVALID, "expression %u of system %u reads variable %u >= %u", i, s, vars8[q], nvt);
+            }
+            for (int q = 0; q < 4; ++q) p.expr_idx16[4 * (size_t)e + q] = (uint16_t)(f[q] < nvt ? f[q] : 0);
+            p.expr_sys[e] = s;
+            uint16_t c = p.expr_comp[e];
+            if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
+
+            if (want_structure) {
+                // distinct free columns of the row, ascending; slot of each gradient entry
+                int32_t cols[8];
+                int ncols = 0;
+                for (int q = 0; q < k; ++q) {
+                    int32_t col = free_rank[vars8[q]];
+                    if (col < 0) continue;
+                    bool seen = false;
+                    for (int t = 0; t < ncols; ++t) seen = seen || cols[t] == col;
+                    if (!seen) cols[ncols++] = col;
+                }
+                std::sort(cols, cols + ncols);
+                uint32_t slots = 0;
+                for (int q = 0; q < 8; ++q) {
+                    uint32_t sl = 0xFu;
+                    if (q < k) {
+                        int32_t col = free_rank[vars8[q]];
+                        if (col >= 0) sl = (uint32_t)(std::find(cols, cols + ncols, col) - cols);
+                    }
+                    slots |= sl << (4 * q);
+                }
+                p.jslot[e] = slots;
+                for (int t = 0; t < ncols; ++t) p.jcol.push_back((uint32_t)cols[t]);
+                p.jrow_ptr[(size_t)e + 1] = p.jrow_ptr[e] + (uint32_t)ncols;
+            }
+        }
+        for (uint32_t c = 0; c < ncomp; ++c) {
+            if (comp_free[c] > FX_MAX_FREE_VARS)
+                return fail(FX_ERR_TOO_LARGE, "system %u component %u has %u free variables (limit %u)", s, c,
+                            comp_free[c], FX_MAX_FREE_VARS);
+            if (comp_rows[c] > FX_MAX_ROWS)
+                return fail(FX_ERR_TOO_LARGE, "system %u component %u has %u expressions (limit %u)", s, c,
+                            comp_rows[c], FX_MAX_ROWS);
+            p.max_free = std::max(p.max_free, comp_free[c]);
+            p.max_rows = std::max(p.max_rows, comp_rows[c]);
+        }
+    }
+    if (want_structure) p.nnz = p.jcol.size();
+    return FX_OK;
+}
+
+}  // namespace
+
+struct fx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    char name[128] = {0};
+    char arch[64] = {0};
+};
+
+struct fx_dbatch {
+    fx::DeviceBatch d{};
+    std::vector<void*> allocations;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc_copy(fx_ctx* ctx, fx_dbatch* db, T** out, const T* host, size_t count) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    db->allocations.push_back(p);
+    if (host && count) {
+        FX_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        FX_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream));
+    }
+    *out = static_cast<T*>(p);
+    return FX_OK;
+}
+
+int bind(fx_ctx* ctx) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    FX_HIP(hipSetDevice(ctx->device));
+    return FX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fx_abi_version(void) { return FX_ABI_VERSION; }
+
+const char* fx_last_error(void) { return g_last_error.c_str(); }
+
+int fx_device_count(int* count) {
+    if (!count) return fail(FX_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(FX_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return FX_OK;
+}
+
+int fx_ctx_create(fx_ctx** out, int device) {
+    if (!out) return fail(FX_ERR_INVALID, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(FX_ERR_NO_DEVICE, "no HIP device available (%s); fiksi_amd has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(FX_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, n - 1);
+    hipDeviceProp_t prop;
+    FX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FX_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    fx_ctx* ctx = new (std::nothrow) fx_ctx();
+    if (!ctx) return fail(FX_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    snprintf(ctx->name, sizeof(ctx->name), "%s", prop.name);
+    snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_begin);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e != hipSuccess) {
+        fx_ctx_destroy(ctx);
+        return fail(FX_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return FX_OK;
+}
+
+void fx_ctx_destroy(fx_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    delete ctx;
+}
+
+int fx_ctx_synchronize(fx_ctx* ctx) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len) {
+    if (!ctx || !buf || len == 0) return fail(FX_ERR_INVALID, "bad argument");
+    snprintf(buf, len, "%s (%s)", ctx->name, ctx->arch);
+    return FX_OK;
+}
+
+void fx_lm_opts_default(fx_lm_opts* o) {
+    if (!o) return;
+    o->lambda0 = 0.5;
+    o->sse_tol = 1e-8;
+    o->step_tol = 1e-12;
+    o->ftol = 1e-6;
+    o->accept_factor = 0.125;
+    o->reject_factor = 2.0;
+    o->singular_factor = 8.0;
+    o->lambda_min = 1e-50;
+    o->max_outer = 100;
+    o->max_trials = 4096;
+    o->solver = FX_STEP_CHOLESKY;
+    o->reserved = 0;
+}
+
+void fx_solving_opts_default(fx_solving_opts* o) {
+    if (!o) return;
+    o->optimizer = 0;
+    o->decomposer = 0;
+    o->perturb = 1;
+    o->reserved = 0;
+    fx_lm_opts_default(&o->lm);
+}
+
+int fx_batch_validate(const fx_batch* batch) { return analyze(batch, nullptr, false); }
+
+int fx_jacobian_structure(const fx_batch* batch, uint64_t* nnz, uint32_t* row_ptr, uint32_t* col_idx) {
+    HostPlan p;
+    int rc = analyze(batch, &p, true);
+    if (rc) return rc;
+    if (nnz) *nnz = p.nnz;
+    if (row_ptr) std::copy(p.jrow_ptr.begin(), p.jrow_ptr.end(), row_ptr);
+    if (col_idx) std::copy(p.jcol.begin(), p.jcol.end(), col_idx);
+    return FX_OK;
+}
+
+int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
+    if (!out) return fail(FX_ERR_INVALID, "out-pointer is NULL");
+    *out = nullptr;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HostPlan p;
+    rc = analyze(batch, &p, true);
+    if (rc) return rc;
+    fx_dbatch* db = new (std::nothrow) fx_dbatch();
+    if (!db) return fail(FX_ERR_NOMEM, "out of host memory");
+    fx::DeviceBatch& d = db->d;
+    d.n_systems = p.n_systems;
+    d.n_vars = p.n_vars;
+    d.n_exprs = p.n_exprs;
+    d.nnz = p.nnz;
+    d.max_free = p.max_free;
+    d.max_rows = p.max_rows;
+    d.max_vars = p.max_vars;
+    d.max_exprs = p.max_exprs;
+    const uint32_t zero_off[1] = {0};
+    const uint32_t* voff = p.n_systems ? batch->var_off : zero_off;
+    const uint32_t* eoff = p.n_systems ? batch->expr_off : zero_off;
+#define FX_UP(field, host, count)                                       \
+    rc = dev_alloc_copy(ctx, db, &d.field, host, (size_t)(count));      \
+    if (rc) {                                                           \
+        fx_batch_free(ctx, db);                                         \
+        return rc;                                                      \
+    }
+    FX_UP(var_off, voff, (size_t)p.n_systems + 1)
+    FX_UP(expr_off, eoff, (size_t)p.n_systems + 1)
+    FX_UP(sys_ncomp, p.sys_ncomp.data(), p.n_systems)
+    FX_UP(vars0, (const double*)batch->vars, p.n_vars)
+    FX_UP(vars, (const double*)batch->vars, p.n_vars)
+    FX_UP(var_info, p.var_info.data(), p.n_vars)
+    FX_UP(expr_tag, batch->expr_tag, p.n_exprs)
+    FX_UP(expr_comp, p.expr_comp.data(), p.n_exprs)
+    FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
+    FX_UP(expr_param, batch->expr_param, p.n_exprs)
+    FX_UP(expr_sys, p.expr_sys.data(), p.n_exprs)
+    FX_UP(jrow_ptr, p.jrow_ptr.data(), (size_t)p.n_exprs + 1)
+    FX_UP(jcol, p.jcol.data(), p.nnz)
+    FX_UP(jslot, p.jslot.data(), p.n_exprs)
+    FX_UP(jvals, (const double*)nullptr, p.nnz)
+    FX_UP(resid, (const double*)nullptr, p.n_exprs)
+    FX_UP(results, (const fx_result*)nullptr, p.n_systems)
+#undef FX_UP
+    // the host plan lives on this stack frame: finish the copies before returning
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        fx_batch_free(ctx, db);
+        return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    if (fx::solve_lds_bytes(d) > 160u * 1024u) {
+        fx_batch_free(ctx, db);
+        return fail(FX_ERR_TOO_LARGE, "batch needs %zu bytes of LDS per wavefront (limit 163840)", fx::solve_lds_bytes(d));
+    }
+    *out = db;
+    return FX_OK;
+}
+
+void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) {
+    if (!db) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    for (void* p : db->allocations) (void)hipFree(p);
+    delete db;
+}
+
+int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    FX_HIP(hipMemcpyAsync(db->d.vars0, vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FX_HIP(hipMemcpyAsync(db->d.vars, vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_batch_get_vars(fx_ctx* ctx, fx_dbatch* db, double* vars) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    FX_HIP(hipMemcpyAsync(vars, db->d.vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_batch_get_results(fx_ctx* ctx, fx_dbatch* db, fx_result* results) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !results) return fail(FX_ERR_INVALID, "bad argument");
+    FX_HIP(hipMemcpyAsync(results, db->d.results, (size_t)db->d.n_systems * sizeof(fx_result), hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+uint64_t fx_batch_nnz(const fx_dbatch* db) { return db ? db->d.nnz : 0; }
+
+int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    fx_solving_opts o;
+    if (opts) o = *opts; else fx_solving_opts_default(&o);
+    if (o.optimizer != 0) return fail(FX_ERR_UNSUPPORTED, "only Optimizer::LevenbergMarquardt runs on the device");
+    if (o.decomposer != 0) return fail(FX_ERR_UNSUPPORTED, "only Decomposer::None runs on the device");
+    fx::LmParams p;
+    p.lm = o.lm;
+    p.mode = 1u | (o.perturb ? 2u : 0u);
+    FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    return FX_OK;
+}
+
+int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    fx::LmParams p;
+    if (opts) p.lm = *opts; else fx_lm_opts_default(&p.lm);
+    p.mode = 0;
+    FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    return FX_OK;
+}
+
+int fx_eval_residual_jacobian_device(fx_ctx* ctx, fx_dbatch* db, int which) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    FX_HIP(fx::launch_eval(db->d, which ? db->d.vars : db->d.vars0, true, ctx->stream));
+    return FX_OK;
+}
+
+int fx_eval_residual_device(fx_ctx* ctx, fx_dbatch* db, int which) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    FX_HIP(fx::launch_eval(db->d, which ? db->d.vars : db->d.vars0, false, ctx->stream));
+    return FX_OK;
+}
+
+int fx_batch_get_residuals(fx_ctx* ctx, fx_dbatch* db, double* r) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !r) return fail(FX_ERR_INVALID, "bad argument");
+    FX_HIP(hipMemcpyAsync(r, db->d.resid, (size_t)db->d.n_exprs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_batch_get_jacobian_values(fx_ctx* ctx, fx_dbatch* db, double* jvals) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !jvals) return fail(FX_ERR_INVALID, "bad argument");
+    FX_HIP(hipMemcpyAsync(jvals, db->d.jvals, (size_t)db->d.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_timer_begin(fx_ctx* ctx) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    FX_HIP(hipEventRecord(ctx->ev_begin, ctx->stream));
+    return FX_OK;
+}
+
+int fx_timer_end(fx_ctx* ctx, float* milliseconds) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!milliseconds) return fail(FX_ERR_INVALID, "milliseconds is NULL");
+    FX_HIP(hipEventRecord(ctx->ev_end, ctx->stream));
+    FX_HIP(hipEventSynchronize(ctx->ev_end));
+    FX_HIP(hipEventElapsedTime(milliseconds, ctx->ev_begin, ctx->ev_end));
+    return FX_OK;
+}
+
+// ---- host-buffer entry points ---------------------------------------------------------------
+
+static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
+                      bool system_level, fx_result* results) {
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
+    if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
+    if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
+int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results) {
+    return solve_host(ctx, batch, opts, nullptr, true, results);
+}
+
+int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results) {
+    return solve_host(ctx, batch, nullptr, opts, false, results);
+}
+
+int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals) {
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    rc = jvals ? fx_eval_residual_jacobian_device(ctx, db, 0) : fx_eval_residual_device(ctx, db, 0);
+    if (!rc && r && db->d.n_exprs) rc = fx_batch_get_residuals(ctx, db, r);
+    if (!rc && jvals && db->d.nnz) rc = fx_batch_get_jacobian_values(ctx, db, jvals);
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
+int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r) {
+    if (!r) return fail(FX_ERR_INVALID, "r is NULL");
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    hipError_t e = fx::launch_identity_residuals(db->d, db->d.vars0, db->d.resid, ctx->stream);
+    if (e != hipSuccess) rc = fail(FX_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
+    if (!rc && db->d.n_exprs) rc = fx_batch_get_residuals(ctx, db, r);
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,475 @@
+// Host-side System builder behind include/fiksi_amd_builder.h. Bookkeeping only: it records
+// elements, constraints, fixed variables and the incremental connected components exactly as the
+// reference builder does, and flattens Systems into fx_batch. No numerics live here.
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/fiksi_amd_builder.h"
+
+namespace {
+
+int bfail(int code, const char*) { return code; }  // messages surface through the mirrors' exceptions
+
+// EncodedElement, fiksi/src/lib.rs:123-128
+struct Element {
+    int tag;       // fxs_element_tag
+    uint32_t a, b; // Length{idx=a}; Point{idx=a}; Line{point1_idx=a, point2_idx=b}; Circle{center_idx=a, radius_idx=b}
+};
+
+// EncodedConstraint, fiksi/src/lib.rs:134-137
+struct Constraint {
+    int tag;
+    uint32_t expressions_idx;
+};
+
+struct Expr {
+    uint8_t tag;
+    uint32_t idx[4];
+    double param;
+};
+
+// ConnectedComponent, fiksi/src/graph.rs:121-125 (BTreeSets -> std::set, ascending)
+struct Component {
+    std::set<uint32_t> elements;
+    std::set<uint32_t> constraints;
+};
+
+}  // namespace
+
+struct fxs_system {
+    uint32_t id = 0;
+    std::vector<Element> elements;
+    std::vector<double> variables;
+    std::vector<uint32_t> variable_to_primitive;  // lib.rs:279
+    std::set<uint32_t> fixed_variables;           // lib.rs:283
+    std::vector<Constraint> constraints;
+    std::vector<Expr> expressions;
+    // graph.rs:135-147
+    std::vector<int32_t> element_component;  // 1-based index into `components`, 0 = None
+    std::vector<Component> components;
+};
+
+struct fxs_flat {
+    std::vector<uint32_t> var_off, expr_off, expr_idx;
+    std::vector<double> vars, expr_param;
+    std::vector<uint8_t> var_fixed, expr_tag;
+    std::vector<uint16_t> var_comp, expr_comp;
+    fx_batch batch{};
+};
+
+namespace {
+
+std::atomic<uint32_t> g_system_counter{0};
+
+int valency_of(int tag) { return tag == FXS_POINT_POINT_COINCIDENCE ? 2 : 1; }
+
+// System::add_element, lib.rs:363-407 (+ Graph::add_element, graph.rs:160-176)
+int64_t add_element(fxs_system* s, int tag, const double* vars, int nvars, uint32_t a, uint32_t b) {
+    uint32_t id = (uint32_t)s->elements.size();
+    uint32_t variables_idx = (uint32_t)s->variables.size();
+    for (int i = 0; i < nvars; ++i) {
+        s->variables.push_back(vars[i]);
+        s->variable_to_primitive.push_back(id);
+    }
+    s->element_component.push_back(0);
+    Element e{tag, a, b};
+    if (tag == FXS_LENGTH || tag == FXS_POINT) e.a = variables_idx;
+    s->elements.push_back(e);
+    return id;
+}
+
+// Graph::merge_connected_components, graph.rs:178-225 — including its behaviour of re-labelling
+// only the *incident* elements of an absorbed component.
+void merge_components(fxs_system* s, uint32_t constraint, const uint32_t* els, int n) {
+    int32_t target = 0;
+    size_t size_largest = 0;
+    for (int i = 0; i < n; ++i) {
+        int32_t ci = s->element_component[els[i]];
+        if (ci != 0) {
+            const Component& c = s->components[(size_t)ci - 1];
+            if (c.elements.size() > size_largest) {
+                target = ci;
+                size_largest = c.elements.size();
+            }
+        }
+    }
+    if (target == 0) {
+        s->components.emplace_back();
+        target = (int32_t)s->components.size();
+    }
+    Component tc = std::move(s->components[(size_t)target - 1]);
+    s->components[(size_t)target - 1] = Component();
+    for (int i = 0; i < n; ++i) {
+        int32_t ci = s->element_component[els[i]];
+        if (ci != 0) {
+            Component c = std::move(s->components[(size_t)ci - 1]);
+            s->components[(size_t)ci - 1] = Component();
+            tc.elements.insert(c.elements.begin(), c.elements.end());
+            tc.constraints.insert(c.constraints.begin(), c.constraints.end());
+        } else {
+            tc.elements.insert(els[i]);
+        }
+        s->element_component[els[i]] = target;
+    }
+    tc.constraints.insert(constraint);
+    s->components[(size_t)target - 1] = std::move(tc);
+}
+
+bool is_tag(const fxs_system* s, uint32_t el, int tag) { return el < s->elements.size() && s->elements[el].tag == tag; }
+
+// variables of an element, `T::variable_indices` (elements/mod.rs:296-301,334-339,406-418,470-482)
+int element_variables(const fxs_system* s, uint32_t el, uint32_t out[4]) {
+    const Element& e = s->elements[el];
+    switch (e.tag) {
+        case FXS_LENGTH: out[0] = e.a; return 1;
+        case FXS_POINT: out[0] = e.a; out[1] = e.a + 1; return 2;
+        case FXS_LINE: out[0] = e.a; out[1] = e.a + 1; out[2] = e.b; out[3] = e.b + 1; return 4;
+        case FXS_CIRCLE: out[0] = e.a; out[1] = e.a + 1; out[2] = e.b; return 3;
+    }
+    return 0;
+}
+
+// assemble/mod.rs:81-111: the live components in iteration order, empties skipped
+void live_components(const fxs_system* s, std::vector<const Component*>& out) {
+    out.clear();
+    for (const Component& c : s->components) {
+        if (c.elements.empty()) continue;
+        out.push_back(&c);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fxs_system_new(fxs_system** out) {
+    if (!out) return FX_ERR_INVALID;
+    fxs_system* s = new (std::nothrow) fxs_system();
+    if (!s) return FX_ERR_NOMEM;
+    s->id = g_system_counter.fetch_add(1, std::memory_order_relaxed);
+    *out = s;
+    return FX_OK;
+}
+
+void fxs_system_free(fxs_system* s) { delete s; }
+uint32_t fxs_system_id(const fxs_system* s) { return s ? s->id : 0; }
+uint32_t fxs_num_elements(const fxs_system* s) { return s ? (uint32_t)s->elements.size() : 0; }
+uint32_t fxs_num_constraints(const fxs_system* s) { return s ? (uint32_t)s->constraints.size() : 0; }
+uint32_t fxs_num_variables(const fxs_system* s) { return s ? (uint32_t)s->variables.size() : 0; }
+uint32_t fxs_num_expressions(const fxs_system* s) { return s ? (uint32_t)s->expressions.size() : 0; }
+
+int64_t fxs_length_create(fxs_system* s, double length) {  // elements/mod.rs:280-284
+    if (!s) return FX_ERR_INVALID;
+    return add_element(s, FXS_LENGTH, &length, 1, 0, 0);
+}
+
+int64_t fxs_point_create(fxs_system* s, double x, double y) {  // elements/mod.rs:321-325
+    if (!s) return FX_ERR_INVALID;
+    double v[2] = {x, y};
+    return add_element(s, FXS_POINT, v, 2, 0, 0);
+}
+
+int64_t fxs_line_create(fxs_system* s, uint32_t point1, uint32_t point2) {  // elements/mod.rs:365-382
+    if (!s || !is_tag(s, point1, FXS_POINT) || !is_tag(s, point2, FXS_POINT)) return bfail(FX_ERR_INVALID, "Line::create needs two points");
+    return add_element(s, FXS_LINE, nullptr, 0, s->elements[point1].a, s->elements[point2].a);
+}
+
+int64_t fxs_circle_create(fxs_system* s, uint32_t center, uint32_t radius) {  // elements/mod.rs:437-454
+    if (!s || !is_tag(s, center, FXS_POINT) || !is_tag(s, radius, FXS_LENGTH)) return bfail(FX_ERR_INVALID, "Circle::create needs a point and a length");
+    return add_element(s, FXS_CIRCLE, nullptr, 0, s->elements[center].a, s->elements[radius].a);
+}
+
+int fxs_element_tag_of(const fxs_system* s, uint32_t element) {
+    if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
+    return s->elements[element].tag;
+}
+
+int fxs_element_fix(fxs_system* s, uint32_t element) {  // elements/mod.rs:60-65
+    if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
+    uint32_t v[4];
+    int n = element_variables(s, element, v);
+    for (int i = 0; i < n; ++i) s->fixed_variables.insert(v[i]);
+    return FX_OK;
+}
+
+int fxs_element_unfix(fxs_system* s, uint32_t element) {  // elements/mod.rs:80-85
+    if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
+    uint32_t v[4];
+    int n = element_variables(s, element, v);
+    for (int i = 0; i < n; ++i) s->fixed_variables.erase(v[i]);
+    return FX_OK;
+}
+
+int fxs_element_get_value(const fxs_system* s, uint32_t element, double out[4]) {  // elements/mod.rs:88-100
+    if (!s || !out || element >= s->elements.size()) return FX_ERR_INVALID;
+    uint32_t v[4];
+    int n = element_variables(s, element, v);
+    for (int i = 0; i < n; ++i) out[i] = s->variables[v[i]];
+    return n;
+}
+
+int fxs_point_update_value(fxs_system* s, uint32_t element, double x, double y) {  // elements/mod.rs:560-568
+    if (!s || !is_tag(s, element, FXS_POINT)) return FX_ERR_INVALID;
+    s->variables[s->elements[element].a] = x;
+    s->variables[s->elements[element].a + 1] = y;
+    return FX_OK;
+}
+
+int fxs_length_update_value(fxs_system* s, uint32_t element, double length) {  // elements/mod.rs:572-578
+    if (!s || !is_tag(s, element, FXS_LENGTH)) return FX_ERR_INVALID;
+    s->variables[s->elements[element].a] = length;
+    return FX_OK;
+}
+
+int fxs_constraint_valency(int tag) { return (tag < 0 || tag > FXS_LINE_CIRCLE_TANGENCY) ? FX_ERR_INVALID : valency_of(tag); }
+
+// constraints::*::create, constraints/mod.rs:317-891: graph.add_constraint(valency, incident
+// primitive elements) then System::add_constraint(tag, expressions) (lib.rs:412-445).
+int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32_t n, double param) {
+    if (!s || !el) return FX_ERR_INVALID;
+    static const int kArgs[11][4] = {
+        {FXS_POINT, FXS_POINT, -1, -1},                 // PointPointCoincidence
+        {FXS_POINT, FXS_POINT, -1, -1},                 // PointPointDistance
+        {FXS_POINT, FXS_POINT, FXS_POINT, -1},          // PointPointPointAngle
+        {FXS_POINT, FXS_LINE, -1, -1},                  // PointLineIncidence
+        {FXS_POINT, FXS_LINE, -1, -1},                  // PointLineDistance
+        {FXS_POINT, FXS_CIRCLE, -1, -1},                // PointCircleIncidence
+        {FXS_POINT, FXS_POINT, FXS_POINT, FXS_POINT},   // SegmentSegmentLengthEquality
+        {FXS_LINE, FXS_LINE, -1, -1},                   // LineLineAngle
+        {FXS_LINE, FXS_LINE, -1, -1},                   // LineLineParallelism
+        {FXS_LINE, FXS_LINE, -1, -1},                   // LineLinePerpendicularity
+        {FXS_LINE, FXS_CIRCLE, -1, -1},                 // LineCircleTangency
+    };
+    if (tag < 0 || tag > FXS_LINE_CIRCLE_TANGENCY) return FX_ERR_INVALID;
+    uint32_t want = 0;
+    while (want < 4 && kArgs[tag][want] >= 0) ++want;
+    if (n != want) return bfail(FX_ERR_INVALID, "wrong number of elements");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!is_tag(s, el[i], kArgs[tag][i])) return bfail(FX_ERR_INVALID, "wrong element type");
+    }
+
+    // flatten the handles to variable indices and list the incident primitive elements
+    uint32_t vidx[8];   // element fields in expression order
+    uint32_t inc[6];    // incident primitives
+    int nf = 0, ni = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Element& e = s->elements[el[i]];
+        switch (e.tag) {
+            case FXS_POINT:
+                vidx[nf++] = e.a;
+                // points are passed as their own element id; SegmentSegmentLengthEquality goes
+                // through variable_to_primitive, which is the same id (constraints/mod.rs:650-657)
+                inc[ni++] = s->variable_to_primitive[e.a];
+                break;
+            case FXS_LINE:
+                vidx[nf++] = e.a;
+                vidx[nf++] = e.b;
+                inc[ni++] = s->variable_to_primitive[e.a];
+                inc[ni++] = s->variable_to_primitive[e.b];
+                break;
+            case FXS_CIRCLE:
+                vidx[nf++] = e.a;
+                vidx[nf++] = e.b;
+                inc[ni++] = s->variable_to_primitive[e.a];
+                inc[ni++] = s->variable_to_primitive[e.b];
+                break;
+            default:
+                return FX_ERR_INVALID;
+        }
+    }
+
+    uint32_t cid = (uint32_t)s->constraints.size();
+    merge_components(s, cid, inc, ni);  // graph.rs:235-254
+    uint32_t expressions_idx = (uint32_t)s->expressions.size();
+    s->constraints.push_back(Constraint{tag, expressions_idx});
+
+    auto push = [&](uint8_t etag, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, double p) {
+        Expr x;
+        x.tag = etag;
+        x.idx[0] = i0; x.idx[1] = i1; x.idx[2] = i2; x.idx[3] = i3;
+        x.param = p;
+        s->expressions.push_back(x);
+    };
+    switch (tag) {
+        case FXS_POINT_POINT_COINCIDENCE:  // constraints/mod.rs:335-351: x then y equality
+            push(FX_VARIABLE_VARIABLE_EQUALITY, vidx[0], vidx[1], 0, 0, 0.);
+            push(FX_VARIABLE_VARIABLE_EQUALITY, vidx[0] + 1, vidx[1] + 1, 0, 0, 0.);
+            break;
+        case FXS_POINT_POINT_DISTANCE: push(FX_POINT_POINT_DISTANCE, vidx[0], vidx[1], 0, 0, param); break;
+        case FXS_POINT_POINT_POINT_ANGLE: push(FX_POINT_POINT_POINT_ANGLE, vidx[0], vidx[1], vidx[2], 0, param); break;
+        case FXS_POINT_LINE_INCIDENCE: push(FX_POINT_LINE_INCIDENCE, vidx[0], vidx[1], vidx[2], 0, 0.); break;
+        case FXS_POINT_LINE_DISTANCE: push(FX_POINT_LINE_DISTANCE, vidx[0], vidx[1], vidx[2], 0, param); break;
+        case FXS_POINT_CIRCLE_INCIDENCE: push(FX_POINT_CIRCLE_INCIDENCE, vidx[0], vidx[1], vidx[2], 0, 0.); break;
+        case FXS_SEGMENT_SEGMENT_LENGTH_EQUALITY:
+            push(FX_SEGMENT_SEGMENT_LENGTH_EQUALITY, vidx[0], vidx[1], vidx[2], vidx[3], 0.);
+            break;
+        case FXS_LINE_LINE_ANGLE: push(FX_LINE_LINE_ANGLE, vidx[0], vidx[1], vidx[2], vidx[3], param); break;
+        case FXS_LINE_LINE_PARALLELISM: push(FX_LINE_LINE_PARALLELISM, vidx[0], vidx[1], vidx[2], vidx[3], 0.); break;
+        case FXS_LINE_LINE_PERPENDICULARITY: push(FX_LINE_LINE_PERPENDICULARITY, vidx[0], vidx[1], vidx[2], vidx[3], 0.); break;
+        case FXS_LINE_CIRCLE_TANGENCY: push(FX_LINE_CIRCLE_TANGENCY, vidx[0], vidx[1], vidx[2], vidx[3], 0.); break;
+    }
+    return cid;
+}
+
+int fxs_constraint_tag_of(const fxs_system* s, uint32_t constraint) {
+    if (!s || constraint >= s->constraints.size()) return FX_ERR_INVALID;
+    return s->constraints[constraint].tag;
+}
+
+// ConstraintHandle::update_parameter, constraints/mod.rs:992-1046 (the four parameterised kinds)
+int fxs_constraint_update_parameter(fxs_system* s, uint32_t constraint, double value) {
+    if (!s || constraint >= s->constraints.size()) return FX_ERR_INVALID;
+    const Constraint& c = s->constraints[constraint];
+    switch (c.tag) {
+        case FXS_POINT_POINT_DISTANCE:
+        case FXS_POINT_POINT_POINT_ANGLE:
+        case FXS_POINT_LINE_DISTANCE:
+        case FXS_LINE_LINE_ANGLE:
+            s->expressions[c.expressions_idx].param = value;
+            return FX_OK;
+        default:
+            return FX_ERR_INVALID;
+    }
+}
+
+int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* element_comp, uint16_t* constraint_comp) {
+    if (!s) return FX_ERR_INVALID;
+    std::vector<const Component*> live;
+    live_components(s, live);
+    if (n_components) *n_components = (uint32_t)live.size();
+    if (element_comp) {
+        for (size_t i = 0; i < s->elements.size(); ++i) element_comp[i] = (uint16_t)FX_NO_COMPONENT;
+    }
+    if (constraint_comp) {
+        for (size_t i = 0; i < s->constraints.size(); ++i) constraint_comp[i] = (uint16_t)FX_NO_COMPONENT;
+    }
+    for (size_t c = 0; c < live.size(); ++c) {
+        if (element_comp) for (uint32_t e : live[c]->elements) element_comp[e] = (uint16_t)c;
+        if (constraint_comp) for (uint32_t k : live[c]->constraints) constraint_comp[k] = (uint16_t)c;
+    }
+    return FX_OK;
+}
+
+int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out) {
+    if (!out || (n && !systems)) return FX_ERR_INVALID;
+    fxs_flat* f = new (std::nothrow) fxs_flat();
+    if (!f) return FX_ERR_NOMEM;
+    f->var_off.push_back(0);
+    f->expr_off.push_back(0);
+    std::vector<const Component*> live;
+    for (uint32_t k = 0; k < n; ++k) {
+        const fxs_system* s = systems[k];
+        if (!s) {
+            delete f;
+            return FX_ERR_INVALID;
+        }
+        size_t v0 = f->vars.size(), e0 = f->expr_tag.size();
+        f->vars.insert(f->vars.end(), s->variables.begin(), s->variables.end());
+        f->var_fixed.resize(v0 + s->variables.size(), 0);
+        for (uint32_t v : s->fixed_variables) f->var_fixed[v0 + v] = 1;
+        f->var_comp.resize(v0 + s->variables.size(), (uint16_t)FX_NO_COMPONENT);
+        f->expr_comp.resize(e0 + s->expressions.size(), (uint16_t)FX_NO_COMPONENT);
+        for (const Expr& x : s->expressions) {
+            f->expr_tag.push_back(x.tag);
+            for (int q = 0; q < 4; ++q) f->expr_idx.push_back(x.idx[q]);
+            f->expr_param.push_back(x.param);
+        }
+        // assemble/mod.rs:91-111: a component's variables are those of its elements;
+        // :136-145: its rows are the expressions of its constraints.
+        live_components(s, live);
+        if (live.size() >= 0x7FFF) {
+            delete f;
+            return FX_ERR_TOO_LARGE;
+        }
+        for (size_t c = 0; c < live.size(); ++c) {
+            for (uint32_t e : live[c]->elements) {
+                uint32_t v[4];
+                int nv = element_variables(s, e, v);
+                for (int q = 0; q < nv; ++q) f->var_comp[v0 + v[q]] = (uint16_t)c;
+            }
+            for (uint32_t ci : live[c]->constraints) {
+                const Constraint& con = s->constraints[ci];
+                for (int q = 0; q < valency_of(con.tag); ++q) f->expr_comp[e0 + con.expressions_idx + q] = (uint16_t)c;
+            }
+        }
+        f->var_off.push_back((uint32_t)f->vars.size());
+        f->expr_off.push_back((uint32_t)f->expr_tag.size());
+    }
+    f->batch.n_systems = n;
+    f->batch.var_off = f->var_off.data();
+    f->batch.expr_off = f->expr_off.data();
+    f->batch.vars = f->vars.data();
+    f->batch.var_fixed = f->var_fixed.data();
+    f->batch.expr_tag = f->expr_tag.data();
+    f->batch.expr_idx = f->expr_idx.data();
+    f->batch.expr_param = f->expr_param.data();
+    f->batch.var_comp = f->var_comp.data();
+    f->batch.expr_comp = f->expr_comp.data();
+    *out = f;
+    return FX_OK;
+}
+
+const fx_batch* fxs_flat_batch(const fxs_flat* f) { return f ? &f->batch : nullptr; }
+void fxs_flat_free(fxs_flat* f) { delete f; }
+
+int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) {
+    if (!f || (n && !systems) || n != f->batch.n_systems) return FX_ERR_INVALID;
+    for (uint32_t k = 0; k < n; ++k) {
+        fxs_system* s = systems[k];
+        uint32_t v0 = f->var_off[k], nv = f->var_off[k + 1] - v0;
+        if (!s || nv != s->variables.size()) return FX_ERR_INVALID;
+        std::memcpy(s->variables.data(), f->vars.data() + v0, nv * sizeof(double));
+    }
+    return FX_OK;
+}
+
+int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const fx_solving_opts* opts,
+                      fx_result* results) {
+    fxs_flat* f = nullptr;
+    int rc = fxs_flatten(systems, n, &f);
+    if (rc) return rc;
+    rc = fx_system_solve_batch(ctx, &f->batch, opts, results);
+    if (!rc) rc = fxs_flat_scatter(f, systems, n);
+    fxs_flat_free(f);
+    return rc;
+}
+
+int fxs_system_solve(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result) {
+    fxs_system* one[1] = {s};
+    return fxs_systems_solve(one, 1, ctx, opts, result);
+}
+
+int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* out) {
+    if (!s || !out) return FX_ERR_INVALID;
+    const fxs_system* one[1] = {s};
+    fxs_flat* f = nullptr;
+    int rc = fxs_flatten(one, 1, &f);
+    if (rc) return rc;
+    std::vector<double> r(s->expressions.size() + 1, 0.);
+    rc = fx_constraint_residuals(ctx, &f->batch, r.data());
+    fxs_flat_free(f);
+    if (rc) return rc;
+    for (size_t c = 0; c < s->constraints.size(); ++c) {
+        const Constraint& con = s->constraints[c];
+        if (valency_of(con.tag) > 1) {  // constraints/mod.rs:99-105
+            double sum = 0.;
+            for (int q = 0; q < valency_of(con.tag); ++q) {
+                double v = r[con.expressions_idx + q];
+                sum += v * v;
+            }
+            out[c] = std::sqrt(sum);
+        } else {
+            out[c] = r[con.expressions_idx];
+        }
+    }
+    return FX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Host <-> device plumbing shared by fx_abi.cpp and fx_kernels.hip (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fiksi_amd.h"
+
+namespace fx {
+
+// var_info encoding (one u16 per variable): low 15 bits = component (0x7FFF = none), bit 15 = fixed.
+constexpr uint16_t VAR_COMP_MASK = 0x7FFF;
+constexpr uint16_t VAR_COMP_NONE = 0x7FFF;
+constexpr uint16_t VAR_FIXED_BIT = 0x8000;
+
+// A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
+struct DeviceBatch {
+    uint32_t n_systems, n_vars, n_exprs;
+    uint64_t nnz;
+    // maxima over the batch (host-computed; size LDS and pick the kernel instantiation)
+    uint32_t max_free;   // free variables per component
+    uint32_t max_rows;   // expressions per component
+    uint32_t max_vars;   // variables per System
+    uint32_t max_exprs;  // expressions per System
+
+    uint32_t* var_off;     // [n_systems+1]
+    uint32_t* expr_off;    // [n_systems+1]
+    uint16_t* sys_ncomp;   // [n_systems] number of components
+    double* vars0;         // [n_vars] start values (never written by solves)
+    double* vars;          // [n_vars] last solved values
+    uint16_t* var_info;    // [n_vars]
+    uint8_t* expr_tag;     // [n_exprs]
+    uint16_t* expr_comp;   // [n_exprs]
+    uint16_t* expr_idx;    // [4*n_exprs] system-local element fields (ushort4 per expression)
+    double* expr_param;    // [n_exprs]
+    uint32_t* expr_sys;    // [n_exprs] owning system (for the row-parallel kernels)
+    // CSR Jacobian (fixed pattern): rows global, columns = system-local free rank
+    uint32_t* jrow_ptr;    // [n_exprs+1]
+    uint32_t* jcol;        // [nnz]
+    uint32_t* jslot;       // [n_exprs] 8 x 4-bit: CSR slot of gradient entry e, 0xF = dropped
+    double* jvals;         // [nnz]
+    double* resid;         // [n_exprs]
+    fx_result* results;    // [n_systems]
+    double* sse_unscaled;  // [n_systems] sum r^2 on the solved, unscaled variables
+};
+
+struct LmParams {
+    fx_lm_opts lm;
+    uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation
+};
+
+// Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.
+hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);
+hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream);
+size_t solve_lds_bytes(const DeviceBatch& b);
+
+}  // namespace fx

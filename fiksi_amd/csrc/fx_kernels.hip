@@ -1,0 +1,581 @@
+// HIP kernels for gfx950 (MI355X, wave64). Hand-written; no CUDA dual path.
+//
+//   lm_solve_kernel<N>   one wavefront per System: scale + LCG perturbation (K0), then per connected
+//                        component: residual/Jacobian rows (K1), JtJ + lambda I in LDS via ds_add_f64
+//                        (K3), register-resident Cholesky + triangular solves with v_readlane
+//                        broadcasts (K4), LM control (K5), write-back (K6), unscaled residual check.
+//                        Reference: fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193.
+//   eval_rows_kernel     one thread per expression over the whole batch: residual + CSR Jacobian
+//                        values (subsystem.rs:126-166) — the HBM-streaming kernel.
+//   identity_residual_kernel  calculate_residual with IdentityVariableMap (constraints/mod.rs:96-109).
+//
+// Compiled with -ffp-contract=off: products and sums stay separate exactly as in the reference;
+// fused multiply-adds are written explicitly (fma) where the algorithm is ours (Cholesky).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fx_device.h"
+#include "fx_expr.h"
+
+namespace fx {
+
+// ------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane must be wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double first_lane(double v) {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
+
+// butterfly all-reduce: every lane ends with the same bits (a+b == b+a)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
+
+// ------------------------------------------------------------------------------------------
+// LDS layout of the fused solve kernel (byte offsets, computed on the host)
+// ------------------------------------------------------------------------------------------
+struct SolveLayout {
+    uint32_t vt;   // padded variables per System
+    uint32_t mr;   // padded rows per component
+    uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx, off_colof;
+    uint32_t total;
+};
+
+static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows) {
+    SolveLayout L;
+    L.vt = (max_vars + 7u) & ~7u;
+    L.mr = (max_rows + 7u) & ~7u;
+    if (L.vt == 0) L.vt = 8;
+    if (L.mr == 0) L.mr = 8;
+    uint32_t o = 0;
+    auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
+    L.off_xs = take(2u * L.vt * 8u);
+    L.off_a = take(n_pad * (n_pad + 1u) * 8u);
+    L.off_rhs = take(n_pad * 8u);
+    L.off_g = take(2u * L.mr * 8u * 8u);
+    L.off_r = take(2u * L.mr * 8u);
+    L.off_p = take(L.mr * 8u);
+    L.off_gvar = take(L.mr * 8u * 2u);
+    L.off_gcol = take(L.mr * 8u);
+    L.off_rtag = take(L.mr);
+    L.off_fidx = take(n_pad * 2u);
+    L.off_colof = take(L.vt * 2u);
+    L.total = o;
+    return L;
+}
+
+static uint32_t pad_n(uint32_t max_free) {
+    uint32_t n = (max_free + 7u) & ~7u;
+    return n < 8u ? 8u : n;
+}
+
+size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows).total; }
+
+// ------------------------------------------------------------------------------------------
+// register-resident Cholesky of the N x N SPD matrix held one column per lane
+// ------------------------------------------------------------------------------------------
+// On entry lane j (< N) holds A[i][j], i = 0..N-1, in a[i] (A symmetric, so this is also row j).
+// On exit lane k holds: a[p] = L[k][p] for p < k (row k of L), a[k] = d_k = L[k][k], and
+// a[i] = L[i][k] * d_k for i > k (column k of L, scaled) — both triangular solves then need only
+// wave-uniform broadcasts (v_readlane), never a per-lane register index. invd = 1 / d_lane.
+// Returns false (wave-uniform) when a pivot is not positive and finite.
+template <int N>
+__device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int lane) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double piv = bcast(a[k], k);
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {
+            ok = false;
+            break;
+        }
+        double rs = 1.0 / ::sqrt(piv);
+        double ip = 1.0 / piv;
+        double ljk = a[k] * rs;
+        double mul = (lane > k) ? a[k] * ip : 0.0;  // A_jk / pivot; 0 keeps lanes <= k untouched
+        if (lane >= k) a[k] = ljk;
+        if (lane == k) invd = rs;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            double aik = bcast(a[i], k);  // lane k still holds A_ik = L_ik * d_k
+            a[i] = fma(-aik, mul, a[i]);
+        }
+    }
+    return ok;
+}
+
+// Solves L L^T x = b with the factor layout above. b in `rhs` (lane j holds b_j); returns x_j.
+template <int N>
+__device__ __forceinline__ double chol_solve(const double (&a)[N], double invd, double rhs, int lane) {
+    double acc = rhs;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {  // forward: L y = b, y_k = acc_k / d_k
+        double yk = bcast(acc * invd, k);
+        if (lane > k) acc = fma(-a[k], yk, acc);
+    }
+    // acc_k = y_k d_k. backward: x_k = (y_k d_k - sum_{i>k} (L_ik d_k) x_i) / d_k^2
+    double invd2 = invd * invd;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double xi = bcast(acc * invd2, i);
+        if (lane < i) acc = fma(-a[i], xi, acc);
+    }
+    return acc * invd2;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused per-System solve
+// ------------------------------------------------------------------------------------------
+struct RowEval {
+    double r;
+    double g[8];
+};
+
+template <int N>
+__global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    constexpr int LD = N + 1;
+
+    double* XS = reinterpret_cast<double*>(smem + L.off_xs);       // [2][vt] full variable vectors
+    double* Amat = reinterpret_cast<double*>(smem + L.off_a);      // [N][LD] JtJ (lambda on demand)
+    double* rhsv = reinterpret_cast<double*>(smem + L.off_rhs);    // [N] -Jt r
+    double* G = reinterpret_cast<double*>(smem + L.off_g);         // [2][mr][8] Jacobian rows
+    double* R = reinterpret_cast<double*>(smem + L.off_r);         // [2][mr] residuals
+    double* P = reinterpret_cast<double*>(smem + L.off_p);         // [mr] scaled parameters
+    uint16_t* gvar = reinterpret_cast<uint16_t*>(smem + L.off_gvar);  // [mr][8] variable of entry e
+    int8_t* gcol = reinterpret_cast<int8_t*>(smem + L.off_gcol);      // [mr][8] free column or -1
+    uint8_t* rtag = reinterpret_cast<uint8_t*>(smem + L.off_rtag);    // [mr]
+    uint16_t* fidx = reinterpret_cast<uint16_t*>(smem + L.off_fidx);  // [N] free column -> variable
+    const uint32_t vt = L.vt, mr = L.mr;
+
+    const uint32_t v0 = b.var_off[s], nvt = b.var_off[s + 1] - v0;
+    const uint32_t e0 = b.expr_off[s], net = b.expr_off[s + 1] - e0;
+    const uint32_t ncomp = b.sys_ncomp[s];
+    const fx_lm_opts o = prm.lm;
+
+    // ---- K0a: system scale = sqrt((sum v^2 + sum d^2) / count), summed strictly in reference
+    // order (assemble/mod.rs:32-44, utils.rs:11-33) so the scale is bit-identical. ------------
+    double scale = 1.0, scale_recip = 1.0;
+    if (prm.mode & 1u) {
+        double sum = 0.0;
+        uint32_t count = nvt;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            if (i < nvt) {
+                double v = b.vars0[v0 + i];
+                t = v * v;
+            }
+            uint32_t cnt = min(64u, nvt - base);
+            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+        }
+        for (uint32_t base = 0; base < net; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            bool isd = false;
+            if (i < net) {
+                int tag = b.expr_tag[e0 + i];
+                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
+                if (isd) {
+                    double d = b.expr_param[e0 + i];
+                    t = d * d;
+                }
+            }
+            uint64_t m = __ballot(isd);
+            count += (uint32_t)__popcll(m);
+            uint32_t cnt = min(64u, net - base);
+            // adding the +0.0 of non-distance rows is exact, so the order of real terms is kept
+            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+        }
+        scale = ::sqrt(sum / (double)count);
+        scale_recip = 1.0 / scale;
+    }
+
+    // ---- scaled snapshot of all variables (both halves of XS), output defaults to input ------
+    for (uint32_t i = lane; i < nvt; i += 64) {
+        double v = b.vars0[v0 + i];
+        double xsv = (prm.mode & 1u) ? v * scale_recip : v;
+        XS[i] = xsv;
+        XS[vt + i] = xsv;
+        b.vars[v0 + i] = v;  // fixed / unconstrained variables stay bit-identical
+    }
+    __syncthreads();
+
+    uint32_t rng = 42u;  // one Rng::from_seed(42) per solve, shared by the components (:47)
+    uint32_t tot_accept = 0, tot_trials = 0, last_exit = FX_EXIT_SSE, comps_done = 0;
+    double tot_sse0 = 0.0, tot_sse = 0.0;
+    int16_t* colof = reinterpret_cast<int16_t*>(smem + L.off_colof);  // [vt] variable -> free column
+
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        // ---- free variables of the component, ascending (BTreeSet order, :91-111) -----------
+        uint32_t nfree = 0;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            bool in = false;
+            if (i < nvt) {
+                uint16_t info = b.var_info[v0 + i];
+                in = ((info & VAR_COMP_MASK) == c) && !(info & VAR_FIXED_BIT);
+            }
+            uint64_t m = __ballot(in);
+            uint32_t pos = nfree + (uint32_t)__popcll(m & lanemask_lt(lane));
+            if (i < nvt) colof[i] = in ? (int16_t)pos : (int16_t)-1;
+            if (in && pos < (uint32_t)N) fidx[pos] = (uint16_t)i;
+            nfree += (uint32_t)__popcll(m);
+        }
+        // a component without variables is skipped by the reference (`elements.is_empty()`)
+        bool any_var = false;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            bool in = (i < nvt) && ((b.var_info[v0 + i] & VAR_COMP_MASK) == c);
+            any_var = any_var || (__ballot(in) != 0ull);
+        }
+        if (!uniform(any_var)) continue;
+        __syncthreads();
+
+        // ---- K0b: perturbation of the free variables, 2 LCG draws each, ascending order -----
+        if (prm.mode & 2u) {
+            uint32_t st = rng;
+            for (int k = 0; k < 2 * lane; ++k) st = st * 1664525u + 1013904223u;
+            st = st * 1664525u + 1013904223u;
+            double f1 = (1.0 / 4294967295.0) * (double)st;
+            st = st * 1664525u + 1013904223u;
+            double f2 = (1.0 / 4294967295.0) * (double)st;
+            if ((uint32_t)lane < nfree) {
+                uint32_t vi = fidx[lane];
+                double x = XS[vi];
+                x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                XS[vi] = x;
+                XS[vt + vi] = x;
+            }
+            if (nfree > 0) rng = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)(nfree - 1));
+        }
+
+        // ---- rows of the component: ascending expression id (:139-145) ----------------------
+        uint32_t m_rows = 0;
+        for (uint32_t base = 0; base < net; base += 64) {
+            uint32_t i = base + lane;
+            bool in = (i < net) && (b.expr_comp[e0 + i] == c);
+            uint64_t mk = __ballot(in);
+            uint32_t pos = m_rows + (uint32_t)__popcll(mk & lanemask_lt(lane));
+            if (in) {
+                int tag = b.expr_tag[e0 + i];
+                const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
+                uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+                uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int k = expand_vars(tag, ff, vars8);
+                double prm_e = b.expr_param[e0 + i];
+                if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                rtag[pos] = (uint8_t)tag;
+                P[pos] = prm_e;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                    gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
+                }
+            }
+            m_rows += (uint32_t)__popcll(mk);
+        }
+        __syncthreads();
+
+        // evaluates all rows at XS[buf] into G[buf], R[buf]; returns SSE (wave-uniform)
+        auto eval_rows = [&](int buf) -> double {
+            const double* xs = XS + buf * vt;
+            double part = 0.0;
+            for (uint32_t row = lane; row < m_rows; row += 64) {
+                double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
+                double r = eval_expression<double, true>(rtag[row], v, P[row], g);
+                R[buf * mr + row] = r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
+                part += r * r;
+            }
+            return wave_sum(part);
+        };
+
+        // K3: A = Jt J (full symmetric), rhs = -Jt r, accumulated row by row with LDS f64 atomics
+        // (one row per wave instruction, so the summation order is the row order).
+        auto form_normal = [&](int buf) {
+            for (uint32_t i = lane; i < (uint32_t)(N * LD); i += 64) Amat[i] = 0.0;
+            if (lane < N) rhsv[lane] = 0.0;
+            __syncthreads();
+            const int e1 = lane >> 3, e2 = lane & 7;
+            for (uint32_t row = 0; row < m_rows; ++row) {
+                int c1 = gcol[row * 8 + e1], c2 = gcol[row * 8 + e2];
+                double g1 = G[(buf * mr + row) * 8 + e1], g2 = G[(buf * mr + row) * 8 + e2];
+                if (c1 >= 0 && c2 >= 0) {
+                    __builtin_amdgcn_ds_atomic_fadd_f64(
+                        (__attribute__((address_space(3))) double*)&Amat[c1 * LD + c2], g1 * g2);
+                }
+                if (e2 == 0 && c1 >= 0) {
+                    double rr = -R[buf * mr + row];
+                    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&rhsv[c1], g1 * rr);
+                }
+            }
+            if (lane < N && (uint32_t)lane >= nfree) Amat[lane * LD + lane] = 1.0;  // identity padding
+            __syncthreads();
+        };
+
+        int cur = 0;
+        double sse = eval_rows(0);
+        const double sse_start = sse;
+        form_normal(0);
+        double diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
+        double rhs_l = (lane < N) ? rhsv[lane] : 0.0;
+
+        double lambda = o.lambda0;
+        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
+        bool done = false;
+        if (!(sse == sse) || !(sse < 1.0e300)) {
+            exit_code = FX_EXIT_NAN;
+            done = true;
+        }
+
+        for (uint32_t outer = 0; outer < o.max_outer && !done; ++outer) {
+            if (sse < o.sse_tol) {  // lm.rs:110-112
+                exit_code = FX_EXIT_SSE;
+                break;
+            }
+            for (;;) {  // lambda trials, lm.rs:115-191
+                if (trials >= o.max_trials) {
+                    exit_code = FX_EXIT_TRIAL_CAP;
+                    done = true;
+                    break;
+                }
+                trials += 1;
+                // K4: factor (JtJ + lambda I) and solve for delta
+                double a[N];
+                if (lane < N) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) a[i] = Amat[lane * LD + i];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) a[i] = (i == lane) ? diag + lambda : a[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) a[i] = 0.0;
+                }
+                double invd = 1.0;
+                bool solved = chol_factor<N>(a, invd, lane);
+                if (!uniform(solved)) {  // lm.rs:134-137
+                    lambda *= o.singular_factor;
+                    continue;
+                }
+                double delta = chol_solve<N>(a, invd, rhs_l, lane);
+                if ((uint32_t)lane >= nfree) delta = 0.0;
+                double dn2 = wave_sum(delta * delta);
+                if (!(dn2 == dn2)) {
+                    exit_code = FX_EXIT_NAN;
+                    done = true;
+                    break;
+                }
+                if (dn2 < o.step_tol) {  // lm.rs:139-142
+                    exit_code = FX_EXIT_STEP;
+                    done = true;
+                    break;
+                }
+                // K2/K1 at the trial point (gradient kept: it becomes J on acceptance)
+                const int trial = cur ^ 1;
+                if ((uint32_t)lane < nfree) {
+                    uint32_t vi = fidx[lane];
+                    XS[trial * vt + vi] = XS[cur * vt + vi] + delta;
+                }
+                __syncthreads();
+                double sse_t = eval_rows(trial);
+                if (sse_t < sse) {  // accept, lm.rs:151-186
+                    lambda *= o.accept_factor;
+                    if (lambda < o.lambda_min) lambda = o.lambda_min;
+                    cur = trial;
+                    accepted += 1;
+                    double rel = (sse - sse_t) / sse;
+                    sse = sse_t;  // the returned point's SSE (the reference leaves it stale, quirk Q9)
+                    if (rel <= o.ftol) {
+                        exit_code = FX_EXIT_FTOL;
+                        done = true;
+                        break;
+                    }
+                    __syncthreads();
+                    form_normal(cur);
+                    diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
+                    rhs_l = (lane < N) ? rhsv[lane] : 0.0;
+                    break;
+                } else {  // reject, lm.rs:187-190
+                    if (!(sse_t == sse_t)) {
+                        // NaN trial: the reference would double lambda forever; keep doubling
+                        // under the trial cap, which ends the loop.
+                    }
+                    lambda *= o.reject_factor;
+                }
+            }
+        }
+
+        // ---- K6: write back scale * x for the free variables (:161-166) ----------------------
+        if ((uint32_t)lane < nfree) {
+            uint32_t vi = fidx[lane];
+            double x = XS[cur * vt + vi];
+            b.vars[v0 + vi] = (prm.mode & 1u) ? scale * x : x;
+            // keep both halves equal to the *pre-solve* perturbed snapshot for later components
+            // (quirk Q2): restore the non-current half from the start-of-component value is not
+            // needed because components never share variables.
+        }
+        __syncthreads();
+        tot_accept += accepted;
+        tot_trials += trials;
+        last_exit = exit_code;
+        tot_sse0 += sse_start;
+        tot_sse += sse;
+        comps_done += 1;
+    }
+
+    // ---- post-solve check on unscaled variables (constraints/mod.rs:96-109) ------------------
+    __syncthreads();
+    for (uint32_t i = lane; i < nvt; i += 64) XS[i] = b.vars[v0 + i];
+    __syncthreads();
+    double part = 0.0;
+    for (uint32_t i = lane; i < net; i += 64) {
+        int tag = b.expr_tag[e0 + i];
+        const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
+        uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        expand_vars(tag, ff, vars8);
+        double v[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = XS[vars8[e]];
+        double r = eval_expression<double, false>(tag, v, b.expr_param[e0 + i], g);
+        part += r * r;
+    }
+    double sse_u = wave_sum(part);
+
+    if (lane == 0) {
+        fx_result res;
+        res.accepted = tot_accept;
+        res.trials = tot_trials;
+        res.exit = last_exit;
+        res.ncomp = comps_done;
+        res.scale = scale;
+        res.sse0 = tot_sse0;
+        res.sse = tot_sse;
+        res.sse_unscaled = sse_u;
+        b.results[s] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 / K2 over the whole batch: one thread per expression row
+// ------------------------------------------------------------------------------------------
+// x: n_vars values (vars0 or vars). Rows gather from the owning System's block of x; fixed and
+// free variables alike are read from x (IndexSetVariableMap with the snapshot == x).
+template <bool WANT_J>
+__global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= b.n_exprs) return;
+    uint32_t s = b.expr_sys[row];
+    uint32_t v0 = b.var_off[s];
+    int tag = b.expr_tag[row];
+    ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars(tag, ff, vars8);
+    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
+    double r = eval_expression<double, WANT_J>(tag, v, b.expr_param[row], g);
+    b.resid[row] = r;
+    if (WANT_J) {
+        // scatter the <= 8 partials into the row's CSR slots; duplicates (same variable twice)
+        // are summed, fixed variables dropped (slot 0xF)
+        uint32_t slots = b.jslot[row];
+        uint32_t base = b.jrow_ptr[row];
+        uint32_t cnt = b.jrow_ptr[row + 1] - base;
+        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            uint32_t sl = (slots >> (4 * e)) & 0xFu;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) out[q] += (sl == (uint32_t)q) ? g[e] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if ((uint32_t)q < cnt) b.jvals[base + q] = out[q];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void identity_residual_kernel(DeviceBatch b, const double* __restrict__ x,
+                                                                double* __restrict__ out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= b.n_exprs) return;
+    uint32_t s = b.expr_sys[row];
+    uint32_t v0 = b.var_off[s];
+    int tag = b.expr_tag[row];
+    ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars(tag, ff, vars8);
+    double v[8], g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
+    out[row] = eval_expression<double, false>(tag, v, b.expr_param[row], g);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+template <int N>
+static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lm_solve_kernel<N>, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (b.n_systems == 0) return hipSuccess;
+    uint32_t n = pad_n(b.max_free);
+    SolveLayout L = make_layout(n, b.max_vars, b.max_rows);
+    switch (n) {
+        case 8: return launch_solve_n<8>(b, p, L, stream);
+        case 16: return launch_solve_n<16>(b, p, L, stream);
+        case 24: return launch_solve_n<24>(b, p, L, stream);
+        case 32: return launch_solve_n<32>(b, p, L, stream);
+        case 40: return launch_solve_n<40>(b, p, L, stream);
+        case 48: return launch_solve_n<48>(b, p, L, stream);
+        case 56: return launch_solve_n<56>(b, p, L, stream);
+        case 64: return launch_solve_n<64>(b, p, L, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream) {
+    if (b.n_exprs == 0) return hipSuccess;
+    dim3 grid((b.n_exprs + 255u) / 256u), block(256);
+    if (want_jacobian) {
+        hipLaunchKernelGGL(eval_rows_kernel<true>, grid, block, 0, stream, b, x);
+    } else {
+        hipLaunchKernelGGL(eval_rows_kernel<false>, grid, block, 0, stream, b, x);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream) {
+    if (b.n_exprs == 0) return hipSuccess;
+    dim3 grid((b.n_exprs + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(identity_residual_kernel, grid, block, 0, stream, b, x, out);
+    return hipGetLastError();
+}
+
+}  // namespace fx

@@ -1,0 +1,228 @@
+/*
+ * fiksi_amd — C ABI of the MI355X-native batched geometric-constraint solver.
+ *
+ * Drop-in boundary for fiksi's numeric hot path (reference = endoli/fiksi, paths relative to the
+ * reference tree). The reference has no FFI layer; its internal seams are
+ *
+ *   trait Problem                                   fiksi/src/solve/mod.rs:29-49
+ *   levenberg_marquardt(problem, variables)         fiksi/src/solve/lm.rs:21
+ *   Subsystem::new(vars, exprs, free, expr_ids)     fiksi/src/subsystem.rs:26-38
+ *   assemble::solve(system, opts)  (None arm)       fiksi/src/assemble/mod.rs:46-167
+ *   System::solve(&mut self, SolvingOptions)        fiksi/src/lib.rs:464-466
+ *
+ * and this header exports exactly those, batched over independent Systems:
+ *
+ *   fx_eval_residual_jacobian*  == Problem::calculate_residuals_and_sparse_jacobian (subsystem.rs:126-166)
+ *   fx_eval_residual*           == Problem::calculate_residuals                    (subsystem.rs:93-104)
+ *   fx_lm_solve*                == levenberg_marquardt(Subsystem)                  (lm.rs:21-193)
+ *   fx_system_solve*            == assemble::solve, Decomposer::None, LM           (assemble/mod.rs:46-167)
+ *   fx_constraint_residuals*    == ConstraintHandle::calculate_residual            (constraints/mod.rs:88-110)
+ *
+ * Conventions
+ *  - Plain C: pointers + sizes, no C++/torch types. All functions return 0 (FX_OK) or a negative
+ *    fx_status; nothing throws, aborts or panics across this boundary. A Rust shim turns codes
+ *    into the reference's panics where the reference panics.
+ *  - Every pointer in fx_batch is caller-owned HOST memory; the library copies. Objects created
+ *    by fx_*_create / fx_batch_upload are freed with the matching destroy/free.
+ *  - An fx_ctx is bound to one HIP device + one stream and is NOT thread-safe; use one ctx per
+ *    host thread / GPU. Calls on different contexts are independent.
+ *  - There is no CPU fallback: without a usable gfx950 device fx_ctx_create fails with
+ *    FX_ERR_NO_DEVICE and every compute entry point needs a ctx.
+ */
+#ifndef FIKSI_AMD_H
+#define FIKSI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+typedef enum fx_status {
+    FX_OK = 0,
+    FX_ERR_INVALID = -1,     /* NULL pointer, inconsistent offsets, index out of range, bad tag */
+    FX_ERR_NO_DEVICE = -2,   /* no usable HIP device (no CPU fallback exists)                   */
+    FX_ERR_HIP = -3,         /* a HIP runtime call failed; see fx_last_error                    */
+    FX_ERR_TOO_LARGE = -4,   /* a system exceeds the per-wavefront limits (see FX_MAX_*)        */
+    FX_ERR_NOMEM = -5,
+    FX_ERR_UNSUPPORTED = -6
+} fx_status;
+
+/* Variant order of `enum Expression`, fiksi/src/constraints/expressions.rs:28-40. */
+typedef enum fx_tag {
+    FX_VARIABLE_VARIABLE_EQUALITY = 0,
+    FX_POINT_POINT_DISTANCE = 1,
+    FX_POINT_POINT_POINT_ANGLE = 2,
+    FX_POINT_LINE_INCIDENCE = 3,
+    FX_POINT_LINE_DISTANCE = 4,
+    FX_POINT_CIRCLE_INCIDENCE = 5,
+    FX_SEGMENT_SEGMENT_LENGTH_EQUALITY = 6,
+    FX_LINE_LINE_ANGLE = 7,
+    FX_LINE_LINE_PARALLELISM = 8,
+    FX_LINE_LINE_PERPENDICULARITY = 9,
+    FX_LINE_CIRCLE_TANGENCY = 10,
+    FX_NUM_TAGS = 11
+} fx_tag;
+
+/* Per-wavefront limits of the fused solve kernel (one wavefront per connected component). */
+#define FX_MAX_FREE_VARS 64u   /* free variables (Jacobian columns) per component            */
+#define FX_MAX_ROWS 256u       /* expressions (Jacobian rows) per component                  */
+#define FX_MAX_SYSTEM_VARS 512u/* variables (free + fixed) per System                        */
+#define FX_NO_COMPONENT 0xFFFFu
+
+/*
+ * One batch of independent Systems in flat, struct-of-arrays form == the numeric state of
+ * fiksi::System after building (fiksi/src/lib.rs:256-303): `variables`, `expressions`,
+ * `fixed_variables`, and the connected components of `graph` (fiksi/src/graph.rs).
+ *
+ *  expr_idx: 4 entries per expression = the element fields of the Rust expression struct in
+ *  declaration order, each the SYSTEM-LOCAL variable index of a point's x (y is +1) or of a
+ *  length; unused entries 0. E.g. PointPointDistance {p1, p2}; PointCircleIncidence {point,
+ *  center, radius}; LineCircleTangency {line p1, line p2, center, radius};
+ *  VariableVariableEquality {variable1, variable2}.
+ *  expr_param: `distance` / `angle` of the variant, 0 if none.
+ *  var_comp / expr_comp: index of the connected component (order of
+ *  Graph::connected_components(), empties skipped) the variable's element / the expression's
+ *  constraint belongs to; FX_NO_COMPONENT for variables of unconstrained elements. Either may be
+ *  NULL: then every variable and expression is in component 0.
+ *  Row order inside a component = ascending expression index; column order = ascending index of
+ *  its non-fixed variables (assemble/mod.rs:91-111, :132-146).
+ */
+typedef struct fx_batch {
+    uint32_t n_systems;
+    const uint32_t* var_off;   /* [n_systems+1] offsets into vars / var_fixed / var_comp        */
+    const uint32_t* expr_off;  /* [n_systems+1] offsets into expr_*                             */
+    double* vars;              /* in: start values; out (host entry points): solved values      */
+    const uint8_t* var_fixed;  /* 1 = member of System::fixed_variables                         */
+    const uint8_t* expr_tag;   /* fx_tag                                                        */
+    const uint32_t* expr_idx;  /* [4 * n_exprs]                                                 */
+    const double* expr_param;  /* [n_exprs]                                                     */
+    const uint16_t* var_comp;  /* [n_vars] or NULL                                              */
+    const uint16_t* expr_comp; /* [n_exprs] or NULL                                             */
+} fx_batch;
+
+/* Which linear solve the LM step uses. */
+typedef enum fx_step_solver {
+    FX_STEP_CHOLESKY = 0, /* (JtJ + lambda I) delta = -Jt r, dense Cholesky per wavefront       */
+    FX_STEP_CHOLESKY_REFINED = 1 /* + one step of iterative refinement on the augmented system  */
+} fx_step_solver;
+
+/* Levenberg-Marquardt constants; fx_lm_opts_default() == the literals of lm.rs:108-189. */
+typedef struct fx_lm_opts {
+    double lambda0;       /* 0.5     lm.rs:108                                                  */
+    double sse_tol;       /* 1e-8    lm.rs:110   stop when SSE < sse_tol                        */
+    double step_tol;      /* 1e-12   lm.rs:140   stop when |delta|^2 < step_tol                 */
+    double ftol;          /* 1e-6    lm.rs:164   stop when relative SSE decrease <= ftol        */
+    double accept_factor; /* 0.125   lm.rs:153                                                  */
+    double reject_factor; /* 2       lm.rs:189                                                  */
+    double singular_factor; /* 8     lm.rs:135                                                  */
+    double lambda_min;    /* 1e-50   lm.rs:154-156                                              */
+    uint32_t max_outer;   /* 100     lm.rs:109                                                  */
+    uint32_t max_trials;  /* 4096    (reference: unbounded) total LM trials    */
+    uint32_t solver;      /* fx_step_solver                                                     */
+    uint32_t reserved;
+} fx_lm_opts;
+
+/* SolvingOptions (fiksi/src/lib.rs:205-237). optimizer: 0 = LevenbergMarquardt (only one
+ * implemented on the device); decomposer: 0 = None (only one implemented). */
+typedef struct fx_solving_opts {
+    uint32_t optimizer;
+    uint32_t decomposer;
+    uint32_t perturb;  /* 1 = LCG perturbation, seed 42 (assemble/mod.rs:47,113-124) */
+    uint32_t reserved;
+    fx_lm_opts lm;
+} fx_solving_opts;
+
+/* Why a component's LM loop ended. */
+typedef enum fx_exit {
+    FX_EXIT_SSE = 0,       /* SSE < sse_tol                                                     */
+    FX_EXIT_STEP = 1,      /* |delta|^2 < step_tol                                              */
+    FX_EXIT_FTOL = 2,      /* relative decrease <= ftol                                         */
+    FX_EXIT_MAX_OUTER = 3, /* max_outer accepted steps used                                     */
+    FX_EXIT_TRIAL_CAP = 4, /* max_trials reached (the reference would keep looping)            */
+    FX_EXIT_NAN = 5        /* non-finite SSE or step (the reference would loop forever)        */
+} fx_exit;
+
+/* Per-System outcome. Counters are summed over the System's components. */
+typedef struct fx_result {
+    uint32_t accepted; /* accepted LM steps == Gauss-Newton iterations (one J evaluation each) */
+    uint32_t trials;   /* factor + solve + trial-residual evaluations                          */
+    uint32_t exit;     /* fx_exit of the last component                                        */
+    uint32_t ncomp;    /* components solved                                                    */
+    double scale;      /* system scale (assemble/mod.rs:32-44); 1 for fx_lm_solve*             */
+    double sse0;       /* SSE at the start point (scaled space), summed over components        */
+    double sse;        /* SSE at the returned point (scaled space), summed over components     */
+    double sse_unscaled; /* sum of squared expression residuals on the solved, UNSCALED variables
+                            (constraints/mod.rs:96-109; the bench's `converged` test,
+                            fiksi/benches/fiksi_bench.rs:65-72)                                 */
+} fx_result;
+
+typedef struct fx_ctx fx_ctx;       /* device + stream + scratch                               */
+typedef struct fx_dbatch fx_dbatch; /* a batch resident in HBM (+ its CSR Jacobian structure)  */
+
+/* ---- library / lifecycle ------------------------------------------------------------------ */
+int fx_abi_version(void);
+const char* fx_last_error(void);           /* thread-local text of the last failure           */
+int fx_device_count(int* count);           /* HIP devices visible to this process              */
+int fx_ctx_create(fx_ctx** ctx, int device);
+void fx_ctx_destroy(fx_ctx* ctx);
+int fx_ctx_synchronize(fx_ctx* ctx);
+int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
+
+void fx_lm_opts_default(fx_lm_opts* opts);           /* lm.rs:108-189 literals                */
+void fx_solving_opts_default(fx_solving_opts* opts); /* SolvingOptions::DEFAULT, lib.rs:232-236 */
+
+/* ---- host-side validation / structure (no device needed) ----------------------------------- */
+/* Validate offsets, tags, indices and the per-wavefront limits. */
+int fx_batch_validate(const fx_batch* batch);
+/* CSR structure of the batch Jacobian that fx_eval_residual_jacobian* fills: global rows (row of
+ * system s start at expr_off[s]), system-local free-column indices ascending inside a row,
+ * duplicate columns merged (== TripletMat -> SparseColMat::from_triplet_mat semantics,
+ * solvi/src/sparse_col_mat.rs:690-737, transposed), fixed variables dropped
+ * (subsystem.rs:159-164). row_ptr has n_exprs+1 entries. Pass col_idx == NULL to query nnz. */
+int fx_jacobian_structure(const fx_batch* batch, uint64_t* nnz, uint32_t* row_ptr, uint32_t* col_idx);
+
+/* ---- device-resident batches ---------------------------------------------------------------- */
+int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out);
+void fx_batch_free(fx_ctx* ctx, fx_dbatch* db);
+/* Replace the start values of an uploaded batch (n_vars doubles). */
+int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars);
+/* Copy the current (last solved) values / results back. */
+int fx_batch_get_vars(fx_ctx* ctx, fx_dbatch* db, double* vars);
+int fx_batch_get_results(fx_ctx* ctx, fx_dbatch* db, fx_result* results);
+uint64_t fx_batch_nnz(const fx_dbatch* db);
+
+/* Asynchronous on the ctx stream; inputs are the batch's start values, outputs stay in HBM. */
+int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts);
+int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts);
+/* r (n_exprs) and jvals (nnz) are DEVICE buffers owned by the dbatch; fetch with the getters.
+ * which: 0 = evaluate at the start values, 1 = at the last solved values. */
+int fx_eval_residual_jacobian_device(fx_ctx* ctx, fx_dbatch* db, int which);
+int fx_eval_residual_device(fx_ctx* ctx, fx_dbatch* db, int which);
+int fx_batch_get_residuals(fx_ctx* ctx, fx_dbatch* db, double* r);
+int fx_batch_get_jacobian_values(fx_ctx* ctx, fx_dbatch* db, double* jvals);
+
+/* HIP-event timing on the ctx stream (bench.py: "measured live ... on the stream the kernel is
+ * launched on"). begin/end bracket any number of *_device calls; end synchronizes. */
+int fx_timer_begin(fx_ctx* ctx);
+int fx_timer_end(fx_ctx* ctx, float* milliseconds);
+
+/* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */
+/* == assemble::solve: batch->vars in: unscaled values, out: solved values. results may be NULL. */
+int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results);
+/* == levenberg_marquardt(Subsystem): values used as given (already scaled/perturbed). */
+int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
+/* == Problem::calculate_residuals_and_sparse_jacobian at batch->vars; jvals in
+ * fx_jacobian_structure order (may be NULL for residuals only). */
+int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals);
+/* == calculate_residual of every expression at batch->vars with all variables as given
+ * (IdentityVariableMap, constraints/mod.rs:96-109). */
+int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIKSI_AMD_H */

@@ -1,0 +1,58 @@
+"""Shared builders for the test-suite."""
+import numpy as np
+
+from fiksi_amd import System, constraints, elements
+from fiksi_amd.workloads import LcgVec
+
+
+class Lcg:
+    """Scalar reference LCG (fiksi/src/rand.rs) for test-data generation."""
+
+    def __init__(self, seed):
+        self.v = LcgVec(np.array([seed], dtype=np.uint64))
+
+    def f(self):
+        return float(self.v.next_f64()[0])
+
+    def u(self, lo, hi):
+        return lo + (hi - lo) * self.f()
+
+
+def mixed_sketch(seed: int, fix_some: bool = False) -> System:
+    """A sketch that uses every one of the eleven constraint kinds at least once (plus lines,
+    circles, a shared endpoint so one expression reads the same variable twice, and optionally
+    fixed elements)."""
+    g = Lcg(seed)
+    s = System()
+    P = [elements.Point.create(s, g.u(-10, 10), g.u(-10, 10)) for _ in range(10)]
+    L = [elements.Line.create(s, P[0], P[1]), elements.Line.create(s, P[2], P[3]),
+         elements.Line.create(s, P[4], P[5]), elements.Line.create(s, P[1], P[6])]
+    rad = elements.Length.create(s, g.u(1, 4))
+    circ = elements.Circle.create(s, P[7], rad)
+    if fix_some:
+        P[0].fix(s)
+        rad.fix(s)
+    constraints.PointPointDistance.create(s, P[0], P[1], g.u(2, 8))
+    constraints.PointPointDistance.create(s, P[2], P[3], g.u(2, 8))
+    constraints.PointPointPointAngle.create(s, P[0], P[1], P[2], g.u(-2, 2))
+    constraints.PointLineIncidence.create(s, P[8], L[0])
+    constraints.PointLineDistance.create(s, P[9], L[1], g.u(-3, 3))
+    constraints.PointCircleIncidence.create(s, P[6], circ)
+    # segments share P[1]: the same variable appears twice in one expression
+    constraints.SegmentSegmentLengthEquality.create(s, P[0], P[1], P[1], P[6])
+    constraints.LineLineAngle.create(s, L[0], L[1], g.u(-2, 2))
+    constraints.LineLineParallelism.create(s, L[1], L[2])
+    constraints.LineLinePerpendicularity.create(s, L[2], L[3])
+    constraints.LineCircleTangency.create(s, L[2], circ)
+    constraints.PointPointCoincidence.create(s, P[8], P[9])
+    constraints.PointPointDistance.create(s, P[4], P[7], g.u(2, 8))
+    constraints.PointPointDistance.create(s, P[5], P[3], g.u(2, 8))
+    return s
+
+
+def csr_to_dense(row_ptr, col, vals, rows, ncols):
+    d = np.zeros((rows, ncols))
+    for r in range(rows):
+        for p in range(int(row_ptr[r]), int(row_ptr[r + 1])):
+            d[r, int(col[p])] += vals[p]
+    return d

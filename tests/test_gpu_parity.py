@@ -1,0 +1,216 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on identical inputs. Bit-exact where the arithmetic is IEEE-deterministic (scale,
+perturbation, Jacobian values, non-angle residuals); stated tolerances elsewhere."""
+import numpy as np
+import pytest
+
+from helpers import mixed_sketch
+
+pytestmark = pytest.mark.gpu
+
+ANGLE_TAGS = (2, 7)  # residuals that go through atan2 (device libm vs glibc): ulp-level differences
+
+
+def _flatten(fiksi, systems):
+    return fiksi.flatten(systems)
+
+
+def test_context_reports_gfx950(ctx):
+    assert "gfx950" in ctx.name()
+
+
+def test_k1_residual_jacobian_ring16_bit_exact(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(512)
+    r, (rp, ci, vals) = ctx.eval_residual_jacobian(b)
+    r_o, (rp_o, ci_o, vals_o) = oracle.eval_batch(b)
+    assert np.array_equal(rp.astype(np.int64), rp_o)
+    assert np.array_equal(ci.astype(np.int32), ci_o)
+    assert np.array_equal(vals, vals_o)  # gradients never touch atan2: bit-exact
+    ang = np.isin(b["expr_tag"], ANGLE_TAGS)
+    assert np.array_equal(r[~ang], r_o[~ang])
+    assert np.max(np.abs(r[ang] - r_o[ang])) <= 4e-15  # |angle| <= pi, a few ulp of atan2
+
+
+def test_k1_all_eleven_expression_kinds(fiksi, oracle, ctx):
+    systems = [mixed_sketch(seed, fix_some=(seed % 2 == 1)) for seed in range(40)]
+    b = _flatten(fiksi, systems)
+    assert set(np.unique(b["expr_tag"])) == set(range(11))
+    r, (rp, ci, vals) = ctx.eval_residual_jacobian(b)
+    r_o, (rp_o, ci_o, vals_o) = oracle.eval_batch(b)
+    assert np.array_equal(rp.astype(np.int64), rp_o)
+    assert np.array_equal(ci.astype(np.int32), ci_o)
+    assert np.array_equal(vals, vals_o)
+    ang = np.isin(b["expr_tag"], ANGLE_TAGS)
+    assert np.array_equal(r[~ang], r_o[~ang])
+    assert np.max(np.abs(r[ang] - r_o[ang])) <= 4e-15
+
+
+def test_residual_only_kernel_matches_jacobian_kernel(fiksi, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(128)
+    r1, _ = ctx.eval_residual_jacobian(b, want_jacobian=True)
+    r2, _ = ctx.eval_residual_jacobian(b, want_jacobian=False)
+    assert np.array_equal(r1, r2)
+
+
+def test_scale_and_perturbation_bit_exact(fiksi, oracle, ctx):
+    """K0: with zero LM iterations the output is scale * perturbed(x / scale)."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.concat([workloads.ring16(64), workloads.hinged_triangles(3, 11), workloads.quadrilateral()])
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(perturb=True, max_outer=0))
+    scale = oracle.system_scale_batch(b)
+    assert np.array_equal(res["scale"], scale)
+    draws = oracle.rng_f64(42, 2 * 64)
+    for s in range(len(scale)):
+        v0, v1 = int(b["var_off"][s]), int(b["var_off"][s + 1])
+        x = b["vars"][v0:v1] * (1.0 / scale[s])
+        k = np.arange(v1 - v0)
+        x = x + (x * (1.0 / 8196.0) * draws[2 * k] + (1.0 / 65568.0) * draws[2 * k + 1])
+        assert np.array_equal(v[v0:v1], scale[s] * x), f"system {s}"
+
+
+def _compare_solves(res, res_o, v, v_o, b, oracle, min_same=0.97):
+    same = res["accepted"] == res_o["accepted"]
+    assert same.mean() >= min_same, f"accepted-step counts agree for {same.mean():.3%}"
+    assert (res["exit"][same] == res_o["exit"][same]).mean() >= 0.99
+    # final SSE (scaled space): |sse_gpu - sse_ref| <= 1e-10 + 1e-6 * sse_ref on the systems that took
+    # the same path
+    d = np.abs(res["sse"][same] - res_o["sse"][same])
+    assert np.all(d <= 1e-10 + 1e-6 * np.abs(res_o["sse"][same]))
+    # per-expression unscaled residuals at the solution
+    r = oracle.residuals_batch(b, v)
+    r_o = oracle.residuals_batch(b, v_o)
+    n = len(res)
+    for s in np.nonzero(same)[0][:2000]:
+        e0, e1 = int(b["expr_off"][s]), int(b["expr_off"][s + 1])
+        tol = 1e-7 * max(1.0, res_o["scale"][s]) + 1e-4 * np.sqrt(res_o["sse"][s])
+        assert np.max(np.abs(np.abs(r[e0:e1]) - np.abs(r_o[e0:e1]))) <= tol, f"system {s} of {n}"
+
+
+def test_system_solve_ring16_matches_oracle(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(2048)
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    _compare_solves(res, res_o, v, v_o, b, oracle)
+    # the kernel's own unscaled SSE equals a recomputation from its output
+    r = oracle.residuals_batch(b, v).reshape(len(res), -1)
+    assert np.allclose(res["sse_unscaled"], (r * r).sum(1), rtol=1e-9, atol=1e-18)
+
+
+def test_gauge_fixed_positions_match_oracle(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(512, fix_gauge=True)
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    same = (res["accepted"] == res_o["accepted"]) & (res_o["sse"] < 1e-8)
+    assert same.mean() > 0.9
+    vv, vo = v.reshape(len(res), -1), v_o.reshape(len(res), -1)
+    err = np.max(np.abs(vv - vo), axis=1)
+    assert np.all(err[same] <= 1e-6 * res_o["scale"][same])
+    # fixed points are bit-identical to the input (fiksi/src/tests/fixed.rs:36-40)
+    assert np.array_equal(vv[:, :4], b["vars"].reshape(len(res), -1)[:, :4])
+
+
+def test_lm_solve_l2_matches_oracle(fiksi, oracle, ctx):
+    """L2 boundary: levenberg_marquardt(Subsystem) on values as given (no scale, no perturbation)."""
+    from fiksi_amd import workloads
+
+    b = workloads.hinged_triangles(4, 11)
+    v, res = ctx.lm_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=0)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.array_equal(res["trials"], res_o["trials"])
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+    assert np.all(res["scale"] == 1.0)
+
+
+def test_inconsistent_targets_exit_like_oracle(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.concat([workloads.quadrilateral(False), workloads.ring16(256, inconsistent=True)])
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    # cfg1's impossible quadrilateral: 18 accepted steps, 69 trials, ftol exit, SSE 1.1214
+    assert res["accepted"][0] == res_o["accepted"][0] == 18
+    assert res["trials"][0] == res_o["trials"][0] == 69
+    assert res["exit"][0] == res_o["exit"][0] == 2
+    assert abs(res["sse"][0] - res_o["sse"][0]) < 1e-9
+    same = res["accepted"] == res_o["accepted"]
+    assert same.mean() > 0.9
+    assert np.allclose(res["sse"][same], res_o["sse"][same], rtol=1e-6, atol=1e-10)
+
+
+def test_mixed_sketches_and_multi_component(fiksi, oracle, ctx):
+    systems = [mixed_sketch(100 + seed, fix_some=(seed % 3 == 0)) for seed in range(64)]
+    b = _flatten(fiksi, systems)
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    assert np.array_equal(res["ncomp"], res_o["ncomp"])
+    assert np.array_equal(res["scale"], res_o["scale"])
+    # these sketches are arbitrary (often infeasible): compare what is path-independent enough
+    same = (res["accepted"] == res_o["accepted"]) & (res["trials"] == res_o["trials"])
+    assert same.mean() > 0.5
+    assert np.allclose(res["sse"][same], res_o["sse"][same], rtol=1e-5, atol=1e-9)
+    # fixed variables never move
+    fx = b["var_fixed"] == 1
+    assert np.array_equal(v[fx], b["vars"][fx])
+
+
+def test_device_batch_resolve_is_repeatable(fiksi, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(300)
+    db = ctx.upload(b)
+    db.system_solve()
+    v1, r1 = db.get_vars(), db.get_results()
+    db.system_solve()
+    v2, r2 = db.get_vars(), db.get_results()
+    assert np.array_equal(v1, v2) and np.array_equal(r1, r2)  # deterministic, start values untouched
+    db.free()
+
+
+def test_empty_and_ragged_batches(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    empty = {k: np.zeros(0, dtype=v.dtype) for k, v in workloads.quadrilateral().items()}
+    empty["var_off"] = np.zeros(1, dtype=np.uint32)
+    empty["expr_off"] = np.zeros(1, dtype=np.uint32)
+    v, res = ctx.system_solve_batch(empty)
+    assert len(v) == 0 and len(res) == 0
+    # a system with variables but no expressions, one with a single constraint, one bigger
+    s0 = fiksi.System()
+    fiksi.elements.Point.create(s0, 1.0, 2.0)
+    s1 = fiksi.System()
+    a = fiksi.elements.Point.create(s1, 0.0, 0.0)
+    c = fiksi.elements.Point.create(s1, 1.0, 0.5)
+    fiksi.constraints.PointPointCoincidence.create(s1, a, c)
+    b = workloads.concat([fiksi.flatten([s0, s1]), workloads.hinged_triangles(1, 15), workloads.ring16(3)])
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3)
+    assert np.array_equal(v[:2], b["vars"][:2])  # unconstrained element untouched
+    assert res["ncomp"][0] == 0 and res_o["ncomp"][0] == 0
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+
+
+def test_limits_are_reported_not_crashed(fiksi, ctx):
+    from fiksi_amd import workloads
+    from fiksi_amd._lib import FiksiError
+
+    big = workloads.hinged_triangles(1, 40)  # 162 variables > 64 free per component
+    with pytest.raises(FiksiError) as e:
+        ctx.system_solve_batch(big)
+    assert e.value.code == -4
+    bad = workloads.quadrilateral()
+    bad["expr_idx"] = bad["expr_idx"].copy()
+    bad["expr_idx"][0] = 99
+    with pytest.raises(FiksiError) as e:
+        ctx.system_solve_batch(bad)
+    assert e.value.code == -1
