@@ -42,8 +42,9 @@ def ring16(n_systems: int, seed0: int = 1000, inconsistent: bool = False, fix_ga
     (angle jitter, radius jitter) per point, then one noise draw per coordinate, then (only if
     ``inconsistent``) one draw per distance target.
 
-    ``fix_gauge`` fixes points 0 and 1 (fiksi fixes whole elements), which removes the rigid-motion
-    null space so that solved positions are directly comparable.
+    ``fix_gauge`` fixes points 0 and 1 (fiksi fixes whole elements) at their ground-truth
+    positions, which removes the rigid-motion null space (solved positions become directly
+    comparable) while keeping the targets consistent.
     """
     n = int(n_systems)
     P = 16
@@ -99,6 +100,7 @@ def ring16(n_systems: int, seed0: int = 1000, inconsistent: bool = False, fix_ga
     var_fixed = np.zeros((n, 2 * P), dtype=np.uint8)
     if fix_gauge:
         var_fixed[:, 0:4] = 1
+        start[:, 0:2, :] = truth[:, 0:2, :]
     return {
         "var_off": (np.arange(n + 1, dtype=np.uint64) * (2 * P)).astype(np.uint32),
         "expr_off": (np.arange(n + 1, dtype=np.uint64) * m).astype(np.uint32),
