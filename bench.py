@@ -73,7 +73,7 @@ def main() -> int:
 
     graft.build()
     import fiksi_amd
-    from fiksi_amd import abi, workloads
+    from fiksi_amd import abi, distributed, workloads
 
     dist = None
     torch = None
@@ -87,7 +87,7 @@ def main() -> int:
 
     # ---- inputs: this rank's shard (weak scaling: a full cfg3 batch per GPU, distinct seeds) ----
     n_sys = args.systems
-    batch = workloads.ring16(n_sys, seed0=1000 + rank * n_sys)
+    batch = workloads.ring16(n_sys, seed0=distributed.rank_seed(1000, rank, n_sys))
     ctx = fiksi_amd.Context(local_rank)
     db = ctx.upload(batch)
     opts = abi.solving_opts()  # SolvingOptions::DEFAULT + the reference LM constants
@@ -116,15 +116,8 @@ def main() -> int:
     accepted = int(res["accepted"].sum())
     trials = int(res["trials"].sum())
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([converged, accepted, trials, n_sys], dtype=torch.int64, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        converged, accepted, trials, total_sys = (int(x) for x in c.tolist())
-    else:
-        total_sys = n_sys
+    elapsed, (converged, accepted, trials, total_sys) = distributed.reduce_throughput(
+        dist, elapsed, [converged, accepted, trials, n_sys], device="cuda" if dist is not None else None)
 
     # ---- K1 (Jacobian assembly) on the same resident batch, HIP-event timed ----------------
     k1_launches = max(args.steps, 10)
@@ -219,8 +212,10 @@ def cpu_baseline(batch, sample: int):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a 1-GPU box's CPU share is 16 cores; FIKSI_CPU_THREADS overrides
+    cores = int(os.environ.get("FIKSI_CPU_THREADS", min(cores, 16)))
     n_total = len(batch["var_off"]) - 1
-    n = sample if sample > 0 else min(n_total, 25_000 * cores)  # ~10-30 s of CPU work in total
+    n = sample if sample > 0 else n_total  # 100k systems ~ 5-10 CPU-seconds of reference-algorithm work
     sub = workloads.shard(batch, 0, max(1, n_total // n)) if n < n_total else batch
     n = len(sub["var_off"]) - 1
     t = time.perf_counter()

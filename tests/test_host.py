@@ -1,0 +1,282 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the headers declare,
+batch validation, the CSR Jacobian structure, the System builder mirror (incl. connected components
+and the reference's quirks), and the N>1 sharding / reduction path under gloo. No device compute."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fxs?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(fiksi):
+    from fiksi_amd import _lib
+
+    names = _declared("fiksi_amd.h") + _declared("fiksi_amd_builder.h")
+    assert len(names) > 50
+    bound = {n for n, _, _ in _lib.SIGNATURES}
+    for n in names:
+        assert hasattr(_lib.lib, n), f"libfiksi_amd.so does not export {n}"
+        assert n in bound, f"{n} is declared in include/ but has no ctypes signature"
+    assert _lib.lib.fx_abi_version() == 1
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(fiksi):
+    from fiksi_amd import abi
+    from fiksi_amd._lib import FiksiError
+
+    if abi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(FiksiError) as e:
+        abi.Context(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under fiksi_amd/ or include/ references it."""
+    for base in ("fiksi_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                    text = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert "oracle" not in text.lower().replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_default_options_are_the_reference_literals(fiksi):
+    """lm.rs:108-189 and SolvingOptions::DEFAULT (lib.rs:232-236)."""
+    from fiksi_amd import abi
+
+    o = abi.solving_opts()
+    assert (o.optimizer, o.decomposer, o.perturb) == (0, 0, 1)
+    lm = o.lm
+    assert (lm.lambda0, lm.sse_tol, lm.step_tol, lm.ftol) == (0.5, 1e-8, 1e-12, 1e-6)
+    assert (lm.accept_factor, lm.reject_factor, lm.singular_factor, lm.lambda_min) == (0.125, 2.0, 8.0, 1e-50)
+    assert lm.max_outer == 100
+    d = fiksi.SolvingOptions.DEFAULT
+    assert d.optimizer == fiksi.Optimizer.LevenbergMarquardt and d.decomposer == fiksi.Decomposer.NONE and d.perturb
+
+
+def test_validate_rejects_bad_batches(fiksi):
+    from fiksi_amd import abi, workloads
+    from fiksi_amd._lib import FiksiError
+
+    good = workloads.ring16(4)
+    abi.validate(good)
+    bad = dict(good)
+    bad["expr_tag"] = good["expr_tag"].copy()
+    bad["expr_tag"][3] = 11
+    with pytest.raises(FiksiError) as e:
+        abi.validate(bad)
+    assert e.value.code == -1
+    bad = dict(good)
+    bad["expr_idx"] = good["expr_idx"].copy()
+    bad["expr_idx"][5] = 31  # a point at 31 needs variable 32
+    with pytest.raises(FiksiError):
+        abi.validate(bad)
+    bad = dict(good)
+    bad["var_off"] = good["var_off"].copy()
+    bad["var_off"][2] = bad["var_off"][1] - 1
+    with pytest.raises(FiksiError):
+        abi.validate(bad)
+    with pytest.raises(FiksiError) as e:
+        abi.validate(workloads.hinged_triangles(1, 40))
+    assert e.value.code == -4
+
+
+def test_jacobian_structure_matches_reference_assembly(fiksi, oracle):
+    """fx_jacobian_structure == COO triplets -> from_triplet_mat (sorted, duplicates merged, fixed
+    variables dropped), transposed to rows (subsystem.rs:126-166, sparse_col_mat.rs:690-737)."""
+    from fiksi_amd import abi, workloads
+    from helpers import mixed_sketch
+
+    batches = [workloads.ring16(5), workloads.ring16(3, fix_gauge=True), workloads.hinged_triangles(2, 11),
+               fiksi.flatten([mixed_sketch(s, fix_some=bool(s % 2)) for s in range(12)])]
+    for b in batches:
+        row_ptr, col = abi.jacobian_structure(b)
+        _, (rp_o, ci_o, _) = oracle.eval_batch(b)
+        assert np.array_equal(row_ptr.astype(np.int64), rp_o)
+        assert np.array_equal(col.astype(np.int32), ci_o)
+    row_ptr, col = abi.jacobian_structure(workloads.ring16(1))
+    assert row_ptr[-1] == workloads.RING16_NNZ == 144
+
+
+def test_builder_flatten_equals_direct_generator(fiksi):
+    """The builder mirror produces the same flat arrays as the vectorised workload generator."""
+    from fiksi_amd import System, constraints, elements, workloads
+
+    b = workloads.hinged_triangles(1, 3)
+    s = System()
+    hinge = elements.Point.create(s, 0., 0.)
+    for t in range(3):
+        p1 = elements.Point.create(s, -1., float(t))
+        p2 = elements.Point.create(s, 1., float(t))
+        constraints.PointPointDistance.create(s, hinge, p1, 2.)
+        constraints.PointPointDistance.create(s, hinge, p2, 2.)
+        constraints.PointPointDistance.create(s, p1, p2, 3.)
+    f = s.flatten()
+    for k in b:
+        assert np.array_equal(f[k], b[k]), k
+
+
+def test_builder_handles_and_values(fiksi):
+    from fiksi_amd import System, constraints, elements
+
+    s, other = System(), System()
+    assert other.id == s.id + 1  # global counter, lib.rs:308-309
+    p = elements.Point.create(s, 1.5, -2.0)
+    r = elements.Length.create(s, 3.0)
+    q = elements.Point.create(s, 0.0, 1.0)
+    ln = elements.Line.create(s, p, q)
+    c = elements.Circle.create(s, q, r)
+    assert p.get_value(s) == (1.5, -2.0) and r.get_value(s) == 3.0
+    assert ln.get_value(s) == (1.5, -2.0, 0.0, 1.0) and c.get_value(s) == (0.0, 1.0, 3.0)
+    p.update_value(s, 4.0, 5.0)
+    r.update_value(s, 7.0)
+    assert p.get_value(s) == (4.0, 5.0) and c.get_value(s) == (0.0, 1.0, 7.0)
+    with pytest.raises(AssertionError):  # foreign system: the reference panics (elements/mod.rs:90-93)
+        p.get_value(other)
+    with pytest.raises(TypeError):  # what Rust's type system rejects
+        elements.Line.create(s, p, r)
+    with pytest.raises(TypeError):
+        constraints.PointLineIncidence.create(s, p, q)
+    d = constraints.PointPointDistance.create(s, p, q, 2.0)
+    d.update_parameter(s, 9.0)
+    assert s.flatten()["expr_param"][0] == 9.0
+    co = constraints.PointPointCoincidence.create(s, p, q)
+    with pytest.raises(TypeError):
+        co.update_parameter(s, 1.0)
+    assert [h.id for h in s.get_element_handles()] == [0, 1, 2, 3, 4]
+    assert [h.id for h in s.get_constraint_handles()] == [0, 1]
+    f = s.flatten()
+    assert f["expr_tag"].tolist() == [1, 0, 0]  # coincidence = two VariableVariableEquality rows
+    assert f["expr_idx"].reshape(-1, 4)[1:, :2].tolist() == [[0, 3], [1, 4]]
+
+
+def test_fix_unfix_compound_elements(fiksi):
+    """elements/mod.rs:47-85: fixing a Line fixes its points' variables; unfix frees them."""
+    from fiksi_amd import System, elements
+
+    s = System()
+    a = elements.Point.create(s, 0., 0.)
+    b = elements.Point.create(s, 1., 0.)
+    r = elements.Length.create(s, 2.)
+    ln = elements.Line.create(s, a, b)
+    c = elements.Circle.create(s, a, r)
+    ln.fix(s)
+    assert s.flatten()["var_fixed"].tolist() == [1, 1, 1, 1, 0]
+    c.fix(s)
+    assert s.flatten()["var_fixed"].tolist() == [1, 1, 1, 1, 1]
+    a.unfix(s)
+    assert s.flatten()["var_fixed"].tolist() == [0, 0, 1, 1, 1]
+
+
+def test_connected_components(fiksi):
+    """graph.rs:178-258: components merge as constraints are added; unconstrained elements have none."""
+    from fiksi_amd import System, abi, constraints, elements
+
+    s = System()
+    p = [elements.Point.create(s, float(i), 0.5 * i) for i in range(6)]
+    constraints.PointPointDistance.create(s, p[0], p[1], 1.0)
+    c2 = constraints.PointPointDistance.create(s, p[2], p[3], 1.2)
+    n, ec, cc = s.components()
+    assert n == 2 and ec.tolist() == [0, 0, 1, 1, abi.NO_COMPONENT, abi.NO_COMPONENT] and cc.tolist() == [0, 1]
+    f = s.flatten()
+    assert f["var_comp"].tolist() == [0, 0, 0, 0, 1, 1, 1, 1] + [abi.NO_COMPONENT] * 4
+    constraints.PointPointDistance.create(s, p[1], p[2], 1.0)  # merges both
+    n, ec, cc = s.components()
+    assert n == 1 and cc.tolist() == [0, 0, 0]
+    # lines and circles own no variables and join no component themselves (constraints register
+    # the primitives, constraints/mod.rs:493-500)
+    ln = elements.Line.create(s, p[4], p[5])
+    constraints.PointLineIncidence.create(s, p[0], ln)
+    n, ec, cc = s.components()
+    assert n == 1 and ec[:6].tolist() == [0] * 6 and ec[6] == abi.NO_COMPONENT
+    assert c2.id == 1
+
+
+def test_component_merge_quirk_q1(fiksi):
+    """graph.rs:211-222 only re-labels the incident elements of an absorbed component: a later
+    constraint on a stale element opens a new component. The mirror reproduces it."""
+    from fiksi_amd import System, constraints, elements
+
+    s = System()
+    a, b, c, d, e = (elements.Point.create(s, float(i), 0.) for i in range(5))
+    constraints.PointPointDistance.create(s, a, b, 1.)   # comp X = {a, b}
+    constraints.PointPointDistance.create(s, c, d, 1.)   # comp Y = {c, d}
+    constraints.PointPointDistance.create(s, a, c, 1.)   # X absorbs Y; d keeps the stale label Y
+    constraints.PointPointDistance.create(s, d, e, 1.)   # d's stale, now empty, label: a NEW component
+    n, ec, cc = s.components()
+    assert n == 2
+    # the new component holds only e; d stays an element of the first one, so inside the new
+    # component d's variables are not free (treated as fixed), exactly as in the reference
+    assert ec.tolist() == [0, 0, 0, 0, 1]
+    assert cc.tolist() == [0, 0, 0, 1]
+    f = s.flatten()
+    assert f["var_comp"].tolist() == [0] * 8 + [1, 1] and f["expr_comp"].tolist() == [0, 0, 0, 1]
+
+
+def test_shard_and_concat_roundtrip(fiksi):
+    from fiksi_amd import workloads
+
+    b = workloads.concat([workloads.ring16(7), workloads.hinged_triangles(3, 5), workloads.quadrilateral()])
+    parts = [workloads.shard(b, r, 3) for r in range(3)]
+    assert sum(len(p["var_off"]) - 1 for p in parts) == 11
+    back = workloads.concat(parts)
+    for k in b:
+        assert np.array_equal(back[k], b[k]), k
+
+
+_GLOO_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch.distributed as dist
+from fiksi_amd import distributed, workloads
+from oracle import oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+n = 24
+b = workloads.ring16(n, seed0=distributed.rank_seed(1000, rank, n))
+v, res = O.solve_batch(b, mode=3)          # stand-in for the device solve on a CPU-only host
+conv = int((res["sse"] < 1e-8).sum())
+elapsed = 1.0 + rank
+el, tot = distributed.reduce_throughput(dist, elapsed, [conv, int(res["accepted"].sum()), n])
+if rank == 0:
+    print(json.dumps({"elapsed": el, "tot": tot}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_sharding_and_reduction_gloo(fiksi, oracle, tmp_path):
+    """The N>1 path of bench.py on CPU: two ranks, disjoint seed ranges, MAX time / SUM counters."""
+    from fiksi_amd import distributed, workloads
+
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+         "127.0.0.1", "--master-port", "29631", str(script), ROOT],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    got = json.loads(line)
+    # the same 48 systems solved in one process
+    n = 24
+    both = workloads.concat([workloads.ring16(n, seed0=distributed.rank_seed(1000, r, n)) for r in range(2)])
+    assert np.array_equal(both["vars"], workloads.ring16(2 * n)["vars"])  # shards tile the global seed range
+    _, res = oracle.solve_batch(both, mode=3)
+    assert got["elapsed"] == 2.0
+    assert got["tot"] == [int((res["sse"] < 1e-8).sum()), int(res["accepted"].sum()), 2 * n]
