@@ -218,6 +218,13 @@ class DeviceBatch:
         o = opts if opts is not None else lm_opts()
         check(lib.fx_lm_solve_device(self.ctx.handle, self._h, C.byref(o)), "fx_lm_solve_device")
 
+    def phase_cycles(self, opts: Optional[FxSolvingOpts] = None):
+        """Diagnostic: shader cycles per phase of the fused kernel, summed over wavefronts."""
+        o = opts if opts is not None else solving_opts()
+        c = (C.c_uint64 * 6)()
+        check(lib.fx_debug_phase_cycles(self.ctx.handle, self._h, C.byref(o), c), "fx_debug_phase_cycles")
+        return dict(zip(("setup", "eval", "form", "factor", "solve", "tail"), [int(x) for x in c]))
+
     def eval_residual_jacobian(self, which: int = 0):
         check(lib.fx_eval_residual_jacobian_device(self.ctx.handle, self._h, which), "fx_eval_residual_jacobian_device")
 

@@ -468,6 +468,29 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     return FX_OK;
 }
 
+// Diagnostic (not part of the drop-in surface): runs the stamped build of the fused kernel once and
+// returns the shader cycles summed over all wavefronts for {setup, eval, form, factor, solve, tail}.
+int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, uint64_t cycles[6]) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !cycles) return fail(FX_ERR_INVALID, "bad argument");
+    fx_solving_opts o;
+    if (opts) o = *opts; else fx_solving_opts_default(&o);
+    unsigned long long* dev = nullptr;
+    FX_HIP(hipMalloc((void**)&dev, 6 * sizeof(unsigned long long)));
+    FX_HIP(hipMemsetAsync(dev, 0, 6 * sizeof(unsigned long long), ctx->stream));
+    fx::LmParams p;
+    p.lm = o.lm;
+    p.mode = 1u | (o.perturb ? 2u : 0u);
+    p.prof = dev;
+    hipError_t e = fx::launch_solve(db->d, p, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(cycles, dev, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(FX_ERR_HIP, "phase profile failed: %s", hipGetErrorString(e));
+    return FX_OK;
+}
+
 int fx_eval_residual_jacobian_device(fx_ctx* ctx, fx_dbatch* db, int which) {
     int rc = bind(ctx);
     if (rc) return rc;

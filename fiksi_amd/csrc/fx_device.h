@@ -46,6 +46,7 @@ struct DeviceBatch {
 struct LmParams {
     fx_lm_opts lm;
     uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation
+    unsigned long long* prof = nullptr;  // diagnostic build only: 6 per-phase cycle sums
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

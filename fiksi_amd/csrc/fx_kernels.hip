@@ -34,11 +34,21 @@ __device__ __forceinline__ double first_lane(double v) {
 }
 __device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
-// butterfly all-reduce: every lane ends with the same bits (a+b == b+a)
+// Sum over the 64 lanes, result wave-uniform (identical bits in every lane). Within each row of
+// 16 lanes a DPP butterfly (quad_perm, row_half_mirror, row_mirror: no LDS traffic), then the four
+// row sums are combined through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
 
@@ -61,7 +71,7 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     uint32_t o = 0;
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
     L.off_xs = take(2u * L.vt * 8u);
-    L.off_a = take(n_pad * (n_pad + 1u) * 8u);
+    L.off_a = take(n_pad * (n_pad + 2u) * 8u);
     L.off_rhs = take(n_pad * 8u);
     L.off_g = take(2u * L.mr * 8u * 8u);
     L.off_r = take(2u * L.mr * 8u);
@@ -100,8 +110,11 @@ __device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int la
             ok = false;
             break;
         }
-        double rs = 1.0 / ::sqrt(piv);
-        double ip = 1.0 / piv;
+        // 1/sqrt(pivot): v_rsq_f64 seed (~23 bits) + two Newton steps y <- y + y*(1 - p*y*y)/2
+        double rs = __builtin_amdgcn_rsq(piv);
+        rs = fma(0.5 * rs, fma(-piv * rs, rs, 1.0), rs);
+        rs = fma(0.5 * rs, fma(-piv * rs, rs, 1.0), rs);
+        double ip = rs * rs;  // 1/pivot
         double ljk = a[k] * rs;
         double mul = (lane > k) ? a[k] * ip : 0.0;  // A_jk / pivot; 0 keeps lanes <= k untouched
         if (lane >= k) a[k] = ljk;
@@ -142,12 +155,26 @@ struct RowEval {
     double g[8];
 };
 
-template <int N>
+// PROF = true is the diagnostic build of the same kernel: s_memtime stamps at the phase boundaries,
+// summed per phase into prm.prof (never launched by the product entry points).
+enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4, PH_TAIL = 5, PH_COUNT = 6 };
+
+template <int N, bool PROF>
 __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = 0;
+    auto stamp = [&](int phase) {
+        if (PROF) {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[phase] += t - t_last;
+            t_last = t;
+        }
+    };
+    if (PROF) t_last = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x;
     const uint32_t s = blockIdx.x;
-    constexpr int LD = N + 1;
+    constexpr int LD = N + 2;  // even: 16-byte aligned column pairs, conflict-free ds_read_b128
 
     double* XS = reinterpret_cast<double*>(smem + L.off_xs);       // [2][vt] full variable vectors
     double* Amat = reinterpret_cast<double*>(smem + L.off_a);      // [N][LD] JtJ (lambda on demand)
@@ -314,16 +341,30 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             if (lane < N) rhsv[lane] = 0.0;
             __syncthreads();
             const int e1 = lane >> 3, e2 = lane & 7;
-            for (uint32_t row = 0; row < m_rows; ++row) {
-                int c1 = gcol[row * 8 + e1], c2 = gcol[row * 8 + e2];
-                double g1 = G[(buf * mr + row) * 8 + e1], g2 = G[(buf * mr + row) * 8 + e2];
-                if (c1 >= 0 && c2 >= 0) {
-                    __builtin_amdgcn_ds_atomic_fadd_f64(
-                        (__attribute__((address_space(3))) double*)&Amat[c1 * LD + c2], g1 * g2);
+            constexpr int RB = 4;  // rows per batch: all loads of a batch are issued before its atomics
+            for (uint32_t row0 = 0; row0 < m_rows; row0 += RB) {
+                int c1[RB], c2[RB];
+                double g1[RB], g2[RB], rr[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    uint32_t row = min(row0 + q, m_rows - 1);
+                    c1[q] = gcol[row * 8 + e1];
+                    c2[q] = gcol[row * 8 + e2];
+                    g1[q] = G[(buf * mr + row) * 8 + e1];
+                    g2[q] = G[(buf * mr + row) * 8 + e2];
+                    rr[q] = -R[buf * mr + row];
+                    if (row0 + q >= m_rows) c1[q] = -1;
                 }
-                if (e2 == 0 && c1 >= 0) {
-                    double rr = -R[buf * mr + row];
-                    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&rhsv[c1], g1 * rr);
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    if (c1[q] >= 0 && c2[q] >= 0) {
+                        __builtin_amdgcn_ds_atomic_fadd_f64(
+                            (__attribute__((address_space(3))) double*)&Amat[c1[q] * LD + c2[q]], g1[q] * g2[q]);
+                    }
+                    if (e2 == 0 && c1[q] >= 0) {
+                        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&rhsv[c1[q]],
+                                                            g1[q] * rr[q]);
+                    }
                 }
             }
             if (lane < N && (uint32_t)lane >= nfree) Amat[lane * LD + lane] = 1.0;  // identity padding
@@ -331,9 +372,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         };
 
         int cur = 0;
+        stamp(PH_SETUP);
         double sse = eval_rows(0);
         const double sse_start = sse;
+        stamp(PH_EVAL);
         form_normal(0);
+        stamp(PH_FORM);
         double diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
         double rhs_l = (lane < N) ? rhsv[lane] : 0.0;
 
@@ -360,16 +404,22 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 // K4: factor (JtJ + lambda I) and solve for delta
                 double a[N];
                 if (lane < N) {
+                    Amat[lane * LD + lane] = diag + lambda;  // same lane reads it back: LDS is in order
+                    const double2* col = reinterpret_cast<const double2*>(Amat + lane * LD);
 #pragma unroll
-                    for (int i = 0; i < N; ++i) a[i] = Amat[lane * LD + i];
-#pragma unroll
-                    for (int i = 0; i < N; ++i) a[i] = (i == lane) ? diag + lambda : a[i];
+                    for (int i = 0; i < N; i += 2) {
+                        double2 t = col[i >> 1];
+                        a[i] = t.x;
+                        a[i + 1] = t.y;
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < N; ++i) a[i] = 0.0;
                 }
                 double invd = 1.0;
+                stamp(PH_TAIL);
                 bool solved = chol_factor<N>(a, invd, lane);
+                stamp(PH_FACTOR);
                 if (!uniform(solved)) {  // lm.rs:134-137
                     lambda *= o.singular_factor;
                     continue;
@@ -377,6 +427,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 double delta = chol_solve<N>(a, invd, rhs_l, lane);
                 if ((uint32_t)lane >= nfree) delta = 0.0;
                 double dn2 = wave_sum(delta * delta);
+                stamp(PH_SOLVE);
                 if (!(dn2 == dn2)) {
                     exit_code = FX_EXIT_NAN;
                     done = true;
@@ -394,7 +445,9 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     XS[trial * vt + vi] = XS[cur * vt + vi] + delta;
                 }
                 __syncthreads();
+                stamp(PH_TAIL);
                 double sse_t = eval_rows(trial);
+                stamp(PH_EVAL);
                 if (sse_t < sse) {  // accept, lm.rs:151-186
                     lambda *= o.accept_factor;
                     if (lambda < o.lambda_min) lambda = o.lambda_min;
@@ -408,9 +461,11 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                         break;
                     }
                     __syncthreads();
+                    stamp(PH_TAIL);
                     form_normal(cur);
                     diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
                     rhs_l = (lane < N) ? rhsv[lane] : 0.0;
+                    stamp(PH_FORM);
                     break;
                 } else {  // reject, lm.rs:187-190
                     if (!(sse_t == sse_t)) {
@@ -470,6 +525,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         res.sse = tot_sse;
         res.sse_unscaled = sse_u;
         b.results[s] = res;
+    }
+    if (PROF) {
+        stamp(PH_TAIL);
+        if (lane == 0 && prm.prof) {
+            for (int i = 0; i < PH_COUNT; ++i) atomicAdd(&prm.prof[i], ph[i]);
+        }
     }
 }
 
@@ -534,12 +595,12 @@ __global__ __launch_bounds__(256) void identity_residual_kernel(DeviceBatch b, c
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int N>
+template <int N, bool PROF>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, PROF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lm_solve_kernel<N>, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    hipLaunchKernelGGL((lm_solve_kernel<N, PROF>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
 }
 
@@ -547,15 +608,19 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
     if (b.n_systems == 0) return hipSuccess;
     uint32_t n = pad_n(b.max_free);
     SolveLayout L = make_layout(n, b.max_vars, b.max_rows);
+    if (p.prof) {  // diagnostic build, instantiated for the headline shape only
+        if (n != 32) return hipErrorInvalidValue;
+        return launch_solve_n<32, true>(b, p, L, stream);
+    }
     switch (n) {
-        case 8: return launch_solve_n<8>(b, p, L, stream);
-        case 16: return launch_solve_n<16>(b, p, L, stream);
-        case 24: return launch_solve_n<24>(b, p, L, stream);
-        case 32: return launch_solve_n<32>(b, p, L, stream);
-        case 40: return launch_solve_n<40>(b, p, L, stream);
-        case 48: return launch_solve_n<48>(b, p, L, stream);
-        case 56: return launch_solve_n<56>(b, p, L, stream);
-        case 64: return launch_solve_n<64>(b, p, L, stream);
+        case 8: return launch_solve_n<8, false>(b, p, L, stream);
+        case 16: return launch_solve_n<16, false>(b, p, L, stream);
+        case 24: return launch_solve_n<24, false>(b, p, L, stream);
+        case 32: return launch_solve_n<32, false>(b, p, L, stream);
+        case 40: return launch_solve_n<40, false>(b, p, L, stream);
+        case 48: return launch_solve_n<48, false>(b, p, L, stream);
+        case 56: return launch_solve_n<56, false>(b, p, L, stream);
+        case 64: return launch_solve_n<64, false>(b, p, L, stream);
         default: return hipErrorInvalidValue;
     }
 }

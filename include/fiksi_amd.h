@@ -210,6 +210,10 @@ int fx_batch_get_jacobian_values(fx_ctx* ctx, fx_dbatch* db, double* jvals);
 int fx_timer_begin(fx_ctx* ctx);
 int fx_timer_end(fx_ctx* ctx, float* milliseconds);
 
+/* Diagnostic only: shader cycles per phase {setup, eval, form, factor, solve, tail}, summed over all
+ * wavefronts, from a stamped build of the fused kernel (32-free-variable shape only). */
+int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, uint64_t cycles[6]);
+
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */
 /* == assemble::solve: batch->vars in: unscaled values, out: solved values. results may be NULL. */
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results);
