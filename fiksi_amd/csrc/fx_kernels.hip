@@ -102,14 +102,11 @@ size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_fr
 // Returns false (wave-uniform) when a pivot is not positive and finite.
 template <int N>
 __device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int lane) {
-    bool ok = true;
+    bool bad = false;  // wave-uniform; checked once at the end (a bad pivot only produces NaN/Inf junk)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         double piv = bcast(a[k], k);
-        if (!(piv > 0.0) || !(piv < 1.0e300)) {
-            ok = false;
-            break;
-        }
+        bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
         // 1/sqrt(pivot): v_rsq_f64 seed (~23 bits) + two Newton steps y <- y + y*(1 - p*y*y)/2
         double rs = __builtin_amdgcn_rsq(piv);
         rs = fma(0.5 * rs, fma(-piv * rs, rs, 1.0), rs);
@@ -125,7 +122,7 @@ __device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int la
             a[i] = fma(-aik, mul, a[i]);
         }
     }
-    return ok;
+    return !bad;
 }
 
 // Solves L L^T x = b with the factor layout above. b in `rhs` (lane j holds b_j); returns x_j.
