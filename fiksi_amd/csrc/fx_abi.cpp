@@ -43,7 +43,9 @@ struct HostPlan {
     std::vector<uint16_t> var_info;
     std::vector<uint16_t> expr_comp;
     std::vector<uint16_t> expr_idx16;
-    std::vector<uint32_t> expr_sys;
+    std::vector<uint32_t> expr_var0;
+    std::vector<uint8_t> expr_tagx;   // tag | 0x80 when a free column repeats inside the row
+    std::vector<uint8_t> row_perm;    // tag-sorted order of each 256-row block
     std::vector<uint32_t> jrow_ptr, jcol, jslot;
 };
 
@@ -77,7 +79,9 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
     p.var_info.assign(nv, 0);
     p.expr_comp.assign(ne, 0);
     p.expr_idx16.assign(4 * (size_t)ne, 0);
-    p.expr_sys.assign(ne, 0);
+    p.expr_var0.assign(ne, 0);
+    p.expr_tagx.assign(ne, 0);
+    p.row_perm.assign(ne, 0);
     if (want_structure) {
         p.jrow_ptr.assign((size_t)ne + 1, 0);
         p.jslot.assign(ne, 0xFFFFFFFFu);
@@ -144,7 +148,14 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
                     return fail(FX_ERR_INVALID, "expression %u of system %u reads variable %u >= %u", i, s, vars8[q], nvt);
             }
             for (int q = 0; q < 4; ++q) p.expr_idx16[4 * (size_t)e + q] = (uint16_t)(f[q] < nvt ? f[q] : 0);
-            p.expr_sys[e] = s;
+            p.expr_var0[e] = v0;
+            p.expr_tagx[e] = (uint8_t)tag;
+            {
+                bool dup = false;
+                for (int q = 0; q < k; ++q)
+                    for (int t = q + 1; t < k; ++t) dup = dup || (vars8[q] == vars8[t] && free_rank[vars8[q]] >= 0);
+                if (dup) p.expr_tagx[e] |= 0x80;
+            }
             uint16_t c = p.expr_comp[e];
             if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
 
@@ -186,6 +197,13 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
         }
     }
     if (want_structure) p.nnz = p.jcol.size();
+    // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
+    for (uint32_t r0 = 0; r0 < ne; r0 += 256) {
+        uint32_t nr = std::min<uint32_t>(256, ne - r0), t = 0;
+        for (int tag = 0; tag < FX_NTAGS; ++tag)
+            for (uint32_t i = 0; i < nr; ++i)
+                if ((p.expr_tagx[r0 + i] & 0x7F) == tag) p.row_perm[r0 + t++] = (uint8_t)i;
+    }
     return FX_OK;
 }
 
@@ -376,11 +394,12 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(vars0, (const double*)batch->vars, p.n_vars)
     FX_UP(vars, (const double*)batch->vars, p.n_vars)
     FX_UP(var_info, p.var_info.data(), p.n_vars)
-    FX_UP(expr_tag, batch->expr_tag, p.n_exprs)
+    FX_UP(expr_tag, p.expr_tagx.data(), p.n_exprs)
+    FX_UP(row_perm, p.row_perm.data(), p.n_exprs)
     FX_UP(expr_comp, p.expr_comp.data(), p.n_exprs)
     FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
     FX_UP(expr_param, batch->expr_param, p.n_exprs)
-    FX_UP(expr_sys, p.expr_sys.data(), p.n_exprs)
+    FX_UP(expr_var0, p.expr_var0.data(), p.n_exprs)
     FX_UP(jrow_ptr, p.jrow_ptr.data(), (size_t)p.n_exprs + 1)
     FX_UP(jcol, p.jcol.data(), p.nnz)
     FX_UP(jslot, p.jslot.data(), p.n_exprs)

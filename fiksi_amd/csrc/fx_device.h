@@ -28,11 +28,12 @@ struct DeviceBatch {
     double* vars0;         // [n_vars] start values (never written by solves)
     double* vars;          // [n_vars] last solved values
     uint16_t* var_info;    // [n_vars]
-    uint8_t* expr_tag;     // [n_exprs]
+    uint8_t* expr_tag;     // [n_exprs] fx_tag | 0x80 if the row reads one free variable twice
+    uint8_t* row_perm;     // [n_exprs] per 256-row block: local row handled by thread t (tag-sorted)
     uint16_t* expr_comp;   // [n_exprs]
     uint16_t* expr_idx;    // [4*n_exprs] system-local element fields (ushort4 per expression)
     double* expr_param;    // [n_exprs]
-    uint32_t* expr_sys;    // [n_exprs] owning system (for the row-parallel kernels)
+    uint32_t* expr_var0;   // [n_exprs] var_off of the owning System (for the row-parallel kernels)
     // CSR Jacobian (fixed pattern): rows global, columns = system-local free rank
     uint32_t* jrow_ptr;    // [n_exprs+1]
     uint32_t* jcol;        // [nnz]

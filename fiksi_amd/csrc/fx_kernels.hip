@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             double t = 0.0;
             bool isd = false;
             if (i < net) {
-                int tag = b.expr_tag[e0 + i];
+                int tag = b.expr_tag[e0 + i] & 0x7F;
                 isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
                 if (isd) {
                     double d = b.expr_param[e0 + i];
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             uint64_t mk = __ballot(in);
             uint32_t pos = m_rows + (uint32_t)__popcll(mk & lanemask_lt(lane));
             if (in) {
-                int tag = b.expr_tag[e0 + i];
+                int tag = b.expr_tag[e0 + i] & 0x7F;
                 const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
                 uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
                 uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     __syncthreads();
     double part = 0.0;
     for (uint32_t i = lane; i < net; i += 64) {
-        int tag = b.expr_tag[e0 + i];
+        int tag = b.expr_tag[e0 + i] & 0x7F;
         const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
         uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
         uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -538,37 +538,77 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
 // free variables alike are read from x (IndexSetVariableMap with the snapshot == x).
 template <bool WANT_J>
 __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= b.n_exprs) return;
-    uint32_t s = b.expr_sys[row];
-    uint32_t v0 = b.var_off[s];
-    int tag = b.expr_tag[row];
-    ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
-    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars(tag, ff, vars8);
-    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
-    double r = eval_expression<double, WANT_J>(tag, v, b.expr_param[row], g);
-    b.resid[row] = r;
+    // Block = 256 consecutive rows. Threads take the block's rows in tag-sorted order (host-built
+    // permutation) so that a wavefront sees as few expression kinds as possible (divergence: the
+    // angle rows cost ~8x a distance row). Residuals and the block's CSR values (contiguous in the
+    // value array) are staged in LDS and streamed out with coalesced stores.
+    __shared__ double jstage[WANT_J ? 256 * 8 : 1];
+    __shared__ double rstage[256];
+    const uint32_t row0 = blockIdx.x * 256u;
+    const uint32_t nrows = min(256u, b.n_exprs - row0);
+    uint32_t jbase = 0, jend = 0;
     if (WANT_J) {
-        // scatter the <= 8 partials into the row's CSR slots; duplicates (same variable twice)
-        // are summed, fixed variables dropped (slot 0xF)
-        uint32_t slots = b.jslot[row];
-        uint32_t base = b.jrow_ptr[row];
-        uint32_t cnt = b.jrow_ptr[row + 1] - base;
-        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        jbase = b.jrow_ptr[row0];
+        jend = b.jrow_ptr[row0 + nrows];
+    }
+    if (threadIdx.x < nrows) {
+        const uint32_t lrow = b.row_perm[row0 + threadIdx.x];
+        const uint32_t row = row0 + lrow;
+        const uint32_t v0 = b.expr_var0[row];  // first variable of the owning System
+        const int tagx = b.expr_tag[row];
+        const int tag = tagx & 0x7F;
+        ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
+        uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        expand_vars(tag, ff, vars8);
+        double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            uint32_t sl = (slots >> (4 * e)) & 0xFu;
+        for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
+        rstage[lrow] = eval_expression<double, WANT_J>(tag, v, b.expr_param[row], g);
+        if (WANT_J) {
+            const uint32_t slots = b.jslot[row];
+            const uint32_t base = b.jrow_ptr[row] - jbase;
+            if (!(tagx & 0x80)) {
+                // every free variable of the row is distinct: partial e goes to its CSR slot;
+                // 0xF = fixed variable, dropped (subsystem.rs:159-164)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) out[q] += (sl == (uint32_t)q) ? g[e] : 0.0;
+                for (int e = 0; e < 8; ++e) {
+                    uint32_t sl = (slots >> (4 * e)) & 0xFu;
+                    if (sl != 0xFu) jstage[base + sl] = g[e];
+                }
+            } else {
+                // the same variable appears twice (quirk Q4): duplicates are summed in gradient order
+                const uint32_t cnt = b.jrow_ptr[row + 1] - jbase - base;
+                double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    uint32_t sl = (slots >> (4 * e)) & 0xFu;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) out[q] += (sl == (uint32_t)q) ? g[e] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((uint32_t)q < cnt) jstage[base + q] = out[q];
+                }
+            }
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if ((uint32_t)q < cnt) b.jvals[base + q] = out[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < nrows) b.resid[row0 + threadIdx.x] = rstage[threadIdx.x];
+    if (WANT_J) {
+        // 16-byte stores on the 16-byte-aligned body of [jbase, jend), scalar head / tail
+        const uint32_t n = jend - jbase;
+        const uint32_t head = jbase & 1u;  // jvals is 16-byte aligned at index 0
+        if (head && threadIdx.x == 0 && n > 0) b.jvals[jbase] = jstage[0];
+        const uint32_t pairs = (n - min(n, head)) >> 1;
+        double2* dst = reinterpret_cast<double2*>(b.jvals + jbase + head);
+        for (uint32_t i = threadIdx.x; i < pairs; i += 256u) {
+            double2 t;
+            t.x = jstage[head + 2 * i];
+            t.y = jstage[head + 2 * i + 1];
+            dst[i] = t;
         }
+        if (((n - min(n, head)) & 1u) && threadIdx.x == 1) b.jvals[jend - 1] = jstage[n - 1];
     }
 }
 
@@ -576,9 +616,8 @@ __global__ __launch_bounds__(256) void identity_residual_kernel(DeviceBatch b, c
                                                                 double* __restrict__ out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= b.n_exprs) return;
-    uint32_t s = b.expr_sys[row];
-    uint32_t v0 = b.var_off[s];
-    int tag = b.expr_tag[row];
+    uint32_t v0 = b.expr_var0[row];
+    int tag = b.expr_tag[row] & 0x7F;
     ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
     uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
     uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
