@@ -120,7 +120,7 @@ def main() -> int:
         dist, elapsed, [converged, accepted, trials, n_sys], device="cuda" if dist is not None else None)
 
     # ---- K1 (Jacobian assembly) on the same resident batch, HIP-event timed ----------------
-    k1_launches = max(args.steps, 10)
+    k1_launches = max(args.steps, 50)
     for _ in range(3):
         db.eval_residual_jacobian(0)
     ctx.synchronize()
@@ -173,7 +173,9 @@ def main() -> int:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": k1_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("eval_rows_kernel<true>", n_sys),
+                "traffic_source": "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                  "passes; read bytes = 2 x FETCH_SIZE KiB per the gfx950 correction)",
                 "algorithmic_bytes_per_launch": k1_bytes,
                 "avg_launch_ms": k1_ms,
                 "launches": k1_launches,
@@ -198,6 +200,23 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def pmc_traffic(kernel_substr: str, n_sys: int):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (collected in separate
+    --pmc passes on the same workload); None when the summary does not cover this batch size."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if int(d.get("n_systems", -1)) != int(n_sys):
+            return None
+        for name, v in d["kernels"].items():
+            if kernel_substr in name:
+                return int(v["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(batch, sample: int):
