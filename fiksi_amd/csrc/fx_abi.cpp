@@ -13,6 +13,7 @@
 
 #include "fx_device.h"
 #include "fx_expr.h"
+#include "fx_sparse.h"
 
 namespace {
 
@@ -40,6 +41,8 @@ struct HostPlan {
     uint64_t nnz = 0;
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0;
     std::vector<uint16_t> sys_ncomp;
+    std::vector<uint8_t> sys_large;  // components beyond the one-wavefront limits -> sparse path
+    uint32_t n_large = 0;
     std::vector<uint16_t> var_info;
     std::vector<uint16_t> expr_comp;
     std::vector<uint16_t> expr_idx16;
@@ -76,6 +79,7 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
     p.n_vars = nv;
     p.n_exprs = ne;
     p.sys_ncomp.assign(n, 0);
+    p.sys_large.assign(n, 0);
     p.var_info.assign(nv, 0);
     p.expr_comp.assign(ne, 0);
     p.expr_idx16.assign(4 * (size_t)ne, 0);
@@ -93,10 +97,9 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
     for (uint32_t s = 0; s < n; ++s) {
         const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
         const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
-        if (nvt > FX_MAX_SYSTEM_VARS)
-            return fail(FX_ERR_TOO_LARGE, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_SYSTEM_VARS);
-        p.max_vars = std::max(p.max_vars, nvt);
-        p.max_exprs = std::max(p.max_exprs, net);
+        if (nvt > FX_MAX_LARGE_SYSTEM_VARS)
+            return fail(FX_ERR_TOO_LARGE, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_LARGE_SYSTEM_VARS);
+        bool large = nvt > FX_MAX_SYSTEM_VARS;
 
         uint32_t ncomp = 0;
         free_rank.assign(nvt, -1);
@@ -185,15 +188,18 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
                 p.jrow_ptr[(size_t)e + 1] = p.jrow_ptr[e] + (uint32_t)ncols;
             }
         }
-        for (uint32_t c = 0; c < ncomp; ++c) {
-            if (comp_free[c] > FX_MAX_FREE_VARS)
-                return fail(FX_ERR_TOO_LARGE, "system %u component %u has %u free variables (limit %u)", s, c,
-                            comp_free[c], FX_MAX_FREE_VARS);
-            if (comp_rows[c] > FX_MAX_ROWS)
-                return fail(FX_ERR_TOO_LARGE, "system %u component %u has %u expressions (limit %u)", s, c,
-                            comp_rows[c], FX_MAX_ROWS);
-            p.max_free = std::max(p.max_free, comp_free[c]);
-            p.max_rows = std::max(p.max_rows, comp_rows[c]);
+        for (uint32_t c = 0; c < ncomp; ++c)
+            large = large || comp_free[c] > FX_MAX_FREE_VARS || comp_rows[c] > FX_MAX_ROWS;
+        if (large) {
+            p.sys_large[s] = 1;
+            p.n_large += 1;
+        } else {  // LDS layout and kernel instantiation are sized by the one-wavefront systems only
+            p.max_vars = std::max(p.max_vars, nvt);
+            p.max_exprs = std::max(p.max_exprs, net);
+            for (uint32_t c = 0; c < ncomp; ++c) {
+                p.max_free = std::max(p.max_free, comp_free[c]);
+                p.max_rows = std::max(p.max_rows, comp_rows[c]);
+            }
         }
     }
     if (want_structure) p.nnz = p.jcol.size();
@@ -220,6 +226,13 @@ struct fx_ctx {
 struct fx_dbatch {
     fx::DeviceBatch d{};
     std::vector<void*> allocations;
+    // host copy of the batch, kept only when some System needs the sparse path
+    std::vector<uint32_t> h_var_off, h_expr_off, h_expr_idx;
+    std::vector<double> h_vars, h_expr_param;
+    std::vector<uint8_t> h_var_fixed, h_expr_tag, h_sys_large;
+    std::vector<uint16_t> h_var_comp, h_expr_comp;
+    fx_batch h_batch{};
+    uint32_t n_large = 0;
 };
 
 namespace {
@@ -247,6 +260,23 @@ int bind(fx_ctx* ctx) {
     return FX_OK;
 }
 
+}  // namespace
+
+namespace {
+// Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
+int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
+    if (!db->n_large) return FX_OK;
+    for (uint32_t s = 0; s < db->d.n_systems; ++s) {
+        if (!db->h_sys_large[s]) continue;
+        fx_result res{};
+        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, ctx->stream, db->d.vars + db->h_var_off[s], &res);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(db->d.results + s, &res, sizeof(fx_result), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", s, hipGetErrorString(e));
+    }
+    return FX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -391,6 +421,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(var_off, voff, (size_t)p.n_systems + 1)
     FX_UP(expr_off, eoff, (size_t)p.n_systems + 1)
     FX_UP(sys_ncomp, p.sys_ncomp.data(), p.n_systems)
+    FX_UP(sys_large, p.sys_large.data(), p.n_systems)
     FX_UP(vars0, (const double*)batch->vars, p.n_vars)
     FX_UP(vars, (const double*)batch->vars, p.n_vars)
     FX_UP(var_info, p.var_info.data(), p.n_vars)
@@ -412,6 +443,31 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     if (e != hipSuccess) {
         fx_batch_free(ctx, db);
         return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    if (p.n_large) {
+        const uint32_t nv = p.n_vars, ne = p.n_exprs, n = p.n_systems;
+        db->n_large = p.n_large;
+        db->h_sys_large = p.sys_large;
+        db->h_var_off.assign(batch->var_off, batch->var_off + n + 1);
+        db->h_expr_off.assign(batch->expr_off, batch->expr_off + n + 1);
+        db->h_vars.assign(batch->vars, batch->vars + nv);
+        db->h_var_fixed.assign(batch->var_fixed, batch->var_fixed + nv);
+        db->h_expr_tag.assign(batch->expr_tag, batch->expr_tag + ne);
+        db->h_expr_idx.assign(batch->expr_idx, batch->expr_idx + 4 * (size_t)ne);
+        db->h_expr_param.assign(batch->expr_param, batch->expr_param + ne);
+        if (batch->var_comp) db->h_var_comp.assign(batch->var_comp, batch->var_comp + nv);
+        if (batch->expr_comp) db->h_expr_comp.assign(batch->expr_comp, batch->expr_comp + ne);
+        fx_batch& hb = db->h_batch;
+        hb.n_systems = n;
+        hb.var_off = db->h_var_off.data();
+        hb.expr_off = db->h_expr_off.data();
+        hb.vars = db->h_vars.data();
+        hb.var_fixed = db->h_var_fixed.data();
+        hb.expr_tag = db->h_expr_tag.data();
+        hb.expr_idx = db->h_expr_idx.data();
+        hb.expr_param = db->h_expr_param.data();
+        hb.var_comp = batch->var_comp ? db->h_var_comp.data() : nullptr;
+        hb.expr_comp = batch->expr_comp ? db->h_expr_comp.data() : nullptr;
     }
     if (fx::solve_lds_bytes(d) > 160u * 1024u) {
         fx_batch_free(ctx, db);
@@ -435,6 +491,7 @@ int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!db || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    if (db->n_large) std::copy(vars, vars + db->d.n_vars, db->h_vars.begin());
     FX_HIP(hipMemcpyAsync(db->d.vars0, vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     FX_HIP(hipMemcpyAsync(db->d.vars, vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     FX_HIP(hipStreamSynchronize(ctx->stream));
@@ -473,7 +530,7 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u);
     FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
-    return FX_OK;
+    return solve_large_systems(ctx, db, p);
 }
 
 int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
@@ -484,7 +541,7 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     if (opts) p.lm = *opts; else fx_lm_opts_default(&p.lm);
     p.mode = 0;
     FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
-    return FX_OK;
+    return solve_large_systems(ctx, db, p);
 }
 
 // Diagnostic (not part of the drop-in surface): runs the stamped build of the fused kernel once and

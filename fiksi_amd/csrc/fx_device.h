@@ -25,6 +25,7 @@ struct DeviceBatch {
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]
     uint16_t* sys_ncomp;   // [n_systems] number of components
+    uint8_t* sys_large;    // [n_systems] 1 = exceeds the one-wavefront limits, solved by the sparse path
     double* vars0;         // [n_vars] start values (never written by solves)
     double* vars;          // [n_vars] last solved values
     uint16_t* var_info;    // [n_vars]

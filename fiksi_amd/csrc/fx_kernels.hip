@@ -171,6 +171,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     if (PROF) t_last = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x;
     const uint32_t s = blockIdx.x;
+    if (b.sys_large[s]) return;  // handled by the sparse path (fx_sparse.hip)
     constexpr int LD = N + 2;  // even: 16-byte aligned column pairs, conflict-free ds_read_b128
 
     double* XS = reinterpret_cast<double*>(smem + L.off_xs);       // [2][vt] full variable vectors
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         };
 
         int cur = 0;
+        const double xstart = ((uint32_t)lane < nfree) ? XS[fidx[lane]] : 0.0;  // perturbed start of this lane's variable
         stamp(PH_SETUP);
         double sse = eval_rows(0);
         const double sse_start = sse;
@@ -479,9 +481,10 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             uint32_t vi = fidx[lane];
             double x = XS[cur * vt + vi];
             b.vars[v0 + vi] = (prm.mode & 1u) ? scale * x : x;
-            // keep both halves equal to the *pre-solve* perturbed snapshot for later components
-            // (quirk Q2): restore the non-current half from the start-of-component value is not
-            // needed because components never share variables.
+            // later components are solved against the PRE-solve snapshot (only `system.variables` is
+            // written back, quirk Q2): restore the perturbed start value in both halves
+            XS[vi] = xstart;
+            XS[vt + vi] = xstart;
         }
         __syncthreads();
         tot_accept += accepted;

@@ -1,0 +1,14 @@
+// Large-component path (fx_sparse.hip): host structure + device numeric sparse Cholesky LM.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fx_device.h"
+
+namespace fx {
+
+// Solves System `s` of the host batch `b` (all of its connected components) on `stream`; the
+// solved variables go to the device buffer `d_vars_out` (the System's slice, nvt doubles).
+hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
+                               double* d_vars_out, fx_result* result);
+
+}  // namespace fx

@@ -1,0 +1,834 @@
+// Large-component path: Systems whose connected components exceed the one-wavefront limits of the
+// fused kernel (more than 64 free variables or 256 expressions) — e.g. BASELINE cfg2, one sketch of
+// 5 000 points / 10 000 constraints.
+//
+// Same algorithm as the fused kernel (fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193,
+// LM step in normal-equation form), organised for one big sparse problem instead of many small dense
+// ones:
+//   host   : structure only — free-column list, CSR pattern of J, pattern of A = JtJ, a
+//            reverse-Cuthill-McKee fill-reducing order (the reference runs COLAMD on the host too,
+//            qr.rs:118-206), symbolic Cholesky (pattern of L via elimination-tree merging) and, for
+//            every non-zero of A and of L, the list of products that define it ("gather lists").
+//            The LM accept/reject decisions are taken on the host from three scalars per trial.
+//   device : all arithmetic — scale/perturb (K0), residual + Jacobian rows (K1/K2, one thread per
+//            row), A = JtJ and g = -Jt r by deterministic gathers (K3), numeric sparse Cholesky and
+//            the two triangular solves column by column in one wavefront (K4), trial update, SSE.
+// No floating-point work happens on the host.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+#include <vector>
+
+#include "fx_device.h"
+#include "fx_expr.h"
+#include "fx_sparse.h"
+
+namespace fx {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// device kernels
+// ------------------------------------------------------------------------------------------------
+struct SpRows {                 // expression data of the whole System (device)
+    const uint8_t* tag;         // [net]
+    const uint16_t* idx;        // [4*net]
+    const double* param;        // [net] unscaled
+    double* sparam;             // [net] scaled (distance parameters * 1/scale)
+    uint32_t net;
+};
+
+// scal[0] = scale, scal[1] = 1/scale. Sequential summation in the reference's order
+// (assemble/mod.rs:32-44) so the scale is bit-identical: one wavefront, 64 values per step.
+__global__ __launch_bounds__(64) void sp_scale_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows,
+                                                      double* __restrict__ scal, int do_scale) {
+    const int lane = threadIdx.x;
+    double scale = 1.0;
+    if (do_scale) {
+        double sum = 0.0;
+        uint32_t count = nvt;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            if (i < nvt) {
+                double v = vars0[i];
+                t = v * v;
+            }
+            uint32_t cnt = min(64u, nvt - base);
+            for (uint32_t k = 0; k < cnt; ++k) {
+                int lo = __builtin_amdgcn_readlane(__double2loint(t), (int)k);
+                int hi = __builtin_amdgcn_readlane(__double2hiint(t), (int)k);
+                sum += __hiloint2double(hi, lo);
+            }
+        }
+        for (uint32_t base = 0; base < rows.net; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            bool isd = false;
+            if (i < rows.net) {
+                int tag = rows.tag[i] & 0x7F;
+                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
+                if (isd) {
+                    double d = rows.param[i];
+                    t = d * d;
+                }
+            }
+            count += (uint32_t)__popcll(__ballot(isd));
+            uint32_t cnt = min(64u, rows.net - base);
+            for (uint32_t k = 0; k < cnt; ++k) {
+                int lo = __builtin_amdgcn_readlane(__double2loint(t), (int)k);
+                int hi = __builtin_amdgcn_readlane(__double2hiint(t), (int)k);
+                sum += __hiloint2double(hi, lo);
+            }
+        }
+        scale = ::sqrt(sum / (double)count);
+    }
+    if (lane == 0) {
+        scal[0] = scale;
+        scal[1] = 1.0 / scale;
+    }
+}
+
+__global__ void sp_init_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows, const double* __restrict__ scal,
+                               double* __restrict__ xs_a, double* __restrict__ xs_b, int do_scale) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double recip = scal[1];
+    if (i < nvt) {
+        double v = vars0[i];
+        double x = do_scale ? v * recip : v;
+        xs_a[i] = x;
+        xs_b[i] = x;
+    }
+    if (i < rows.net) {
+        int tag = rows.tag[i] & 0x7F;
+        double p = rows.param[i];
+        if (do_scale && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) p = recip * p;
+        rows.sparam[i] = p;
+    }
+}
+
+// LCG skip-ahead: state after n steps of s <- s*A + C is s*A^n + C*(A^n-1)/(A-1) (mod 2^32),
+// computed by squaring the affine map.
+__device__ __forceinline__ uint32_t lcg_skip(uint32_t s, uint32_t n) {
+    uint32_t a = 1664525u, c = 1013904223u;  // fiksi/src/rand.rs:24-30
+    uint32_t acc_a = 1u, acc_c = 0u;
+    while (n) {
+        if (n & 1u) {
+            acc_c = acc_c * a + c;
+            acc_a = acc_a * a;
+        }
+        c = c * a + c;
+        a = a * a;
+        n >>= 1;
+    }
+    return s * acc_a + acc_c;
+}
+
+// assemble/mod.rs:113-124: free variable k (ascending) takes draws 2k and 2k+1 of the shared Rng.
+__global__ void sp_perturb_kernel(const uint32_t* __restrict__ fvar, uint32_t nv, uint32_t rng_state,
+                                  double* __restrict__ xs_a, double* __restrict__ xs_b) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nv) return;
+    uint32_t st = lcg_skip(rng_state, 2u * k);
+    st = st * 1664525u + 1013904223u;
+    double f1 = (1.0 / 4294967295.0) * (double)st;
+    st = st * 1664525u + 1013904223u;
+    double f2 = (1.0 / 4294967295.0) * (double)st;
+    uint32_t vi = fvar[k];
+    double x = xs_a[vi];
+    x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+    xs_a[vi] = x;
+    xs_b[vi] = x;
+}
+
+struct SpJac {                   // J of one component (device)
+    const uint32_t* rows;        // [m] expression id of row
+    const uint32_t* jrow_ptr;    // [m+1]
+    const uint32_t* jslot;       // [m] 8 x 4-bit slot of each gradient entry (0xF = not a free column)
+    uint32_t m;
+};
+
+// K1/K2 for one component: thread per row (subsystem.rs:93-166).
+template <bool WANT_J>
+__global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, const double* __restrict__ xs,
+                                                      double* __restrict__ r, double* __restrict__ jvals) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= jac.m) return;
+    uint32_t e = jac.rows[row];
+    int tag = rows.tag[e] & 0x7F;
+    ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars(tag, ff, vars8);
+    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
+    r[row] = eval_expression<double, WANT_J>(tag, v, rows.sparam[e], g);
+    if (WANT_J) {
+        uint32_t slots = jac.jslot[row];
+        uint32_t base = jac.jrow_ptr[row];
+        uint32_t cnt = jac.jrow_ptr[row + 1] - base;
+        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint32_t sl = (slots >> (4 * q)) & 0xFu;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) out[t] += (sl == (uint32_t)t) ? g[q] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if ((uint32_t)t < cnt) jvals[base + t] = out[t];
+        }
+    }
+}
+
+// out[0] = sum v[i]^2 (fixed-shape tree: deterministic)
+__global__ __launch_bounds__(1024) void sp_sumsq_kernel(const double* __restrict__ v, uint32_t n, double* __restrict__ out) {
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += v[i] * v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+// K3a: A[k] = sum over its gather list of J[a]*J[b] (lower triangle of JtJ, permuted order)
+__global__ void sp_form_a_kernel(const uint32_t* __restrict__ pair_ptr, const uint32_t* __restrict__ pairs,
+                                 const double* __restrict__ jvals, uint32_t nnz_a, double* __restrict__ a) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz_a) return;
+    double s = 0.0;
+    for (uint32_t p = pair_ptr[k]; p < pair_ptr[k + 1]; ++p) s += jvals[pairs[2 * p]] * jvals[pairs[2 * p + 1]];
+    a[k] = s;
+}
+
+// K3b: b[c] = -sum_{rows of column c} J * r   (permuted column order)
+__global__ void sp_rhs_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx,
+                              const uint32_t* __restrict__ crow, const double* __restrict__ jvals,
+                              const double* __restrict__ r, uint32_t nv, double* __restrict__ b) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nv) return;
+    double s = 0.0;
+    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * (-r[crow[p]]);
+    b[c] = s;
+}
+
+__device__ __forceinline__ double ld_l2(const double* p) {  // L2-coherent load (bypasses the CU's L1)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct SpChol {                  // symbolic factor (device)
+    const uint32_t* lcolptr;     // [nv+1]; first entry of every column is its diagonal
+    const uint32_t* lrow;        // [nnzL]
+    const int32_t* l2a;          // [nnzL] index into A or -1 (fill-in)
+    const uint32_t* lpair_ptr;   // [nnzL+1]
+    const uint32_t* lpairs;      // [2*npairs] indices into L
+    uint32_t nv;
+};
+
+// K4a: numeric sparse Cholesky of A + lambda I, left-looking by gather lists, one wavefront walks
+// the columns in order. flag[0] = 1 when a pivot is not positive and finite.
+__global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* __restrict__ a, double lambda,
+                                                       double* __restrict__ l, uint32_t* __restrict__ flag) {
+    const int lane = threadIdx.x;
+    bool bad = false;
+    for (uint32_t j = 0; j < c.nv; ++j) {
+        const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
+        for (uint32_t base = beg; base < end; base += 64) {
+            uint32_t k = base + lane;
+            if (k < end) {
+                int32_t ai = c.l2a[k];
+                double s = ai >= 0 ? a[ai] : 0.0;
+                if (k == beg) s += lambda;
+                for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
+                    s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
+                l[k] = s;
+            }
+        }
+        __syncthreads();
+        double piv = ld_l2(l + beg);
+        bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
+        double d = ::sqrt(piv);
+        double inv = 1.0 / d;
+        for (uint32_t base = beg; base < end; base += 64) {
+            uint32_t k = base + lane;
+            if (k < end) {
+                double raw = ld_l2(l + k);
+                l[k] = (k == beg) ? d : raw * inv;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) flag[0] = bad ? 1u : 0u;
+}
+
+// K4b: L y = b (column sweep), Lt x = y (row gathers); x overwrites b; out[0] = |x|^2.
+__global__ __launch_bounds__(64) void sp_solve_kernel(SpChol c, const double* __restrict__ l, double* __restrict__ b,
+                                                      double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    for (uint32_t j = 0; j < c.nv; ++j) {
+        const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
+        double yj = ld_l2(b + j) / l[beg];
+        for (uint32_t k = beg + 1 + lane; k < end; k += 64) {
+            uint32_t i = c.lrow[k];
+            b[i] = ld_l2(b + i) - l[k] * yj;  // rows of one column are distinct: no conflicts
+        }
+        if (lane == 0) b[j] = yj;
+        __syncthreads();
+    }
+    double n2 = 0.0;
+    for (uint32_t jj = c.nv; jj-- > 0;) {
+        const uint32_t beg = c.lcolptr[jj], end = c.lcolptr[jj + 1];
+        double part = 0.0;
+        for (uint32_t k = beg + 1 + lane; k < end; k += 64) part += l[k] * ld_l2(b + c.lrow[k]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        double xj = (ld_l2(b + jj) - part) / l[beg];
+        if (lane == 0) b[jj] = xj;
+        n2 += xj * xj;
+        __syncthreads();
+    }
+    if (lane == 0) out[0] = n2;
+}
+
+// trial point: xs_dst[fvar[perm[k]]] = xs_src[...] + delta[k]
+__global__ void sp_trial_kernel(const uint32_t* __restrict__ fvar, const uint32_t* __restrict__ perm, uint32_t nv,
+                                const double* __restrict__ delta, const double* __restrict__ xs_src,
+                                double* __restrict__ xs_dst) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nv) return;
+    uint32_t vi = fvar[perm[k]];
+    xs_dst[vi] = xs_src[vi] + delta[k];
+}
+
+__global__ void sp_copy_free_kernel(const uint32_t* __restrict__ fvar, uint32_t nv, const double* __restrict__ src,
+                                    double* __restrict__ dst) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nv) dst[fvar[k]] = src[fvar[k]];
+}
+
+// assemble/mod.rs:161-166
+__global__ void sp_writeback_kernel(const uint32_t* __restrict__ fvar, uint32_t nv, const double* __restrict__ xs,
+                                    const double* __restrict__ scal, int do_scale, double* __restrict__ vars_out) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nv) return;
+    uint32_t vi = fvar[k];
+    vars_out[vi] = do_scale ? scal[0] * xs[vi] : xs[vi];
+}
+
+// residual of every expression on unscaled variables (constraints/mod.rs:96-109)
+__global__ void sp_identity_residual_kernel(SpRows rows, const double* __restrict__ x, double* __restrict__ out) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows.net) return;
+    int tag = rows.tag[e] & 0x7F;
+    ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars(tag, ff, vars8);
+    double v[8], g[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = x[vars8[q]];
+    out[e] = eval_expression<double, false>(tag, v, rows.param[e], g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: structure
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct DevArr {
+    T* p = nullptr;
+    size_t n = 0;
+};
+
+struct Pool {  // device allocations of one solve
+    std::vector<void*> ptrs;
+    hipStream_t stream;
+    hipError_t err = hipSuccess;
+    template <typename T>
+    T* up(const std::vector<T>& h) {
+        T* d = alloc<T>(h.size());
+        if (d && !h.empty() && err == hipSuccess)
+            err = hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+        return d;
+    }
+    template <typename T>
+    T* alloc(size_t n) {
+        void* d = nullptr;
+        if (err != hipSuccess) return nullptr;
+        err = hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T));
+        if (err != hipSuccess) return nullptr;
+        ptrs.push_back(d);
+        return static_cast<T*>(d);
+    }
+    ~Pool() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+// reverse Cuthill-McKee order of the column graph of A (adjacency given as sorted lists)
+std::vector<uint32_t> rcm_order(const std::vector<std::vector<uint32_t>>& adj) {
+    const uint32_t n = (uint32_t)adj.size();
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<uint8_t> seen(n, 0);
+    std::vector<uint32_t> by_degree(n);
+    for (uint32_t i = 0; i < n; ++i) by_degree[i] = i;
+    std::stable_sort(by_degree.begin(), by_degree.end(),
+                     [&](uint32_t x, uint32_t y) { return adj[x].size() < adj[y].size(); });
+    std::vector<uint32_t> nb;
+    for (uint32_t start : by_degree) {
+        if (seen[start]) continue;
+        // pseudo-peripheral start: walk to the last node of a BFS twice
+        uint32_t root = start;
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<uint32_t> q{root};
+            std::vector<uint8_t> mark(n, 0);
+            mark[root] = 1;
+            size_t head = 0;
+            while (head < q.size()) {
+                uint32_t u = q[head++];
+                for (uint32_t w : adj[u])
+                    if (!mark[w] && !seen[w]) {
+                        mark[w] = 1;
+                        q.push_back(w);
+                    }
+            }
+            root = q.back();
+        }
+        size_t head = order.size();
+        order.push_back(root);
+        seen[root] = 1;
+        while (head < order.size()) {
+            uint32_t u = order[head++];
+            nb.clear();
+            for (uint32_t w : adj[u])
+                if (!seen[w]) {
+                    seen[w] = 1;
+                    nb.push_back(w);
+                }
+            std::stable_sort(nb.begin(), nb.end(), [&](uint32_t x, uint32_t y) { return adj[x].size() < adj[y].size(); });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    return order;  // order[new] = old
+}
+
+struct ComponentPlan {
+    uint32_t m = 0, nv = 0, nnz_j = 0, nnz_a = 0, nnz_l = 0;
+    std::vector<uint32_t> rows, fvar;
+    std::vector<uint32_t> jrow_ptr, jslot;
+    std::vector<uint32_t> perm;                        // new column -> old column
+    std::vector<uint32_t> apair_ptr, apairs;           // gather lists of A
+    std::vector<uint32_t> cptr, cidx, crow;            // columns of J (permuted order) for the rhs
+    std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs;
+    std::vector<int32_t> l2a;
+};
+
+// Builds every index structure of one component. `colof[v]` = free column of system variable v
+// (ascending rank among the component's free variables) or -1.
+void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& rows,
+                    const std::vector<uint32_t>& fvar, ComponentPlan& P) {
+    const uint32_t e0 = b->expr_off[s], nvt = b->var_off[s + 1] - b->var_off[s];
+    P.rows = rows;
+    P.fvar = fvar;
+    P.m = (uint32_t)rows.size();
+    P.nv = (uint32_t)fvar.size();
+    std::vector<int32_t> colof(nvt, -1);
+    for (uint32_t k = 0; k < P.nv; ++k) colof[fvar[k]] = (int32_t)k;
+
+    // --- row patterns (old column numbering), adjacency of the column graph
+    std::vector<std::vector<uint32_t>> rowcols(P.m);
+    std::vector<std::vector<uint32_t>> adj(P.nv);
+    std::vector<uint32_t> entry_cols(8 * (size_t)P.m, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < P.m; ++r) {
+        uint32_t e = e0 + rows[r];
+        uint32_t vars8[8];
+        int k = expand_vars((int)b->expr_tag[e], b->expr_idx + 4 * (size_t)e, vars8);
+        auto& rc = rowcols[r];
+        for (int q = 0; q < k; ++q) {
+            int32_t c = colof[vars8[q]];
+            if (c < 0) continue;
+            entry_cols[8 * (size_t)r + q] = (uint32_t)c;
+            if (std::find(rc.begin(), rc.end(), (uint32_t)c) == rc.end()) rc.push_back((uint32_t)c);
+        }
+        for (uint32_t x : rc)
+            for (uint32_t y : rc)
+                if (x != y) adj[x].push_back(y);
+    }
+    for (auto& a : adj) {
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    P.perm = rcm_order(adj);
+    std::vector<uint32_t> iperm(P.nv);
+    for (uint32_t k = 0; k < P.nv; ++k) iperm[P.perm[k]] = k;
+
+    // --- J in CSR with columns in the permuted numbering, slots ascending by new column
+    P.jrow_ptr.assign((size_t)P.m + 1, 0);
+    P.jslot.assign(P.m, 0xFFFFFFFFu);
+    std::vector<uint32_t> jcol;  // new column of every J entry
+    for (uint32_t r = 0; r < P.m; ++r) {
+        std::vector<uint32_t> nc;
+        for (uint32_t c : rowcols[r]) nc.push_back(iperm[c]);
+        std::sort(nc.begin(), nc.end());
+        uint32_t slots = 0;
+        for (int q = 0; q < 8; ++q) {
+            uint32_t sl = 0xFu, c = entry_cols[8 * (size_t)r + q];
+            if (c != 0xFFFFFFFFu) sl = (uint32_t)(std::find(nc.begin(), nc.end(), iperm[c]) - nc.begin());
+            slots |= sl << (4 * q);
+        }
+        P.jslot[r] = slots;
+        jcol.insert(jcol.end(), nc.begin(), nc.end());
+        P.jrow_ptr[r + 1] = (uint32_t)jcol.size();
+    }
+    P.nnz_j = (uint32_t)jcol.size();
+
+    // --- columns of J (for the rhs) and pattern of A (lower triangle, new numbering)
+    std::vector<uint32_t> ccount(P.nv + 1, 0);
+    for (uint32_t c : jcol) ccount[c + 1]++;
+    for (uint32_t c = 0; c < P.nv; ++c) ccount[c + 1] += ccount[c];
+    P.cptr = ccount;
+    P.cidx.assign(P.nnz_j, 0);
+    P.crow.assign(P.nnz_j, 0);
+    {
+        std::vector<uint32_t> fill(P.cptr.begin(), P.cptr.end() - 1);
+        for (uint32_t r = 0; r < P.m; ++r)
+            for (uint32_t p = P.jrow_ptr[r]; p < P.jrow_ptr[r + 1]; ++p) {
+                uint32_t dst = fill[jcol[p]]++;
+                P.cidx[dst] = p;
+                P.crow[dst] = r;
+            }
+    }
+    // A[i][j] (i >= j) exists when some row holds both columns; list rows per (i,j) in row order
+    std::vector<std::vector<uint32_t>> acol(P.nv);  // rows i of column j (lower, incl. diagonal)
+    for (uint32_t r = 0; r < P.m; ++r)
+        for (uint32_t p = P.jrow_ptr[r]; p < P.jrow_ptr[r + 1]; ++p)
+            for (uint32_t q = P.jrow_ptr[r]; q <= p; ++q) acol[jcol[q]].push_back(jcol[p]);
+    std::vector<uint32_t> acolptr(P.nv + 1, 0);
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        std::sort(acol[j].begin(), acol[j].end());
+        acol[j].erase(std::unique(acol[j].begin(), acol[j].end()), acol[j].end());
+        acolptr[j + 1] = acolptr[j] + (uint32_t)acol[j].size();
+    }
+    P.nnz_a = acolptr[P.nv];
+    auto a_index = [&](uint32_t i, uint32_t j) {
+        return acolptr[j] + (uint32_t)(std::lower_bound(acol[j].begin(), acol[j].end(), i) - acol[j].begin());
+    };
+    std::vector<uint32_t> acount(P.nnz_a + 1, 0);
+    for (uint32_t r = 0; r < P.m; ++r)
+        for (uint32_t p = P.jrow_ptr[r]; p < P.jrow_ptr[r + 1]; ++p)
+            for (uint32_t q = P.jrow_ptr[r]; q <= p; ++q) acount[a_index(jcol[p], jcol[q]) + 1]++;
+    for (uint32_t k = 0; k < P.nnz_a; ++k) acount[k + 1] += acount[k];
+    P.apair_ptr = acount;
+    P.apairs.assign(2 * (size_t)acount[P.nnz_a], 0);
+    {
+        std::vector<uint32_t> fill(P.apair_ptr.begin(), P.apair_ptr.end() - 1);
+        for (uint32_t r = 0; r < P.m; ++r)
+            for (uint32_t p = P.jrow_ptr[r]; p < P.jrow_ptr[r + 1]; ++p)
+                for (uint32_t q = P.jrow_ptr[r]; q <= p; ++q) {
+                    uint32_t dst = fill[a_index(jcol[p], jcol[q])]++;
+                    P.apairs[2 * (size_t)dst] = p;
+                    P.apairs[2 * (size_t)dst + 1] = q;
+                }
+    }
+
+    // --- symbolic Cholesky: pattern(L_j) = pattern(A_j) U (patterns of the etree children \ child)
+    std::vector<std::vector<uint32_t>> lcol(P.nv);
+    std::vector<std::vector<uint32_t>> children(P.nv);
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        std::vector<uint32_t> pat = acol[j];  // sorted, starts with j (the diagonal always exists: damping)
+        if (pat.empty() || pat[0] != j) pat.insert(pat.begin(), j);
+        for (uint32_t ch : children[j]) {
+            std::vector<uint32_t> merged;
+            merged.reserve(pat.size() + lcol[ch].size());
+            std::set_union(pat.begin(), pat.end(), lcol[ch].begin() + 1, lcol[ch].end(), std::back_inserter(merged));
+            pat.swap(merged);
+        }
+        // entries of a child's pattern are > child and >= j by construction; drop anything < j
+        pat.erase(pat.begin(), std::lower_bound(pat.begin(), pat.end(), j));
+        lcol[j] = pat;
+        if (pat.size() > 1) children[pat[1]].push_back(j);  // etree parent = first sub-diagonal row
+    }
+    P.lcolptr.assign((size_t)P.nv + 1, 0);
+    for (uint32_t j = 0; j < P.nv; ++j) P.lcolptr[j + 1] = P.lcolptr[j] + (uint32_t)lcol[j].size();
+    P.nnz_l = P.lcolptr[P.nv];
+    P.lrow.resize(P.nnz_l);
+    P.l2a.assign(P.nnz_l, -1);
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        std::copy(lcol[j].begin(), lcol[j].end(), P.lrow.begin() + P.lcolptr[j]);
+        for (size_t t = 0; t < acol[j].size(); ++t) {
+            uint32_t i = acol[j][t];
+            uint32_t li = P.lcolptr[j] + (uint32_t)(std::lower_bound(lcol[j].begin(), lcol[j].end(), i) - lcol[j].begin());
+            P.l2a[li] = (int32_t)(acolptr[j] + t);
+        }
+    }
+    auto l_index = [&](uint32_t i, uint32_t j) {
+        return P.lcolptr[j] + (uint32_t)(std::lower_bound(lcol[j].begin(), lcol[j].end(), i) - lcol[j].begin());
+    };
+    // gather lists: column k updates L[i][j] for every pair j <= i of its sub-diagonal rows
+    std::vector<uint32_t> lcount((size_t)P.nnz_l + 1, 0);
+    for (uint32_t k = 0; k < P.nv; ++k)
+        for (size_t p = 1; p < lcol[k].size(); ++p)
+            for (size_t q = p; q < lcol[k].size(); ++q) lcount[l_index(lcol[k][q], lcol[k][p]) + 1]++;
+    for (uint32_t t = 0; t < P.nnz_l; ++t) lcount[t + 1] += lcount[t];
+    P.lpair_ptr = lcount;
+    P.lpairs.assign(2 * (size_t)lcount[P.nnz_l], 0);
+    {
+        std::vector<uint32_t> fill(P.lpair_ptr.begin(), P.lpair_ptr.end() - 1);
+        for (uint32_t k = 0; k < P.nv; ++k)
+            for (size_t p = 1; p < lcol[k].size(); ++p)
+                for (size_t q = p; q < lcol[k].size(); ++q) {
+                    uint32_t dst = fill[l_index(lcol[k][q], lcol[k][p])]++;
+                    P.lpairs[2 * (size_t)dst] = P.lcolptr[k] + (uint32_t)q;      // L[i][k]
+                    P.lpairs[2 * (size_t)dst + 1] = P.lcolptr[k] + (uint32_t)p;  // L[j][k]
+                }
+    }
+}
+
+inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block ? (n + block - 1) / block : 1); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host: LM driver for one System (all of its components), numerics on the device
+// ------------------------------------------------------------------------------------------------
+hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
+                               double* d_vars_out /* device, n_vars of the System */, fx_result* result) {
+    const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
+    const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
+    const fx_lm_opts o = prm.lm;
+    const int do_scale = (prm.mode & 1u) ? 1 : 0;
+    Pool pool;
+    pool.stream = stream;
+
+    // ---- System-wide device data
+    std::vector<uint8_t> tags(b->expr_tag + e0, b->expr_tag + e0 + net);
+    std::vector<uint16_t> idx16(4 * (size_t)net);
+    for (size_t q = 0; q < idx16.size(); ++q) idx16[q] = (uint16_t)b->expr_idx[4 * (size_t)e0 + q];
+    std::vector<double> params(b->expr_param + e0, b->expr_param + e0 + net);
+    std::vector<double> vars0(b->vars + v0, b->vars + v0 + nvt);
+    SpRows rows;
+    rows.tag = pool.up(tags);
+    rows.idx = pool.up(idx16);
+    rows.param = pool.up(params);
+    rows.sparam = pool.alloc<double>(net);
+    rows.net = net;
+    double* d_vars0 = pool.up(vars0);
+    double* d_xs[2] = {pool.alloc<double>(nvt), pool.alloc<double>(nvt)};
+    double* d_snap = pool.alloc<double>(nvt);  // pre-solve snapshot (quirk Q2)
+    double* d_scal = pool.alloc<double>(8);       // scale, 1/scale, sse, dn2, sse_unscaled
+    uint32_t* d_flag = pool.alloc<uint32_t>(2);
+    double* d_runs = pool.alloc<double>(std::max(net, 1u));
+    if (pool.err != hipSuccess) return pool.err;
+
+    hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(64), 0, stream, d_vars0, nvt, rows, d_scal, do_scale);
+    hipLaunchKernelGGL(sp_init_kernel, grid_for(std::max(nvt, net)), dim3(256), 0, stream, d_vars0, nvt, rows, d_scal,
+                       d_xs[0], d_xs[1], do_scale);
+    hipError_t e = hipMemcpyAsync(d_vars_out, d_vars0, nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+
+    // ---- components in order (assemble/mod.rs:81)
+    uint32_t ncomp = 0;
+    for (uint32_t i = 0; i < nvt; ++i) {
+        uint16_t c = b->var_comp ? b->var_comp[v0 + i] : 0;
+        if (c != FX_NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, c + 1u);
+    }
+    for (uint32_t i = 0; i < net; ++i) {
+        uint16_t c = b->expr_comp ? b->expr_comp[e0 + i] : 0;
+        if (c != FX_NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, c + 1u);
+    }
+    fx_result res{};
+    res.exit = FX_EXIT_SSE;
+    uint32_t rng = 42u;  // Rng::from_seed(42), shared by the components (:47)
+    double host3[4];
+
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        std::vector<uint32_t> crow_ids, fvar;
+        bool any_var = false;
+        for (uint32_t i = 0; i < nvt; ++i) {
+            uint16_t vc = b->var_comp ? b->var_comp[v0 + i] : 0;
+            if (vc != c) continue;
+            any_var = true;
+            if (!b->var_fixed[v0 + i]) fvar.push_back(i);
+        }
+        if (!any_var) continue;
+        for (uint32_t i = 0; i < net; ++i)
+            if ((b->expr_comp ? b->expr_comp[e0 + i] : 0) == c) crow_ids.push_back(i);
+
+        ComponentPlan P;
+        plan_component(b, s, crow_ids, fvar, P);
+        const uint32_t m = P.m, nv = P.nv;
+
+        uint32_t* d_fvar = pool.up(P.fvar);
+        uint32_t* d_perm = pool.up(P.perm);
+        SpJac jac;
+        jac.rows = pool.up(P.rows);
+        jac.jrow_ptr = pool.up(P.jrow_ptr);
+        jac.jslot = pool.up(P.jslot);
+        jac.m = m;
+        uint32_t* d_apair_ptr = pool.up(P.apair_ptr);
+        uint32_t* d_apairs = pool.up(P.apairs);
+        uint32_t* d_cptr = pool.up(P.cptr);
+        uint32_t* d_cidx = pool.up(P.cidx);
+        uint32_t* d_crow = pool.up(P.crow);
+        SpChol chol;
+        chol.lcolptr = pool.up(P.lcolptr);
+        chol.lrow = pool.up(P.lrow);
+        chol.l2a = pool.up(P.l2a);
+        chol.lpair_ptr = pool.up(P.lpair_ptr);
+        chol.lpairs = pool.up(P.lpairs);
+        chol.nv = nv;
+        double* d_r[2] = {pool.alloc<double>(m), pool.alloc<double>(m)};
+        double* d_j[2] = {pool.alloc<double>(P.nnz_j), pool.alloc<double>(P.nnz_j)};
+        double* d_a = pool.alloc<double>(P.nnz_a);
+        double* d_l = pool.alloc<double>(P.nnz_l);
+        double* d_rhs = pool.alloc<double>(nv);
+        double* d_delta = pool.alloc<double>(nv);
+        if (pool.err != hipSuccess) return pool.err;
+
+        if (prm.mode & 2u) {
+            if (nv) hipLaunchKernelGGL(sp_perturb_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, rng, d_xs[0], d_xs[1]);
+            for (uint32_t k = 0; k < 2 * nv; ++k) rng = rng * 1664525u + 1013904223u;  // integer bookkeeping only
+        }
+
+        e = hipMemcpyAsync(d_snap, d_xs[0], nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+
+        auto eval = [&](int buf, bool want_j, double* sse_out) -> hipError_t {
+            if (m) {
+                if (want_j)
+                    hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
+                else
+                    hipLaunchKernelGGL(sp_eval_kernel<false>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
+            }
+            hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[buf], m, d_scal + 2);
+            hipError_t er = hipMemcpyAsync(sse_out, d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (er == hipSuccess) er = hipStreamSynchronize(stream);
+            return er;
+        };
+        auto form = [&](int buf) {
+            if (P.nnz_a) hipLaunchKernelGGL(sp_form_a_kernel, grid_for(P.nnz_a), dim3(256), 0, stream, d_apair_ptr, d_apairs, d_j[buf], P.nnz_a, d_a);
+            if (nv) hipLaunchKernelGGL(sp_rhs_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf], d_r[buf], nv, d_rhs);
+        };
+
+        int cur = 0;
+        double sse = 0.0;
+        e = eval(0, true, &sse);
+        if (e != hipSuccess) return e;
+        const double sse_start = sse;
+        form(0);
+        double lambda = o.lambda0;
+        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
+        bool done = false;
+        if (!(sse == sse) || !(sse < 1.0e300)) {
+            exit_code = FX_EXIT_NAN;
+            done = true;
+        }
+        for (uint32_t outer = 0; outer < o.max_outer && !done; ++outer) {
+            if (sse < o.sse_tol) {
+                exit_code = FX_EXIT_SSE;
+                break;
+            }
+            for (;;) {
+                if (trials >= o.max_trials) {
+                    exit_code = FX_EXIT_TRIAL_CAP;
+                    done = true;
+                    break;
+                }
+                trials += 1;
+                const int trial = cur ^ 1;
+                // factor, solve, trial point, trial residuals (+ Jacobian: it becomes J on acceptance)
+                hipLaunchKernelGGL(sp_factor_kernel, dim3(1), dim3(64), 0, stream, chol, d_a, lambda, d_l, d_flag);
+                e = hipMemcpyAsync(d_delta, d_rhs, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(sp_solve_kernel, dim3(1), dim3(64), 0, stream, chol, d_l, d_delta, d_scal + 3);
+                if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);
+                if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[trial], d_r[trial], d_j[trial]);
+                hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[trial], m, d_scal + 2);
+                uint32_t hflag = 0;
+                e = hipMemcpyAsync(host3, d_scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(&hflag, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) return e;
+                const double sse_t = host3[0], dn2 = host3[1];
+                if (hflag) {  // lm.rs:134-137
+                    lambda *= o.singular_factor;
+                    if (!(lambda < 1.0e300)) {
+                        exit_code = FX_EXIT_NAN;
+                        done = true;
+                        break;
+                    }
+                    continue;
+                }
+                if (!(dn2 == dn2)) {
+                    exit_code = FX_EXIT_NAN;
+                    done = true;
+                    break;
+                }
+                if (dn2 < o.step_tol) {  // lm.rs:139-142
+                    exit_code = FX_EXIT_STEP;
+                    done = true;
+                    break;
+                }
+                if (sse_t < sse) {  // accept
+                    lambda *= o.accept_factor;
+                    if (lambda < o.lambda_min) lambda = o.lambda_min;
+                    cur = trial;
+                    accepted += 1;
+                    double rel = (sse - sse_t) / sse;
+                    sse = sse_t;
+                    if (rel <= o.ftol) {
+                        exit_code = FX_EXIT_FTOL;
+                        done = true;
+                        break;
+                    }
+                    form(cur);
+                    break;
+                } else {
+                    lambda *= o.reject_factor;
+                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
+                        exit_code = FX_EXIT_NAN;
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+        // accepted point -> output; later components see the pre-solve snapshot (quirk Q2)
+        if (nv) {
+            hipLaunchKernelGGL(sp_writeback_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_scal, do_scale, d_vars_out);
+            hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[0]);
+            hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[1]);
+        }
+        res.accepted += accepted;
+        res.trials += trials;
+        res.exit = exit_code;
+        res.sse0 += sse_start;
+        res.sse += sse;
+        res.ncomp += 1;
+    }
+
+    // ---- post-solve check on the unscaled variables
+    if (net) hipLaunchKernelGGL(sp_identity_residual_kernel, grid_for(net), dim3(256), 0, stream, rows, d_vars_out, d_runs);
+    hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_runs, net, d_scal + 4);
+    e = hipMemcpyAsync(host3, d_scal, sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host3 + 1, d_scal + 4, sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    res.scale = host3[0];
+    res.sse_unscaled = host3[1];
+    if (result) *result = res;
+    e = hipGetLastError();
+    return e;
+}
+
+}  // namespace fx

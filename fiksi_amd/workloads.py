@@ -215,3 +215,47 @@ def shard(batch: Dict[str, np.ndarray], rank: int, world: int) -> Dict[str, np.n
     for k in ("expr_tag", "expr_param", "expr_comp"):
         out[k] = batch[k][e0:e1].copy()
     return out
+
+
+def large_sketch(n_points: int = 5000, seed: int = 7, noise: float = 0.01) -> Dict[str, np.ndarray]:
+    """cfg2 (SURVEY.md §8d): ONE large sketch. ``n_points`` ground-truth points uniform in [0,100]^2;
+    n-1 chain distances (i,i+1); skip distances (i,i+2) for the first 0.4*n+1 even i; 0.6*n
+    three-point angles (i-1,i,i+1), odd i first, then even i; targets from the ground truth; start =
+    truth + noise*100*U(-1,1). For n = 5000: 10 000 variables, 10 000 expressions (4999 + 2001
+    distances, 3000 angles), 46 000 Jacobian non-zeros."""
+    n = int(n_points)
+    rng = LcgVec(np.array([seed], dtype=np.uint64))
+
+    def draws(k):
+        return np.array([rng.next_f64()[0] for _ in range(k)])
+
+    truth = 100.0 * draws(2 * n).reshape(n, 2)
+    start = truth + noise * 100.0 * (2.0 * draws(2 * n).reshape(n, 2) - 1.0)
+    n_skip = (2 * n) // 5 + 1
+    n_ang = (3 * n) // 5
+    tags, idx, par = [], [], []
+
+    def dist(a, b):
+        d = truth[a] - truth[b]
+        return float(np.sqrt(d[0] * d[0] + d[1] * d[1]))
+
+    for i in range(n - 1):
+        tags.append(abi.POINT_POINT_DISTANCE); idx.append((2 * i, 2 * (i + 1), 0, 0)); par.append(dist(i, i + 1))
+    for i in list(range(0, n - 2, 2))[:n_skip]:
+        tags.append(abi.POINT_POINT_DISTANCE); idx.append((2 * i, 2 * (i + 2), 0, 0)); par.append(dist(i, i + 2))
+    for i in (list(range(1, n - 1, 2)) + list(range(2, n - 1, 2)))[:n_ang]:
+        u, v = truth[i - 1] - truth[i], truth[i + 1] - truth[i]
+        ang = float(_wrap(np.arctan2(v[1], v[0]) - np.arctan2(u[1], u[0])))
+        tags.append(abi.POINT_POINT_POINT_ANGLE); idx.append((2 * (i - 1), 2 * i, 2 * (i + 1), 0)); par.append(ang)
+    m = len(tags)
+    return {
+        "var_off": np.array([0, 2 * n], dtype=np.uint32),
+        "expr_off": np.array([0, m], dtype=np.uint32),
+        "vars": start.reshape(-1).copy(),
+        "var_fixed": np.zeros(2 * n, dtype=np.uint8),
+        "expr_tag": np.array(tags, dtype=np.uint8),
+        "expr_idx": np.array(idx, dtype=np.uint32).reshape(-1),
+        "expr_param": np.array(par, dtype=np.float64),
+        "var_comp": np.zeros(2 * n, dtype=np.uint16),
+        "expr_comp": np.zeros(m, dtype=np.uint16),
+    }

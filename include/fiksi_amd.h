@@ -46,7 +46,7 @@ typedef enum fx_status {
     FX_ERR_INVALID = -1,     /* NULL pointer, inconsistent offsets, index out of range, bad tag */
     FX_ERR_NO_DEVICE = -2,   /* no usable HIP device (no CPU fallback exists)                   */
     FX_ERR_HIP = -3,         /* a HIP runtime call failed; see fx_last_error                    */
-    FX_ERR_TOO_LARGE = -4,   /* a system exceeds the per-wavefront limits (see FX_MAX_*)        */
+    FX_ERR_TOO_LARGE = -4,   /* a system exceeds FX_MAX_LARGE_SYSTEM_VARS                       */
     FX_ERR_NOMEM = -5,
     FX_ERR_UNSUPPORTED = -6
 } fx_status;
@@ -67,10 +67,13 @@ typedef enum fx_tag {
     FX_NUM_TAGS = 11
 } fx_tag;
 
-/* Per-wavefront limits of the fused solve kernel (one wavefront per connected component). */
-#define FX_MAX_FREE_VARS 64u   /* free variables (Jacobian columns) per component            */
-#define FX_MAX_ROWS 256u       /* expressions (Jacobian rows) per component                  */
-#define FX_MAX_SYSTEM_VARS 512u/* variables (free + fixed) per System                        */
+/* One-wavefront limits of the fused solve kernel (one wavefront per System). Systems within them
+ * are solved thousands at a time; a System beyond them (more free variables or expressions in a
+ * component, or more variables) is solved by the sparse large-sketch path, one at a time. */
+#define FX_MAX_FREE_VARS 64u          /* free variables (Jacobian columns) per component          */
+#define FX_MAX_ROWS 256u              /* expressions (Jacobian rows) per component                */
+#define FX_MAX_SYSTEM_VARS 512u       /* variables (free + fixed) per System, fused kernel        */
+#define FX_MAX_LARGE_SYSTEM_VARS 65535u /* variables per System, sparse path (16-bit local indices) */
 #define FX_NO_COMPONENT 0xFFFFu
 
 /*

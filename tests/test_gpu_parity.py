@@ -212,13 +212,77 @@ def test_limits_are_reported_not_crashed(fiksi, ctx):
     from fiksi_amd import workloads
     from fiksi_amd._lib import FiksiError
 
-    big = workloads.hinged_triangles(1, 40)  # 162 variables > 64 free per component
-    with pytest.raises(FiksiError) as e:
-        ctx.system_solve_batch(big)
-    assert e.value.code == -4
     bad = workloads.quadrilateral()
     bad["expr_idx"] = bad["expr_idx"].copy()
     bad["expr_idx"][0] = 99
     with pytest.raises(FiksiError) as e:
         ctx.system_solve_batch(bad)
     assert e.value.code == -1
+    # more than 65535 variables in one System: 16-bit local indices are exhausted
+    n = 70000
+    huge = {
+        "var_off": np.array([0, n], dtype=np.uint32), "expr_off": np.array([0, 1], dtype=np.uint32),
+        "vars": np.zeros(n), "var_fixed": np.zeros(n, dtype=np.uint8), "expr_tag": np.ones(1, dtype=np.uint8),
+        "expr_idx": np.array([0, 2, 0, 0], dtype=np.uint32), "expr_param": np.ones(1),
+    }
+    with pytest.raises(FiksiError) as e:
+        ctx.system_solve_batch(huge)
+    assert e.value.code == -4
+
+
+# ---- sparse large-sketch path (components beyond the one-wavefront limits) -------------------------
+
+def test_large_sketch_path_matches_oracle(fiksi, oracle, ctx):
+    """Systems with more than 64 free variables go through fx_sparse.hip: same iteration counts as the
+    oracle, positions to ~1e-10 (these sketches are well conditioned)."""
+    from fiksi_amd import workloads
+
+    for b in (workloads.hinged_triangles(1, 16), workloads.hinged_triangles(2, 64), workloads.large_sketch(300)):
+        v, res = ctx.system_solve_batch(b)
+        v_o, res_o = oracle.solve_batch(b, mode=3)
+        assert np.array_equal(res["accepted"], res_o["accepted"])
+        assert np.array_equal(res["trials"], res_o["trials"])
+        assert np.array_equal(res["exit"], res_o["exit"])
+        assert np.array_equal(res["scale"], res_o["scale"])
+        assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+        assert np.max(np.abs(v - v_o)) <= 1e-9 * res_o["scale"].max()
+        r = oracle.residuals_batch(b, v)
+        assert float((r * r).sum()) < 1e-4  # fiksi_bench.rs:65-72 spot-check (n = 16, 64)
+
+
+def test_mixed_small_and_large_systems_in_one_batch(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.concat([workloads.ring16(5), workloads.hinged_triangles(1, 20), workloads.ring16(3, seed0=77),
+                          workloads.large_sketch(120), workloads.quadrilateral()])
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.array_equal(res["exit"], res_o["exit"])
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+    # device-resident batch: same answer, repeatable
+    db = ctx.upload(b)
+    db.system_solve()
+    assert np.array_equal(db.get_vars(), v)
+    db.free()
+
+
+def test_component_quirks_q1_q2_match_oracle(fiksi, oracle, ctx):
+    """graph.rs:211-222 (stale component label, quirk Q1) + assemble/mod.rs:161-166 (later components
+    read the pre-solve snapshot, quirk Q2): d belongs to the first component and is read as a fixed
+    value, at its PRE-solve position, by the second one."""
+    from fiksi_amd import System, constraints, elements
+
+    s = System()
+    a, b_, c, d, e = (elements.Point.create(s, 1.3 * i, 0.4 * i * i) for i in range(5))
+    constraints.PointPointDistance.create(s, a, b_, 2.)
+    constraints.PointPointDistance.create(s, c, d, 2.)
+    constraints.PointPointDistance.create(s, a, c, 3.)
+    constraints.PointPointDistance.create(s, d, e, 1.)
+    flat = s.flatten()
+    assert flat["var_comp"].tolist() == [0] * 8 + [1, 1]
+    v, res = ctx.system_solve_batch(flat)
+    v_o, res_o = oracle.solve_batch(flat, mode=3)
+    assert res["ncomp"][0] == res_o["ncomp"][0] == 2
+    assert res["accepted"][0] == res_o["accepted"][0]
+    assert np.max(np.abs(v - v_o)) < 1e-9

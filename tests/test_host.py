@@ -87,9 +87,7 @@ def test_validate_rejects_bad_batches(fiksi):
     bad["var_off"][2] = bad["var_off"][1] - 1
     with pytest.raises(FiksiError):
         abi.validate(bad)
-    with pytest.raises(FiksiError) as e:
-        abi.validate(workloads.hinged_triangles(1, 40))
-    assert e.value.code == -4
+    abi.validate(workloads.hinged_triangles(1, 40))  # beyond one wavefront: sparse path, not an error
 
 
 def test_jacobian_structure_matches_reference_assembly(fiksi, oracle):
