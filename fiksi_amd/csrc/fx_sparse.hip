@@ -235,13 +235,33 @@ struct SpChol {                  // symbolic factor (device)
 };
 
 // K4a: numeric sparse Cholesky of A + lambda I, left-looking by gather lists, one wavefront walks
-// the columns in order. flag[0] = 1 when a pivot is not positive and finite.
+// the columns in order. flag[0] = 1 when a pivot is not positive and finite. Columns of up to 64
+// entries (the usual case) take one pass and one barrier: the pivot travels by v_readlane.
 __global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* __restrict__ a, double lambda,
                                                        double* __restrict__ l, uint32_t* __restrict__ flag) {
     const int lane = threadIdx.x;
     bool bad = false;
     for (uint32_t j = 0; j < c.nv; ++j) {
         const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
+        if (end - beg <= 64u) {
+            const uint32_t k = beg + lane;
+            double s = 0.0;
+            if (k < end) {
+                int32_t ai = c.l2a[k];
+                s = ai >= 0 ? a[ai] : 0.0;
+                if (k == beg) s += lambda;
+                for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
+                    s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
+            }
+            int lo = __builtin_amdgcn_readfirstlane(__double2loint(s));
+            int hi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
+            double piv = __hiloint2double(hi, lo);
+            bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
+            double d = ::sqrt(piv);
+            if (k < end) l[k] = (k == beg) ? d : s / d;
+            __syncthreads();
+            continue;
+        }
         for (uint32_t base = beg; base < end; base += 64) {
             uint32_t k = base + lane;
             if (k < end) {
@@ -257,12 +277,11 @@ __global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* _
         double piv = ld_l2(l + beg);
         bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
         double d = ::sqrt(piv);
-        double inv = 1.0 / d;
         for (uint32_t base = beg; base < end; base += 64) {
             uint32_t k = base + lane;
             if (k < end) {
                 double raw = ld_l2(l + k);
-                l[k] = (k == beg) ? d : raw * inv;
+                l[k] = (k == beg) ? d : raw / d;
             }
         }
         __syncthreads();
@@ -270,31 +289,48 @@ __global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* _
     if (lane == 0) flag[0] = bad ? 1u : 0u;
 }
 
-// K4b: L y = b (column sweep), Lt x = y (row gathers); x overwrites b; out[0] = |x|^2.
+// K4b: L y = b (column sweep), Lt x = y (row gathers); x overwrites b; out[0] = |x|^2. With
+// IN_LDS the right-hand side lives in LDS for the two sweeps (nv * 8 bytes <= 160 KB).
+template <bool IN_LDS>
 __global__ __launch_bounds__(64) void sp_solve_kernel(SpChol c, const double* __restrict__ l, double* __restrict__ b,
                                                       double* __restrict__ out) {
+    extern __shared__ __align__(16) double sb[];
     const int lane = threadIdx.x;
+    if (IN_LDS) {
+        for (uint32_t i = lane; i < c.nv; i += 64) sb[i] = b[i];
+        __syncthreads();
+    }
+    auto get = [&](uint32_t i) -> double { return IN_LDS ? sb[i] : ld_l2(b + i); };
+    auto put = [&](uint32_t i, double v) {
+        if (IN_LDS) sb[i] = v; else b[i] = v;
+    };
     for (uint32_t j = 0; j < c.nv; ++j) {
         const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
-        double yj = ld_l2(b + j) / l[beg];
+        // One wavefront: LDS operations retire in program order, so in LDS mode the sweeps need no
+        // barrier at all; the global-memory fallback waits for its stores at every column.
+        double yj = get(j) / l[beg];
         for (uint32_t k = beg + 1 + lane; k < end; k += 64) {
             uint32_t i = c.lrow[k];
-            b[i] = ld_l2(b + i) - l[k] * yj;  // rows of one column are distinct: no conflicts
+            put(i, get(i) - l[k] * yj);  // rows of one column are distinct: no conflicts
         }
-        if (lane == 0) b[j] = yj;
-        __syncthreads();
+        if (lane == 0) put(j, yj);
+        if (!IN_LDS) __syncthreads();
     }
     double n2 = 0.0;
     for (uint32_t jj = c.nv; jj-- > 0;) {
         const uint32_t beg = c.lcolptr[jj], end = c.lcolptr[jj + 1];
         double part = 0.0;
-        for (uint32_t k = beg + 1 + lane; k < end; k += 64) part += l[k] * ld_l2(b + c.lrow[k]);
+        for (uint32_t k = beg + 1 + lane; k < end; k += 64) part += l[k] * get(c.lrow[k]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        double xj = (ld_l2(b + jj) - part) / l[beg];
-        if (lane == 0) b[jj] = xj;
+        double xj = (get(jj) - part) / l[beg];
+        if (lane == 0) put(jj, xj);
         n2 += xj * xj;
-        __syncthreads();
+        if (!IN_LDS) __syncthreads();
+    }
+    if (IN_LDS) __syncthreads();
+    if (IN_LDS) {
+        for (uint32_t i = lane; i < c.nv; i += 64) b[i] = sb[i];
     }
     if (lane == 0) out[0] = n2;
 }
@@ -750,7 +786,15 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 hipLaunchKernelGGL(sp_factor_kernel, dim3(1), dim3(64), 0, stream, chol, d_a, lambda, d_l, d_flag);
                 e = hipMemcpyAsync(d_delta, d_rhs, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
                 if (e != hipSuccess) return e;
-                hipLaunchKernelGGL(sp_solve_kernel, dim3(1), dim3(64), 0, stream, chol, d_l, d_delta, d_scal + 3);
+                if ((size_t)nv * sizeof(double) <= 150u * 1024u) {
+                    size_t lds = (size_t)nv * sizeof(double);
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_solve_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(sp_solve_kernel<true>, dim3(1), dim3(64), lds, stream, chol, d_l, d_delta, d_scal + 3);
+                } else {
+                    hipLaunchKernelGGL(sp_solve_kernel<false>, dim3(1), dim3(64), 0, stream, chol, d_l, d_delta, d_scal + 3);
+                }
                 if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);
                 if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[trial], d_r[trial], d_j[trial]);
                 hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[trial], m, d_scal + 2);
