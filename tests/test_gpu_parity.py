@@ -286,3 +286,25 @@ def test_component_quirks_q1_q2_match_oracle(fiksi, oracle, ctx):
     assert res["ncomp"][0] == res_o["ncomp"][0] == 2
     assert res["accepted"][0] == res_o["accepted"][0]
     assert np.max(np.abs(v - v_o)) < 1e-9
+
+
+def test_cfg2_one_large_sketch_matches_oracle_fixture(fiksi, ctx):
+    """BASELINE cfg2: ONE sketch of 5 000 points / 10 000 mixed distance + angle constraints (10 000
+    variables, 46 000 Jacobian non-zeros), f64, one MI355X. The oracle needs ~85 s for it, so its outcome
+    is a committed fixture (tests/golden/cfg2_oracle.json, made by tests/golden/make_cfg2_golden.py)."""
+    import json
+    import os
+
+    from fiksi_amd import workloads
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cfg2_oracle.json")))
+    b = workloads.large_sketch(5000)
+    assert int(b["var_off"][-1]) == 10000 and int(b["expr_off"][-1]) == 10000
+    v, res = ctx.system_solve_batch(b)
+    r = res[0]
+    assert (int(r["accepted"]), int(r["trials"]), int(r["exit"])) == (gold["accepted"], gold["trials"], gold["exit"])
+    assert r["scale"] == gold["scale"]
+    assert abs(r["sse0"] - gold["sse0"]) <= 1e-9 * gold["sse0"]
+    assert abs(r["sse"] - gold["sse"]) <= 1e-9 + 1e-6 * gold["sse"]
+    assert abs(r["sse_unscaled"] - gold["sse_unscaled"]) <= 1e-6 * gold["sse_unscaled"] + 1e-9
+    assert np.max(np.abs(v[::97] - np.array(gold["vars_every_97th"]))) <= 1e-6 * gold["scale"]
