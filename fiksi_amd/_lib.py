@@ -43,7 +43,7 @@ class FxLmOpts(C.Structure):
         ("lambda0", C.c_double), ("sse_tol", C.c_double), ("step_tol", C.c_double), ("ftol", C.c_double),
         ("accept_factor", C.c_double), ("reject_factor", C.c_double), ("singular_factor", C.c_double),
         ("lambda_min", C.c_double), ("max_outer", C.c_uint32), ("max_trials", C.c_uint32),
-        ("solver", C.c_uint32), ("reserved", C.c_uint32),
+        ("solver", C.c_uint32), ("precision", C.c_uint32),
     ]
 
 
@@ -72,6 +72,7 @@ SIGNATURES = [
     ("fx_ctx_synchronize", C.c_int, [_vp]),
     ("fx_ctx_device_name", C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     ("fx_lm_opts_default", None, [C.POINTER(FxLmOpts)]),
+    ("fx_lm_opts_default_f32", None, [C.POINTER(FxLmOpts)]),
     ("fx_solving_opts_default", None, [C.POINTER(FxSolvingOpts)]),
     ("fx_batch_validate", C.c_int, [C.POINTER(FxBatch)]),
     ("fx_jacobian_structure", C.c_int, [C.POINTER(FxBatch), u64p, _vp, _vp]),

@@ -57,17 +57,19 @@ def as_struct(arrays: Dict[str, np.ndarray]) -> FxBatch:
     return b
 
 
-def lm_opts(**kw) -> FxLmOpts:
+def lm_opts(f32: bool = False, **kw) -> FxLmOpts:
     o = FxLmOpts()
-    lib.fx_lm_opts_default(C.byref(o))
+    (lib.fx_lm_opts_default_f32 if f32 else lib.fx_lm_opts_default)(C.byref(o))
     for k, v in kw.items():
         setattr(o, k, v)
     return o
 
 
-def solving_opts(perturb: bool = True, **lm_kw) -> FxSolvingOpts:
+def solving_opts(perturb: bool = True, f32: bool = False, **lm_kw) -> FxSolvingOpts:
     o = FxSolvingOpts()
     lib.fx_solving_opts_default(C.byref(o))
+    if f32:
+        lib.fx_lm_opts_default_f32(C.byref(o.lm))
     o.perturb = 1 if perturb else 0
     for k, v in lm_kw.items():
         setattr(o.lm, k, v)

@@ -366,7 +366,15 @@ void fx_lm_opts_default(fx_lm_opts* o) {
     o->max_outer = 100;
     o->max_trials = 4096;
     o->solver = FX_STEP_CHOLESKY;
-    o->reserved = 0;
+    o->precision = 64;
+}
+
+void fx_lm_opts_default_f32(fx_lm_opts* o) {
+    if (!o) return;
+    fx_lm_opts_default(o);
+    o->ftol = 1e-5;        // f32 SSE carries ~1e-6 relative round-off
+    o->lambda_min = 1e-7;  // keeps JtJ + lambda I numerically positive definite in f32
+    o->precision = 32;
 }
 
 void fx_solving_opts_default(fx_solving_opts* o) {

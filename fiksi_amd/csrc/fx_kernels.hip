@@ -27,10 +27,8 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {  // src_lane m
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double first_lane(double v) {
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ float bcast(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 __device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_readfirstlane((int)c) != 0; }
 
@@ -43,13 +41,44 @@ __device__ __forceinline__ double dpp_move(double v) {
     int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum(double v) {
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
     v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
     v += dpp_move<0x141>(v);  // row_half_mirror
     v += dpp_move<0x140>(v);  // row_mirror
     return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
 }
+
+// per-precision pieces of the linear algebra
+__device__ __forceinline__ void lds_add(double* p, double v) {
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+}
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, 0, 0, false);
+}
+// 1/sqrt(p): hardware seed + Newton steps y <- y + y*(1 - p*y*y)/2 (v_rsq_f64 ~23 bits -> two steps;
+// v_rsq_f32 ~1 ulp -> one step)
+__device__ __forceinline__ double rsqrt_refined(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    y = fma(0.5 * y, fma(-p * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-p * y, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ float rsqrt_refined(float p) {
+    float y = __builtin_amdgcn_rsqf(p);
+    return fmaf(0.5f * y, fmaf(-p * y, y, 1.0f), y);
+}
+template <typename T> struct Lim;
+template <> struct Lim<double> { static __device__ __forceinline__ double huge() { return 1.0e300; } };
+template <> struct Lim<float> { static __device__ __forceinline__ float huge() { return 1.0e30f; } };
+template <typename T> struct Vec16;  // 16-byte LDS vector of T
+template <> struct Vec16<double> { using type = double2; static constexpr int n = 2; };
+template <> struct Vec16<float> { using type = float4; static constexpr int n = 4; };
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
 
 // ------------------------------------------------------------------------------------------
@@ -62,7 +91,7 @@ struct SolveLayout {
     uint32_t total;
 };
 
-static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows) {
+static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows, uint32_t es /* sizeof(T) */) {
     SolveLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -70,12 +99,12 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     if (L.mr == 0) L.mr = 8;
     uint32_t o = 0;
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
-    L.off_xs = take(2u * L.vt * 8u);
-    L.off_a = take(n_pad * (n_pad + 2u) * 8u);
-    L.off_rhs = take(n_pad * 8u);
-    L.off_g = take(2u * L.mr * 8u * 8u);
-    L.off_r = take(2u * L.mr * 8u);
-    L.off_p = take(L.mr * 8u);
+    L.off_xs = take(2u * L.vt * es > L.vt * 8u ? 2u * L.vt * es : L.vt * 8u);  // also holds nvt doubles at the end
+    L.off_a = take(n_pad * (n_pad + 16u / es) * es);
+    L.off_rhs = take(n_pad * es);
+    L.off_g = take(2u * L.mr * 8u * es);
+    L.off_r = take(2u * L.mr * es);
+    L.off_p = take(L.mr * es);
     L.off_gvar = take(L.mr * 8u * 2u);
     L.off_gcol = take(L.mr * 8u);
     L.off_rtag = take(L.mr);
@@ -90,7 +119,7 @@ static uint32_t pad_n(uint32_t max_free) {
     return n < 8u ? 8u : n;
 }
 
-size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows).total; }
+size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows, 8u).total; }
 
 // ------------------------------------------------------------------------------------------
 // register-resident Cholesky of the N x N SPD matrix held one column per lane
@@ -100,25 +129,22 @@ size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_fr
 // a[i] = L[i][k] * d_k for i > k (column k of L, scaled) — both triangular solves then need only
 // wave-uniform broadcasts (v_readlane), never a per-lane register index. invd = 1 / d_lane.
 // Returns false (wave-uniform) when a pivot is not positive and finite.
-template <int N>
-__device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int lane) {
+template <int N, typename T>
+__device__ __forceinline__ bool chol_factor(T (&a)[N], T& invd, int lane) {
     bool bad = false;  // wave-uniform; checked once at the end (a bad pivot only produces NaN/Inf junk)
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        double piv = bcast(a[k], k);
-        bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
-        // 1/sqrt(pivot): v_rsq_f64 seed (~23 bits) + two Newton steps y <- y + y*(1 - p*y*y)/2
-        double rs = __builtin_amdgcn_rsq(piv);
-        rs = fma(0.5 * rs, fma(-piv * rs, rs, 1.0), rs);
-        rs = fma(0.5 * rs, fma(-piv * rs, rs, 1.0), rs);
-        double ip = rs * rs;  // 1/pivot
-        double ljk = a[k] * rs;
-        double mul = (lane > k) ? a[k] * ip : 0.0;  // A_jk / pivot; 0 keeps lanes <= k untouched
+        T piv = bcast(a[k], k);
+        bad = bad || !(piv > T(0)) || !(piv < Lim<T>::huge());
+        T rs = rsqrt_refined(piv);
+        T ip = rs * rs;  // 1/pivot
+        T ljk = a[k] * rs;
+        T mul = (lane > k) ? a[k] * ip : T(0);  // A_jk / pivot; 0 keeps lanes <= k untouched
         if (lane >= k) a[k] = ljk;
         if (lane == k) invd = rs;
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
-            double aik = bcast(a[i], k);  // lane k still holds A_ik = L_ik * d_k
+            T aik = bcast(a[i], k);  // lane k still holds A_ik = L_ik * d_k
             a[i] = fma(-aik, mul, a[i]);
         }
     }
@@ -126,19 +152,19 @@ __device__ __forceinline__ bool chol_factor(double (&a)[N], double& invd, int la
 }
 
 // Solves L L^T x = b with the factor layout above. b in `rhs` (lane j holds b_j); returns x_j.
-template <int N>
-__device__ __forceinline__ double chol_solve(const double (&a)[N], double invd, double rhs, int lane) {
-    double acc = rhs;
+template <int N, typename T>
+__device__ __forceinline__ T chol_solve(const T (&a)[N], T invd, T rhs, int lane) {
+    T acc = rhs;
 #pragma unroll
     for (int k = 0; k < N; ++k) {  // forward: L y = b, y_k = acc_k / d_k
-        double yk = bcast(acc * invd, k);
+        T yk = bcast(acc * invd, k);
         if (lane > k) acc = fma(-a[k], yk, acc);
     }
     // acc_k = y_k d_k. backward: x_k = (y_k d_k - sum_{i>k} (L_ik d_k) x_i) / d_k^2
-    double invd2 = invd * invd;
+    T invd2 = invd * invd;
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        double xi = bcast(acc * invd2, i);
+        T xi = bcast(acc * invd2, i);
         if (lane < i) acc = fma(-a[i], xi, acc);
     }
     return acc * invd2;
@@ -147,16 +173,13 @@ __device__ __forceinline__ double chol_solve(const double (&a)[N], double invd, 
 // ------------------------------------------------------------------------------------------
 // fused per-System solve
 // ------------------------------------------------------------------------------------------
-struct RowEval {
-    double r;
-    double g[8];
-};
-
 // PROF = true is the diagnostic build of the same kernel: s_memtime stamps at the phase boundaries,
 // summed per phase into prm.prof (never launched by the product entry points).
 enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4, PH_TAIL = 5, PH_COUNT = 6 };
 
-template <int N, bool PROF>
+// T = double: the reference precision. T = float: BASELINE cfg5 (the HBM arrays stay f64; scale and
+// perturbation are computed in f64, everything after in f32).
+template <int N, typename T, bool PROF>
 __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -172,14 +195,14 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     const int lane = threadIdx.x;
     const uint32_t s = blockIdx.x;
     if (b.sys_large[s]) return;  // handled by the sparse path (fx_sparse.hip)
-    constexpr int LD = N + 2;  // even: 16-byte aligned column pairs, conflict-free ds_read_b128
+    constexpr int LD = N + Vec16<T>::n;  // 16-byte aligned columns, conflict-free ds_read_b128
 
-    double* XS = reinterpret_cast<double*>(smem + L.off_xs);       // [2][vt] full variable vectors
-    double* Amat = reinterpret_cast<double*>(smem + L.off_a);      // [N][LD] JtJ (lambda on demand)
-    double* rhsv = reinterpret_cast<double*>(smem + L.off_rhs);    // [N] -Jt r
-    double* G = reinterpret_cast<double*>(smem + L.off_g);         // [2][mr][8] Jacobian rows
-    double* R = reinterpret_cast<double*>(smem + L.off_r);         // [2][mr] residuals
-    double* P = reinterpret_cast<double*>(smem + L.off_p);         // [mr] scaled parameters
+    T* XS = reinterpret_cast<T*>(smem + L.off_xs);       // [2][vt] full variable vectors
+    T* Amat = reinterpret_cast<T*>(smem + L.off_a);      // [N][LD] JtJ (lambda on demand)
+    T* rhsv = reinterpret_cast<T*>(smem + L.off_rhs);    // [N] -Jt r
+    T* G = reinterpret_cast<T*>(smem + L.off_g);         // [2][mr][8] Jacobian rows
+    T* R = reinterpret_cast<T*>(smem + L.off_r);         // [2][mr] residuals
+    T* P = reinterpret_cast<T*>(smem + L.off_p);         // [mr] scaled parameters
     uint16_t* gvar = reinterpret_cast<uint16_t*>(smem + L.off_gvar);  // [mr][8] variable of entry e
     int8_t* gcol = reinterpret_cast<int8_t*>(smem + L.off_gcol);      // [mr][8] free column or -1
     uint8_t* rtag = reinterpret_cast<uint8_t*>(smem + L.off_rtag);    // [mr]
@@ -233,8 +256,8 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     for (uint32_t i = lane; i < nvt; i += 64) {
         double v = b.vars0[v0 + i];
         double xsv = (prm.mode & 1u) ? v * scale_recip : v;
-        XS[i] = xsv;
-        XS[vt + i] = xsv;
+        XS[i] = (T)xsv;
+        XS[vt + i] = (T)xsv;
         b.vars[v0 + i] = v;  // fixed / unconstrained variables stay bit-identical
     }
     __syncthreads();
@@ -280,10 +303,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             double f2 = (1.0 / 4294967295.0) * (double)st;
             if ((uint32_t)lane < nfree) {
                 uint32_t vi = fidx[lane];
-                double x = XS[vi];
+                // recomputed from the f64 input so the f64 start point is bit-identical to the reference
+                double x = b.vars0[v0 + vi];
+                if (prm.mode & 1u) x = x * scale_recip;
                 x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
-                XS[vi] = x;
-                XS[vt + vi] = x;
+                XS[vi] = (T)x;
+                XS[vt + vi] = (T)x;
             }
             if (nfree > 0) rng = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)(nfree - 1));
         }
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 double prm_e = b.expr_param[e0 + i];
                 if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
                 rtag[pos] = (uint8_t)tag;
-                P[pos] = prm_e;
+                P[pos] = (T)prm_e;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     gvar[pos * 8 + e] = (uint16_t)vars8[e];
@@ -316,14 +341,14 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         __syncthreads();
 
         // evaluates all rows at XS[buf] into G[buf], R[buf]; returns SSE (wave-uniform)
-        auto eval_rows = [&](int buf) -> double {
-            const double* xs = XS + buf * vt;
-            double part = 0.0;
+        auto eval_rows = [&](int buf) -> T {
+            const T* xs = XS + buf * vt;
+            T part = T(0);
             for (uint32_t row = lane; row < m_rows; row += 64) {
-                double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
-                double r = eval_expression<double, true>(rtag[row], v, P[row], g);
+                T r = eval_expression<T, true>(rtag[row], v, P[row], g);
                 R[buf * mr + row] = r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
@@ -335,14 +360,14 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         // K3: A = Jt J (full symmetric), rhs = -Jt r, accumulated row by row with LDS f64 atomics
         // (one row per wave instruction, so the summation order is the row order).
         auto form_normal = [&](int buf) {
-            for (uint32_t i = lane; i < (uint32_t)(N * LD); i += 64) Amat[i] = 0.0;
-            if (lane < N) rhsv[lane] = 0.0;
+            for (uint32_t i = lane; i < (uint32_t)(N * LD); i += 64) Amat[i] = T(0);
+            if (lane < N) rhsv[lane] = T(0);
             __syncthreads();
             const int e1 = lane >> 3, e2 = lane & 7;
             constexpr int RB = 4;  // rows per batch: all loads of a batch are issued before its atomics
             for (uint32_t row0 = 0; row0 < m_rows; row0 += RB) {
                 int c1[RB], c2[RB];
-                double g1[RB], g2[RB], rr[RB];
+                T g1[RB], g2[RB], rr[RB];
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
                     uint32_t row = min(row0 + q, m_rows - 1);
@@ -355,41 +380,35 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 }
 #pragma unroll
                 for (int q = 0; q < RB; ++q) {
-                    if (c1[q] >= 0 && c2[q] >= 0) {
-                        __builtin_amdgcn_ds_atomic_fadd_f64(
-                            (__attribute__((address_space(3))) double*)&Amat[c1[q] * LD + c2[q]], g1[q] * g2[q]);
-                    }
-                    if (e2 == 0 && c1[q] >= 0) {
-                        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)&rhsv[c1[q]],
-                                                            g1[q] * rr[q]);
-                    }
+                    if (c1[q] >= 0 && c2[q] >= 0) lds_add(&Amat[c1[q] * LD + c2[q]], g1[q] * g2[q]);
+                    if (e2 == 0 && c1[q] >= 0) lds_add(&rhsv[c1[q]], g1[q] * rr[q]);
                 }
             }
-            if (lane < N && (uint32_t)lane >= nfree) Amat[lane * LD + lane] = 1.0;  // identity padding
+            if (lane < N && (uint32_t)lane >= nfree) Amat[lane * LD + lane] = T(1);  // identity padding
             __syncthreads();
         };
 
         int cur = 0;
-        const double xstart = ((uint32_t)lane < nfree) ? XS[fidx[lane]] : 0.0;  // perturbed start of this lane's variable
+        const T xstart = ((uint32_t)lane < nfree) ? XS[fidx[lane]] : T(0);  // perturbed start of this lane's variable
         stamp(PH_SETUP);
-        double sse = eval_rows(0);
-        const double sse_start = sse;
+        T sse = eval_rows(0);
+        const T sse_start = sse;
         stamp(PH_EVAL);
         form_normal(0);
         stamp(PH_FORM);
-        double diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
-        double rhs_l = (lane < N) ? rhsv[lane] : 0.0;
+        T diag = (lane < N) ? Amat[lane * LD + lane] : T(1);
+        T rhs_l = (lane < N) ? rhsv[lane] : T(0);
 
         double lambda = o.lambda0;
         uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
         bool done = false;
-        if (!(sse == sse) || !(sse < 1.0e300)) {
+        if (!(sse == sse) || !(sse < Lim<T>::huge())) {
             exit_code = FX_EXIT_NAN;
             done = true;
         }
 
         for (uint32_t outer = 0; outer < o.max_outer && !done; ++outer) {
-            if (sse < o.sse_tol) {  // lm.rs:110-112
+            if (sse < (T)o.sse_tol) {  // lm.rs:110-112
                 exit_code = FX_EXIT_SSE;
                 break;
             }
@@ -401,38 +420,41 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 }
                 trials += 1;
                 // K4: factor (JtJ + lambda I) and solve for delta
-                double a[N];
+                T a[N];
                 if (lane < N) {
-                    Amat[lane * LD + lane] = diag + lambda;  // same lane reads it back: LDS is in order
-                    const double2* col = reinterpret_cast<const double2*>(Amat + lane * LD);
+                    Amat[lane * LD + lane] = diag + (T)lambda;  // same lane reads it back: LDS is in order
+                    using V = typename Vec16<T>::type;
+                    constexpr int VN = Vec16<T>::n;
+                    const V* col = reinterpret_cast<const V*>(Amat + lane * LD);
 #pragma unroll
-                    for (int i = 0; i < N; i += 2) {
-                        double2 t = col[i >> 1];
-                        a[i] = t.x;
-                        a[i + 1] = t.y;
+                    for (int i = 0; i < N; i += VN) {
+                        V t = col[i / VN];
+                        const T* tv = reinterpret_cast<const T*>(&t);
+#pragma unroll
+                        for (int q = 0; q < VN; ++q) a[i + q] = tv[q];
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < N; ++i) a[i] = 0.0;
+                    for (int i = 0; i < N; ++i) a[i] = T(0);
                 }
-                double invd = 1.0;
+                T invd = T(1);
                 stamp(PH_TAIL);
-                bool solved = chol_factor<N>(a, invd, lane);
+                bool solved = chol_factor<N, T>(a, invd, lane);
                 stamp(PH_FACTOR);
                 if (!uniform(solved)) {  // lm.rs:134-137
                     lambda *= o.singular_factor;
                     continue;
                 }
-                double delta = chol_solve<N>(a, invd, rhs_l, lane);
-                if ((uint32_t)lane >= nfree) delta = 0.0;
-                double dn2 = wave_sum(delta * delta);
+                T delta = chol_solve<N, T>(a, invd, rhs_l, lane);
+                if ((uint32_t)lane >= nfree) delta = T(0);
+                T dn2 = wave_sum(delta * delta);
                 stamp(PH_SOLVE);
                 if (!(dn2 == dn2)) {
                     exit_code = FX_EXIT_NAN;
                     done = true;
                     break;
                 }
-                if (dn2 < o.step_tol) {  // lm.rs:139-142
+                if (dn2 < (T)o.step_tol) {  // lm.rs:139-142
                     exit_code = FX_EXIT_STEP;
                     done = true;
                     break;
@@ -445,16 +467,16 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 }
                 __syncthreads();
                 stamp(PH_TAIL);
-                double sse_t = eval_rows(trial);
+                T sse_t = eval_rows(trial);
                 stamp(PH_EVAL);
                 if (sse_t < sse) {  // accept, lm.rs:151-186
                     lambda *= o.accept_factor;
                     if (lambda < o.lambda_min) lambda = o.lambda_min;
                     cur = trial;
                     accepted += 1;
-                    double rel = (sse - sse_t) / sse;
+                    T rel = (sse - sse_t) / sse;
                     sse = sse_t;  // the returned point's SSE (the reference leaves it stale, quirk Q9)
-                    if (rel <= o.ftol) {
+                    if (rel <= (T)o.ftol) {
                         exit_code = FX_EXIT_FTOL;
                         done = true;
                         break;
@@ -462,16 +484,18 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     __syncthreads();
                     stamp(PH_TAIL);
                     form_normal(cur);
-                    diag = (lane < N) ? Amat[lane * LD + lane] : 1.0;
-                    rhs_l = (lane < N) ? rhsv[lane] : 0.0;
+                    diag = (lane < N) ? Amat[lane * LD + lane] : T(1);
+                    rhs_l = (lane < N) ? rhsv[lane] : T(0);
                     stamp(PH_FORM);
                     break;
                 } else {  // reject, lm.rs:187-190
-                    if (!(sse_t == sse_t)) {
-                        // NaN trial: the reference would double lambda forever; keep doubling
-                        // under the trial cap, which ends the loop.
-                    }
                     lambda *= o.reject_factor;
+                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
+                        // NaN trial point: the reference would double lambda forever
+                        exit_code = FX_EXIT_NAN;
+                        done = true;
+                        break;
+                    }
                 }
             }
         }
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         // ---- K6: write back scale * x for the free variables (:161-166) ----------------------
         if ((uint32_t)lane < nfree) {
             uint32_t vi = fidx[lane];
-            double x = XS[cur * vt + vi];
+            double x = (double)XS[cur * vt + vi];
             b.vars[v0 + vi] = (prm.mode & 1u) ? scale * x : x;
             // later components are solved against the PRE-solve snapshot (only `system.variables` is
             // written back, quirk Q2): restore the perturbed start value in both halves
@@ -490,14 +514,15 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         tot_accept += accepted;
         tot_trials += trials;
         last_exit = exit_code;
-        tot_sse0 += sse_start;
-        tot_sse += sse;
+        tot_sse0 += (double)sse_start;
+        tot_sse += (double)sse;
         comps_done += 1;
     }
 
     // ---- post-solve check on unscaled variables (constraints/mod.rs:96-109) ------------------
     __syncthreads();
-    for (uint32_t i = lane; i < nvt; i += 64) XS[i] = b.vars[v0 + i];
+    double* XD = reinterpret_cast<double*>(smem + L.off_xs);  // the XS area, reused as nvt doubles
+    for (uint32_t i = lane; i < nvt; i += 64) XD[i] = b.vars[v0 + i];
     __syncthreads();
     double part = 0.0;
     for (uint32_t i = lane; i < net; i += 64) {
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         expand_vars(tag, ff, vars8);
         double v[8], g[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = XS[vars8[e]];
+        for (int e = 0; e < 8; ++e) v[e] = XD[vars8[e]];
         double r = eval_expression<double, false>(tag, v, b.expr_param[e0 + i], g);
         part += r * r;
     }
@@ -634,34 +659,41 @@ __global__ __launch_bounds__(256) void identity_residual_kernel(DeviceBatch b, c
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int N, bool PROF>
+template <int N, typename T, bool PROF>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lm_solve_kernel<N, PROF>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    uint32_t n = pad_n(b.max_free);
+    SolveLayout L = make_layout(n, b.max_vars, b.max_rows, (uint32_t)sizeof(T));
+    switch (n) {
+        case 8: return launch_solve_n<8, T, false>(b, p, L, stream);
+        case 16: return launch_solve_n<16, T, false>(b, p, L, stream);
+        case 24: return launch_solve_n<24, T, false>(b, p, L, stream);
+        case 32: return launch_solve_n<32, T, false>(b, p, L, stream);
+        case 40: return launch_solve_n<40, T, false>(b, p, L, stream);
+        case 48: return launch_solve_n<48, T, false>(b, p, L, stream);
+        case 56: return launch_solve_n<56, T, false>(b, p, L, stream);
+        case 64: return launch_solve_n<64, T, false>(b, p, L, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
-    uint32_t n = pad_n(b.max_free);
-    SolveLayout L = make_layout(n, b.max_vars, b.max_rows);
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
-        if (n != 32) return hipErrorInvalidValue;
-        return launch_solve_n<32, true>(b, p, L, stream);
+        uint32_t n = pad_n(b.max_free);
+        if (n != 32 || p.lm.precision == 32) return hipErrorInvalidValue;
+        SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u);
+        return launch_solve_n<32, double, true>(b, p, L, stream);
     }
-    switch (n) {
-        case 8: return launch_solve_n<8, false>(b, p, L, stream);
-        case 16: return launch_solve_n<16, false>(b, p, L, stream);
-        case 24: return launch_solve_n<24, false>(b, p, L, stream);
-        case 32: return launch_solve_n<32, false>(b, p, L, stream);
-        case 40: return launch_solve_n<40, false>(b, p, L, stream);
-        case 48: return launch_solve_n<48, false>(b, p, L, stream);
-        case 56: return launch_solve_n<56, false>(b, p, L, stream);
-        case 64: return launch_solve_n<64, false>(b, p, L, stream);
-        default: return hipErrorInvalidValue;
-    }
+    return p.lm.precision == 32 ? launch_solve_t<float>(b, p, stream) : launch_solve_t<double>(b, p, stream);
 }
 
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream) {

@@ -126,7 +126,8 @@ typedef struct fx_lm_opts {
     uint32_t max_outer;   /* 100     lm.rs:109                                                  */
     uint32_t max_trials;  /* 4096    (reference: unbounded) total LM trials    */
     uint32_t solver;      /* fx_step_solver                                                     */
-    uint32_t reserved;
+    uint32_t precision;   /* 0 or 64: f64 (the reference's arithmetic); 32: f32 compute (cfg5) —
+                             HBM arrays stay f64, scale + perturbation stay f64                    */
 } fx_lm_opts;
 
 /* SolvingOptions (fiksi/src/lib.rs:205-237). optimizer: 0 = LevenbergMarquardt (only one
@@ -176,6 +177,8 @@ int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
 
 void fx_lm_opts_default(fx_lm_opts* opts);           /* lm.rs:108-189 literals                */
+/* f32 variant: same schedule, ftol 1e-5 and lambda_min 1e-7 (what f32 round-off can resolve). */
+void fx_lm_opts_default_f32(fx_lm_opts* opts);
 void fx_solving_opts_default(fx_solving_opts* opts); /* SolvingOptions::DEFAULT, lib.rs:232-236 */
 
 /* ---- host-side validation / structure (no device needed) ----------------------------------- */

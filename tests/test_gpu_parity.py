@@ -308,3 +308,48 @@ def test_cfg2_one_large_sketch_matches_oracle_fixture(fiksi, ctx):
     assert abs(r["sse"] - gold["sse"]) <= 1e-9 + 1e-6 * gold["sse"]
     assert abs(r["sse_unscaled"] - gold["sse_unscaled"]) <= 1e-6 * gold["sse_unscaled"] + 1e-9
     assert np.max(np.abs(v[::97] - np.array(gold["vars_every_97th"]))) <= 1e-6 * gold["scale"]
+
+
+# ---- f32 compute (BASELINE cfg5) -----------------------------------------------------------------------
+
+def test_f32_mode_matches_f64_oracle_within_f32_tolerances(fiksi, oracle, ctx):
+    """precision = 32: f32 residuals / Jacobian / Cholesky, f64 scale + perturbation + storage. Stated
+    tolerances vs the f64 oracle: same verdict (converged or not) on >= 99 % of systems, final scaled SSE
+    within 1e-3 relative (+1e-7) on 95 %, solved positions of gauge-fixed sketches within 2e-3 * scale."""
+    from fiksi_amd import abi, workloads
+
+    o32 = abi.solving_opts(f32=True)
+    assert o32.lm.precision == 32 and o32.lm.ftol == 1e-5 and o32.lm.lambda_min == 1e-7
+    b = workloads.ring16(2048)
+    v, res = ctx.system_solve_batch(b, o32)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    assert np.array_equal(res["scale"], res_o["scale"])  # K0 stays f64
+    r_o = oracle.residuals_batch(b, v_o).reshape(len(res), -1)
+    conv_o = (r_o * r_o).sum(1) < 1e-4
+    conv = res["sse_unscaled"] < 1e-4
+    assert (conv == conv_o).mean() >= 0.99
+    rel = np.abs(res["sse"] - res_o["sse"]) / (1e-7 + res_o["sse"])
+    assert np.percentile(rel, 95) <= 1e-3
+    g = workloads.ring16(512, fix_gauge=True)
+    vg, rg = ctx.system_solve_batch(g, o32)
+    vo, ro = oracle.solve_batch(g, mode=3, nthreads=8)
+    ok = (ro["sse"] < 1e-8) & (rg["sse_unscaled"] < 1e-4)
+    assert ok.mean() > 0.9
+    d = np.abs(vg - vo).reshape(len(rg), -1).max(1) / ro["scale"]
+    assert np.all(d[ok] <= 2e-3)
+    assert np.array_equal(vg.reshape(len(rg), -1)[:, :4], g["vars"].reshape(len(rg), -1)[:, :4])  # fixed: bit-identical
+
+
+def test_cfg5_overconstrained_f32_batch(fiksi, oracle, ctx):
+    """cfg5 shape: inconsistent ring16 targets (every distance off by up to 2 %), f32, LM damping: no
+    system reaches zero residual; the f32 minimum agrees with the f64 oracle's to 1e-4 relative on 95 %."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.ring16(4096, inconsistent=True)
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(f32=True))
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    assert np.all(res["exit"] != 0) and np.all(res_o["exit"] != 0)  # nobody hits SSE < 1e-8
+    assert np.isin(res["exit"], (1, 2)).mean() >= 0.99               # ftol / step exits, not caps
+    rel = np.abs(res["sse"] - res_o["sse"]) / res_o["sse"]
+    assert np.percentile(rel, 95) <= 1e-4
+    assert np.median(rel) <= 1e-5
