@@ -77,13 +77,23 @@ def main() -> int:
 
     dist = None
     torch = None
+    reduce_device = None
     if world > 1:
         import torch
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # Rehearsal knobs (not used by the driver): FIKSI_BENCH_BACKEND=gloo runs the N>1 code path
+        # with CPU reductions, FIKSI_BENCH_DEVICE=0 puts every rank on one GPU (a 1-GPU box).
+        backend = os.environ.get("FIKSI_BENCH_BACKEND", "nccl")
+        if "FIKSI_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["FIKSI_BENCH_DEVICE"])
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+        reduce_device = "cuda" if backend == "nccl" else None
 
     # ---- inputs: this rank's shard (weak scaling: a full cfg3 batch per GPU, distinct seeds) ----
     n_sys = args.systems
@@ -95,7 +105,8 @@ def main() -> int:
     def barrier():
         ctx.synchronize()
         if dist is not None:
-            torch.cuda.synchronize()
+            if reduce_device == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -117,7 +128,7 @@ def main() -> int:
     trials = int(res["trials"].sum())
 
     elapsed, (converged, accepted, trials, total_sys) = distributed.reduce_throughput(
-        dist, elapsed, [converged, accepted, trials, n_sys], device="cuda" if dist is not None else None)
+        dist, elapsed, [converged, accepted, trials, n_sys], device=reduce_device)
 
     # ---- K1 (Jacobian assembly) on the same resident batch, HIP-event timed ----------------
     k1_launches = max(args.steps, 50)
