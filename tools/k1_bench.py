@@ -1,6 +1,6 @@
 """Diagnostic: time the Jacobian-assembly kernel (K1) alone on the cfg3 batch."""
 import sys
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import fiksi_amd
 from fiksi_amd import workloads
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000

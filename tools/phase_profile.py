@@ -1,6 +1,6 @@
 """Diagnostic: where the fused solve kernel spends its cycles (stamped build). Run on the GPU box."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 import fiksi_amd
 from fiksi_amd import workloads, abi
