@@ -1,0 +1,138 @@
+"""GPU edge cases: maximum one-wavefront sizes, degenerate geometry (NaN / Inf paths the reference would
+spin on forever), ragged batches mixing every kernel instantiation, large batches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _star(n_points, fixed_center=True):
+    """One centre + n_points-1 satellites at given distances: 2*(n-1) free variables when the centre is fixed."""
+    from fiksi_amd import System, constraints, elements
+
+    s = System()
+    c = elements.Point.create(s, 0.3, -0.2)
+    if fixed_center:
+        c.fix(s)
+    for k in range(n_points - 1):
+        a = 2.0 * np.pi * k / (n_points - 1)
+        p = elements.Point.create(s, 2.0 * np.cos(a) + 0.1, 2.0 * np.sin(a) - 0.1)
+        constraints.PointPointDistance.create(s, c, p, 1.0 + 0.01 * k)
+    return s
+
+
+def test_exactly_64_free_variables_uses_the_fused_kernel(fiksi, oracle, ctx):
+    s = _star(33)  # 32 satellites = 64 free variables, 32 rows: the one-wavefront maximum
+    b = s.flatten()
+    assert int((b["var_fixed"] == 0).sum()) == 64
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3)
+    assert res["accepted"][0] == res_o["accepted"][0] and res["exit"][0] == res_o["exit"][0]
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    s2 = _star(34)  # 66 free variables: sparse path, same answer quality
+    b2 = s2.flatten()
+    v2, res2 = ctx.system_solve_batch(b2)
+    v2_o, res2_o = oracle.solve_batch(b2, mode=3)
+    assert res2["accepted"][0] == res2_o["accepted"][0]
+    assert np.max(np.abs(v2 - v2_o)) < 1e-8
+
+
+def test_many_rows_few_columns(fiksi, oracle, ctx):
+    """256 expressions on 8 free variables (heavily over-determined, consistent): the row loop of the
+    fused kernel runs 4 chunks of 64; 257 rows go through the sparse path."""
+    from fiksi_amd import System, constraints, elements
+
+    for n_rows in (256, 257):
+        s = System()
+        pts = [elements.Point.create(s, float(i) + 0.05 * i * i, 0.3 * i) for i in range(4)]
+        target = [(0., 0.), (1., 0.2), (2.1, 0.9), (2.9, 2.2)]
+        pairs = [(a, c) for a in range(4) for c in range(a + 1, 4)]
+        for k in range(n_rows):
+            a, c = pairs[k % len(pairs)]
+            d = float(np.hypot(target[a][0] - target[c][0], target[a][1] - target[c][1]))
+            constraints.PointPointDistance.create(s, pts[a], pts[c], d)
+        b = s.flatten()
+        v, res = ctx.system_solve_batch(b)
+        v_o, res_o = oracle.solve_batch(b, mode=3)
+        assert res["accepted"][0] == res_o["accepted"][0], n_rows
+        assert res["exit"][0] == res_o["exit"][0] == 0
+        assert abs(res["sse"][0] - res_o["sse"][0]) <= 1e-10
+
+
+def test_every_padded_size_in_one_batch(fiksi, oracle, ctx):
+    """Stars with 2, 6, 10, ... free variables: the batch is solved by the N=64 instantiation; each
+    smaller batch by its own (8, 16, ..., 64)."""
+    from fiksi_amd import flatten
+
+    systems = [_star(n) for n in (2, 4, 6, 9, 13, 17, 21, 25, 29, 33)]
+    b = flatten(systems)
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    for k, s in enumerate(systems):  # one system at a time -> each template instantiation
+        bs = s.flatten()
+        vs, rs = ctx.system_solve_batch(bs)
+        v0, v1 = int(b["var_off"][k]), int(b["var_off"][k + 1])
+        assert np.max(np.abs(vs - v_o[v0:v1])) < 1e-8, k
+
+
+def test_degenerate_geometry_terminates(fiksi, ctx):
+    """Coincident points under a distance constraint: d = 0 makes the gradient Inf/NaN
+    (expressions.rs:343-349, "singular at d = 0 by design"). The reference's inner loop has no cap
+    (quirk Q8) and would spin on NaN; the device path must end and say why."""
+    from fiksi_amd import System, abi, constraints, elements
+
+    s = System()
+    a = elements.Point.create(s, 1.0, 1.0)
+    c = elements.Point.create(s, 1.0, 1.0)
+    constraints.PointPointDistance.create(s, a, c, 2.0)
+    b = s.flatten()
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(perturb=False))
+    assert res["exit"][0] in (abi.EXIT_NAN, abi.EXIT_TRIAL_CAP)
+    assert np.array_equal(v, b["vars"])  # nothing accepted: the start values come back untouched
+    # with the default perturbation the same sketch is solvable (that is what perturb is for)
+    v, res = ctx.system_solve_batch(b)
+    assert res["exit"][0] == abi.EXIT_SSE and res["sse_unscaled"][0] < 1e-8
+    # zero-length line under tangency: residual and gradient are defined as 0 (quirk Q5), LM stops at once
+    s = System()
+    p = elements.Point.create(s, 0.0, 0.0)
+    q = elements.Point.create(s, 0.0, 0.0)
+    ctr = elements.Point.create(s, 1.0, 1.0)
+    rad = elements.Length.create(s, 0.5)
+    ln = elements.Line.create(s, p, q)
+    ci = elements.Circle.create(s, ctr, rad)
+    constraints.LineCircleTangency.create(s, ln, ci)
+    v, res = ctx.system_solve_batch(s.flatten(), abi.solving_opts(perturb=False))
+    assert res["exit"][0] == abi.EXIT_SSE and res["accepted"][0] == 0
+
+
+def test_non_finite_inputs_do_not_hang(fiksi, ctx):
+    from fiksi_amd import abi, workloads
+
+    b = workloads.ring16(8)
+    b["vars"] = b["vars"].copy()
+    b["vars"][5] = np.nan
+    b["vars"][40] = np.inf
+    v, res = ctx.system_solve_batch(b)
+    assert res["exit"][0] == abi.EXIT_NAN and res["exit"][1] == abi.EXIT_NAN
+    assert np.all(res["exit"][2:] != abi.EXIT_NAN)
+
+
+def test_one_million_systems_in_one_batch(fiksi, ctx):
+    """cfg5 scale (1M sketches; here on one GPU, f32): offsets stay within u32, results are sane, and a
+    checksum of per-system results is reproducible across two runs."""
+    from fiksi_amd import abi, workloads
+
+    n = 1_000_000
+    b = workloads.ring16(n, inconsistent=True)
+    db = ctx.upload(b)
+    o = abi.solving_opts(f32=True)
+    db.system_solve(o)
+    r1 = db.get_results()
+    db.system_solve(o)
+    r2 = db.get_results()
+    db.free()
+    assert np.array_equal(r1, r2)
+    assert np.isin(r1["exit"], (1, 2)).mean() > 0.99
+    assert r1["accepted"].sum() > 4 * n
