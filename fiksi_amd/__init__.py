@@ -12,5 +12,5 @@ a plain C ABI, ``include/fiksi_amd.h``). It mirrors the reference crate's public
 """
 from . import abi, constraints, elements  # noqa: F401
 from .abi import Context, DeviceBatch  # noqa: F401
-from .system import (ConstraintHandle, Decomposer, ElementHandle, Optimizer, SolvingOptions, System,  # noqa: F401
+from .system import (Analysis, ConstraintHandle, Decomposer, ElementHandle, Optimizer, SolvingOptions, System,  # noqa: F401
                      default_context, flatten, solve_systems)

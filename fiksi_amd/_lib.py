@@ -95,6 +95,7 @@ SIGNATURES = [
     ("fx_lm_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
     ("fx_eval_residual_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp]),
     ("fx_constraint_residuals", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
+    ("fx_analyze_batch", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     # builder
     ("fxs_system_new", C.c_int, [C.POINTER(_vp)]),
     ("fxs_system_free", None, [_vp]),
@@ -125,6 +126,7 @@ SIGNATURES = [
     ("fxs_system_solve", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts), C.POINTER(FxResult)]),
     ("fxs_systems_solve", C.c_int, [C.POINTER(_vp), C.c_uint32, _vp, C.POINTER(FxSolvingOpts), _vp]),
     ("fxs_system_constraint_residuals", C.c_int, [_vp, _vp, _vp]),
+    ("fxs_system_analyze", C.c_int, [_vp, _vp, _vp, u32p]),
 ]
 
 for _name, _res, _args in SIGNATURES:

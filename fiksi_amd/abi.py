@@ -180,6 +180,13 @@ class Context:
         check(lib.fx_eval_residual_jacobian(self._h, C.byref(st), _ptr(r), _ptr(vals)), "fx_eval_residual_jacobian")
         return r, (row_ptr, col, vals)
 
+    def analyze_batch(self, arrays):
+        """System::analyze per system: 1 per expression that over-constrains (does not increase the rank)."""
+        a = normalize_batch(arrays)
+        dep = np.zeros(max(int(a["expr_off"][-1]), 1), dtype=np.uint8)
+        check(lib.fx_analyze_batch(self._h, C.byref(as_struct(a)), _ptr(dep)), "fx_analyze_batch")
+        return dep[: int(a["expr_off"][-1])]
+
     def constraint_residuals(self, arrays):
         a = normalize_batch(arrays)
         r = np.zeros(int(a["expr_off"][-1]), dtype=np.float64)

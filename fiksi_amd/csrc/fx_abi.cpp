@@ -39,7 +39,7 @@ int fail(int code, const char* fmt, ...) {
 struct HostPlan {
     uint32_t n_systems = 0, n_vars = 0, n_exprs = 0;
     uint64_t nnz = 0;
-    uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0;
+    uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
     std::vector<uint16_t> sys_ncomp;
     std::vector<uint8_t> sys_large;  // components beyond the one-wavefront limits -> sparse path
     uint32_t n_large = 0;
@@ -100,6 +100,8 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
         if (nvt > FX_MAX_LARGE_SYSTEM_VARS)
             return fail(FX_ERR_TOO_LARGE, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_LARGE_SYSTEM_VARS);
         bool large = nvt > FX_MAX_SYSTEM_VARS;
+        p.max_vars_all = std::max(p.max_vars_all, nvt);
+        p.max_exprs_all = std::max(p.max_exprs_all, net);
 
         uint32_t ncomp = 0;
         free_rank.assign(nvt, -1);
@@ -417,6 +419,8 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     d.max_rows = p.max_rows;
     d.max_vars = p.max_vars;
     d.max_exprs = p.max_exprs;
+    d.max_vars_all = p.max_vars_all;
+    d.max_exprs_all = p.max_exprs_all;
     const uint32_t zero_off[1] = {0};
     const uint32_t* voff = p.n_systems ? batch->var_off : zero_off;
     const uint32_t* eoff = p.n_systems ? batch->expr_off : zero_off;
@@ -657,6 +661,27 @@ int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, dou
     if (!rc && jvals && db->d.nnz) rc = fx_batch_get_jacobian_values(ctx, db, jvals);
     fx_batch_free(ctx, db);
     return rc;
+}
+
+int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent) {
+    if (!dependent) return fail(FX_ERR_INVALID, "dependent is NULL");
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    const uint32_t ne = db->d.n_exprs;
+    if (fx::analyze_lds_bytes(db->d.max_vars_all, db->d.max_exprs_all) > 150u * 1024u) {
+        fx_batch_free(ctx, db);
+        return fail(FX_ERR_TOO_LARGE, "analyze keeps the dense expressions x variables Jacobian of a System in LDS (limit 150 KB)");
+    }
+    uint8_t* d_dep = nullptr;
+    hipError_t e = hipMalloc((void**)&d_dep, std::max<uint32_t>(ne, 1));
+    if (e == hipSuccess) e = fx::launch_analyze(db->d, db->d.vars0, db->d.max_vars_all, db->d.max_exprs_all, d_dep, ctx->stream);
+    if (e == hipSuccess && ne) e = hipMemcpyAsync(dependent, d_dep, ne, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_dep) (void)hipFree(d_dep);
+    fx_batch_free(ctx, db);
+    if (e != hipSuccess) return fail(FX_ERR_HIP, "analyze failed: %s", hipGetErrorString(e));
+    return FX_OK;
 }
 
 int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r) {

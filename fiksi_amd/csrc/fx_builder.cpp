@@ -472,4 +472,25 @@ int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* ou
     return FX_OK;
 }
 
+int fxs_system_analyze(const fxs_system* s, fx_ctx* ctx, uint32_t* ids, uint32_t* n) {
+    if (!s || !ids || !n) return FX_ERR_INVALID;
+    const fxs_system* one[1] = {s};
+    fxs_flat* f = nullptr;
+    int rc = fxs_flatten(one, 1, &f);
+    if (rc) return rc;
+    std::vector<uint8_t> dep(s->expressions.size() + 1, 0);
+    rc = fx_analyze_batch(ctx, &f->batch, dep.data());
+    fxs_flat_free(f);
+    if (rc) return rc;
+    // expression -> constraint (System::expression_to_constraint, lib.rs:301-302)
+    uint32_t count = 0;
+    for (size_t c = 0; c < s->constraints.size(); ++c) {
+        const Constraint& con = s->constraints[c];
+        for (int q = 0; q < valency_of(con.tag); ++q)
+            if (dep[con.expressions_idx + q]) ids[count++] = (uint32_t)c;
+    }
+    *n = count;
+    return FX_OK;
+}
+
 }  // extern "C"

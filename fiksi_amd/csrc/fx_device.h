@@ -21,6 +21,7 @@ struct DeviceBatch {
     uint32_t max_rows;   // expressions per component
     uint32_t max_vars;   // variables per System
     uint32_t max_exprs;  // expressions per System
+    uint32_t max_vars_all, max_exprs_all;  // the same maxima over ALL Systems (large ones included)
 
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]
@@ -56,5 +57,8 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);
 hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream);
 size_t solve_lds_bytes(const DeviceBatch& b);
+size_t analyze_lds_bytes(uint32_t max_vars, uint32_t max_exprs);
+hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_vars, uint32_t max_exprs,
+                          uint8_t* dependent, hipStream_t stream);
 
 }  // namespace fx

@@ -657,6 +657,110 @@ __global__ __launch_bounds__(256) void identity_residual_kernel(DeviceBatch b, c
 }
 
 // ------------------------------------------------------------------------------------------
+// System::analyze — over-constraint detection (fiksi/src/analyze/numerical/mod.rs:33-163)
+// ------------------------------------------------------------------------------------------
+// One wavefront per System. Dense Jacobian of ALL expressions w.r.t. ALL variables (all free,
+// unscaled, duplicates overwrite: expressions.rs:1003-1007) in LDS, then the reference's row-wise
+// incremental Gauss-Jordan elimination with column swaps. Lanes own columns; every matrix element
+// sees exactly the reference's sequence of operations (no reductions), so the verdict is
+// bit-for-bit the reference's. dependent[e] = 1 when expression e does not increase the rank.
+__global__ __launch_bounds__(64) void analyze_kernel(DeviceBatch b, const double* __restrict__ x, uint32_t ld_m,
+                                                     uint32_t ld_n, uint8_t* __restrict__ dependent) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t s = blockIdx.x;
+    const uint32_t v0 = b.var_off[s], n = b.var_off[s + 1] - v0;
+    const uint32_t e0 = b.expr_off[s], m = b.expr_off[s + 1] - e0;
+    double* M = reinterpret_cast<double*>(smem);                       // [m][n] row-major
+    uint16_t* colidx = reinterpret_cast<uint16_t*>(M + (size_t)ld_m * ld_n);  // [n]
+    uint8_t* inc = reinterpret_cast<uint8_t*>(colidx + ld_n);          // [m]
+    const double EPSILON = 1e-8;  // numerical/mod.rs:8
+
+    for (uint32_t i = lane; i < m * n; i += 64) M[i] = 0.0;
+    for (uint32_t i = lane; i < n; i += 64) colidx[i] = (uint16_t)i;
+    for (uint32_t i = lane; i < m; i += 64) inc[i] = 0;
+    __syncthreads();
+    for (uint32_t row = lane; row < m; row += 64) {  // numerical/mod.rs:135-140
+        int tag = b.expr_tag[e0 + row] & 0x7F;
+        const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + row);
+        uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int k = expand_vars(tag, ff, vars8);
+        double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
+        eval_expression<double, true>(tag, v, b.expr_param[e0 + row], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < k) M[row * n + vars8[e]] = g[e];  // later duplicates overwrite
+    }
+    __syncthreads();
+
+    uint32_t current_col = 0;
+    const uint32_t steps = min(m, n);
+    for (uint32_t row = 0; row < steps; ++row) {
+        uint32_t rank = 0;
+        for (uint32_t row_idx = 0; row_idx < row; ++row_idx) {
+            const uint32_t column_idx = colidx[rank];
+            const double factor = M[row * n + column_idx];  // read by every lane before anyone writes it
+            __syncthreads();
+            for (uint32_t col = lane; col < n; col += 64) M[row * n + col] = M[row * n + col] - factor * M[row_idx * n + col];
+            __syncthreads();
+            if (inc[row_idx]) rank += 1;
+        }
+        // first column (in pivot order) with |value| > eps
+        uint32_t found = 0xFFFFFFFFu;
+        for (uint32_t base = current_col; base < n && found == 0xFFFFFFFFu; base += 64) {
+            uint32_t idx = base + lane;
+            bool hit = idx < n && ::fabs(M[row * n + colidx[min(idx, n - 1)]]) > EPSILON;
+            uint64_t mask = __ballot(hit);
+            if (mask) found = base + (uint32_t)__builtin_ctzll(mask);
+        }
+        if (found == 0xFFFFFFFFu) continue;  // all-zero row: dependent
+        __syncthreads();
+        if (lane == 0) {
+            uint16_t t = colidx[current_col];
+            colidx[current_col] = colidx[found];
+            colidx[found] = t;
+        }
+        __syncthreads();
+        const uint32_t pc = colidx[current_col];
+        const double pivot = M[row * n + pc];
+        const double inv = 1. / pivot;
+        __syncthreads();
+        for (uint32_t col = lane; col < n; col += 64) M[row * n + col] = M[row * n + col] * inv;
+        __syncthreads();
+        for (uint32_t row_idx = 0; row_idx < row; ++row_idx) {
+            const double fct = M[row_idx * n + pc];
+            __syncthreads();
+            for (uint32_t col = lane; col < n; col += 64) M[row_idx * n + col] = M[row_idx * n + col] - fct * M[row * n + col];
+            __syncthreads();
+        }
+        current_col += 1;
+        if (lane == 0) inc[row] = 1;
+        __syncthreads();
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < m; i += 64) dependent[e0 + i] = inc[i] ? 0 : 1;
+}
+
+size_t analyze_lds_bytes(uint32_t max_vars, uint32_t max_exprs) {
+    return (size_t)max_vars * max_exprs * 8u + (size_t)max_vars * 2u + max_exprs + 64u;
+}
+
+hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_vars, uint32_t max_exprs,
+                          uint8_t* dependent, hipStream_t stream) {
+    if (b.n_systems == 0) return hipSuccess;
+    uint32_t ld_n = (max_vars + 3u) & ~3u, ld_m = max_exprs;
+    size_t lds = (size_t)ld_m * ld_n * 8u + (size_t)ld_n * 2u + ld_m + 64u;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&analyze_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(analyze_kernel, dim3(b.n_systems), dim3(64), lds, stream, b, x, ld_m, ld_n, dependent);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 template <int N, typename T, bool PROF>

@@ -127,6 +127,11 @@ class ConstraintHandle:
         return hash((self.system_id, self.id))
 
 
+@dataclass
+class Analysis:  # lib.rs:245-249
+    overconstrained: List[ConstraintHandle]
+
+
 class System:
     """``fiksi::System``: build with ``elements.*.create`` / ``constraints.*.create``, then ``solve``."""
 
@@ -161,6 +166,15 @@ class System:
         o = opts._to_abi()
         check(lib.fxs_system_solve(self._h, ctx.handle, C.byref(o), C.byref(res)), "System::solve")
         self.last_result = {f[0]: getattr(res, f[0]) for f in FxResult._fields_}
+
+    # -- lib.rs:448-459 (doc-hidden in the reference): constraints that over-constrain the System
+    def analyze(self, ctx: Optional[abi.Context] = None) -> "Analysis":
+        ctx = ctx or default_context()
+        ne = max(int(lib.fxs_num_expressions(self._h)), 1)
+        ids = np.zeros(ne, dtype=np.uint32)
+        n = C.c_uint32(0)
+        check(lib.fxs_system_analyze(self._h, ctx.handle, ids.ctypes.data, C.byref(n)), "System::analyze")
+        return Analysis([ConstraintHandle(self.id, int(i), lib.fxs_constraint_tag_of(self._h, int(i))) for i in ids[: n.value]])
 
     def constraint_residuals(self, ctx: Optional[abi.Context] = None) -> np.ndarray:
         ctx = ctx or default_context()

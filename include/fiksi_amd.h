@@ -17,6 +17,7 @@
  *   fx_lm_solve*                == levenberg_marquardt(Subsystem)                  (lm.rs:21-193)
  *   fx_system_solve*            == assemble::solve, Decomposer::None, LM           (assemble/mod.rs:46-167)
  *   fx_constraint_residuals*    == ConstraintHandle::calculate_residual            (constraints/mod.rs:88-110)
+ *   fx_analyze_batch            == System::analyze (over-constraint detection)     (analyze/numerical/mod.rs:123-163)
  *
  * Conventions
  *  - Plain C: pointers + sizes, no C++/torch types. All functions return 0 (FX_OK) or a negative
@@ -228,6 +229,10 @@ int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts
 /* == Problem::calculate_residuals_and_sparse_jacobian at batch->vars; jvals in
  * fx_jacobian_structure order (may be NULL for residuals only). */
 int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals);
+/* == System::analyze -> analyze::numerical::find_overconstraints (analyze/numerical/mod.rs:123-163):
+ * dependent[e] = 1 for every expression that does not increase the rank of the dense Jacobian at
+ * batch->vars (all variables free, no scaling, no perturbation), n_exprs entries. */
+int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent);
 /* == calculate_residual of every expression at batch->vars with all variables as given
  * (IdentityVariableMap, constraints/mod.rs:96-109). */
 int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);

@@ -92,6 +92,11 @@ int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const
  * constraints/mod.rs:99-105); expression residuals come from the device. out: n_constraints. */
 int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* out);
 
+/* System::analyze (lib.rs:455-459): ids of the constraints that over-constrain the System, in expression
+ * order (a constraint with two dependent expressions appears twice, as in the reference). `ids` has room
+ * for n_expressions entries; *n receives the count. */
+int fxs_system_analyze(const fxs_system* s, fx_ctx* ctx, uint32_t* ids, uint32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

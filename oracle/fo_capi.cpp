@@ -7,6 +7,7 @@
 #include <thread>
 #include <vector>
 
+#include "fo_analyze.hpp"
 #include "fo_assemble.hpp"
 #include "fo_colamd.hpp"
 #include "fo_expressions.hpp"
@@ -379,6 +380,22 @@ void fo_residuals_batch(uint32_t n_systems, const uint32_t* var_off, const uint3
             x.param = expr_param[e];
             r[e] = expression_residual(x, vars + var_off[s]);
         }
+    }
+}
+
+// System::analyze (analyze/numerical/mod.rs:123-163) per system: dependent[e] = 1 for expressions that
+// do not increase the rank of the dense Jacobian at the given (unscaled) variables.
+void fo_analyze_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                      const uint8_t* expr_tag, const uint32_t* expr_idx, const double* expr_param, uint8_t* dependent) {
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        uint32_t e0 = expr_off[s], ne = expr_off[s + 1] - e0;
+        std::vector<Expression> ex(ne);
+        for (uint32_t e = 0; e < ne; ++e) {
+            ex[e].tag = expr_tag[e0 + e];
+            for (int k = 0; k < 4; ++k) ex[e].idx[k] = expr_idx[4 * static_cast<size_t>(e0 + e) + k];
+            ex[e].param = expr_param[e0 + e];
+        }
+        find_overconstraints(vars + var_off[s], var_off[s + 1] - var_off[s], ex.data(), ne, dependent + e0);
     }
 }
 

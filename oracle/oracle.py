@@ -213,3 +213,12 @@ def residuals_batch(b, vars_=None):
     lib().fo_residuals_batch(C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(v), _p(b["expr_tag"]),
                              _p(b["expr_idx"]), _p(b["expr_param"]), _p(r))
     return r
+
+
+def analyze_batch(b):
+    """System::analyze: 1 per expression that does not increase the rank (over-constraining)."""
+    n = int(len(b["var_off"]) - 1)
+    dep = np.zeros(int(b["expr_off"][-1]), dtype=np.uint8)
+    lib().fo_analyze_batch(C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(b["vars"]), _p(b["expr_tag"]),
+                           _p(b["expr_idx"]), _p(b["expr_param"]), _p(dep))
+    return dep

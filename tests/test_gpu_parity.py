@@ -355,3 +355,22 @@ def test_cfg5_overconstrained_f32_batch(fiksi, oracle, ctx):
     rel = np.abs(res["sse"] - res_o["sse"]) / res_o["sse"]
     assert np.percentile(rel, 95) <= 1e-4
     assert np.median(rel) <= 1e-5
+
+
+# ---- System::analyze -------------------------------------------------------------------------
+
+def test_analyze_verdicts_identical_to_oracle(fiksi, oracle, ctx):
+    """Over-constraint detection (analyze/numerical/mod.rs:33-163): lanes own matrix columns and every
+    element sees the reference's exact operation sequence, so the per-expression verdict is identical."""
+    from fiksi_amd import workloads
+
+    batches = [
+        workloads.concat([workloads.quadrilateral(False), workloads.quadrilateral(True), workloads.ring16(50),
+                          workloads.hinged_triangles(2, 11), workloads.ring16(20, inconsistent=True)]),
+        fiksi.flatten([mixed_sketch(300 + k, fix_some=bool(k % 2)) for k in range(40)]),
+    ]
+    for b in batches:
+        dep = ctx.analyze_batch(b)
+        dep_o = oracle.analyze_batch(b)
+        assert np.array_equal(dep, dep_o)
+    assert ctx.analyze_batch(workloads.quadrilateral(False)).tolist() == [0, 0, 0, 0, 0, 1]

@@ -83,6 +83,22 @@ def test_overconstrained_triangle_line_incidence(F, oracle):  # basic.rs:56-87
     assert abs(s.last_result["sse"] - res_o["sse"][0]) <= 1e-6 * res_o["sse"][0] + 1e-10
 
 
+def test_overconstrained_analysis(F, oracle):  # basic.rs:90-112
+    s = F.System()
+    p0 = F.elements.Point.create(s, 0.123, 0.1)
+    p1 = F.elements.Point.create(s, 1.2, 0.)
+    p2 = F.elements.Point.create(s, -0.5, 1.1)
+    p3 = F.elements.Point.create(s, 1.599, 1.2)
+    F.constraints.PointPointDistance.create(s, p0, p1, 1.)
+    F.constraints.PointPointDistance.create(s, p0, p2, 1.5)
+    F.constraints.PointPointDistance.create(s, p1, p3, 1.7)
+    F.constraints.PointPointDistance.create(s, p2, p3, 1.2)
+    F.constraints.PointPointDistance.create(s, p1, p2, 2.)
+    p0p3 = F.constraints.PointPointDistance.create(s, p0, p3, 5.)
+    analysis = s.analyze()
+    assert analysis.overconstrained == [p0p3.as_any_constraint()]
+
+
 def test_triangle_inscribed_circle(F, oracle):  # basic.rs:116-149
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
