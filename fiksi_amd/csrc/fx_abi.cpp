@@ -49,6 +49,10 @@ struct HostPlan {
     std::vector<uint32_t> expr_var0;
     std::vector<uint8_t> expr_tagx;   // tag | 0x80 when a free column repeats inside the row
     std::vector<uint8_t> row_perm;    // tag-sorted order of each 256-row block
+    std::vector<uint8_t> row_simple;  // all variables of the row free and distinct
+    std::vector<uint8_t> row_sysoff;
+    std::vector<uint32_t> expr_sys;
+    std::vector<fx::BlockInfo> blk_info;
     std::vector<uint32_t> jrow_ptr, jcol, jslot;
 };
 
@@ -86,6 +90,9 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
     p.expr_var0.assign(ne, 0);
     p.expr_tagx.assign(ne, 0);
     p.row_perm.assign(ne, 0);
+    p.row_simple.assign(ne, 0);
+    p.row_sysoff.assign(ne, 0);
+    p.expr_sys.assign(ne, 0);
     if (want_structure) {
         p.jrow_ptr.assign((size_t)ne + 1, 0);
         p.jslot.assign(ne, 0xFFFFFFFFu);
@@ -160,6 +167,13 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
                 for (int q = 0; q < k; ++q)
                     for (int t = q + 1; t < k; ++t) dup = dup || (vars8[q] == vars8[t] && free_rank[vars8[q]] >= 0);
                 if (dup) p.expr_tagx[e] |= 0x80;
+                bool all_free = true, distinct = true;
+                for (int q = 0; q < k; ++q) {
+                    all_free = all_free && free_rank[vars8[q]] >= 0;
+                    for (int t = q + 1; t < k; ++t) distinct = distinct && vars8[q] != vars8[t];
+                }
+                p.row_simple[e] = (all_free && distinct) ? 1 : 0;
+                p.expr_sys[e] = s;
             }
             uint16_t c = p.expr_comp[e];
             if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
@@ -211,6 +225,19 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
         for (int tag = 0; tag < FX_NTAGS; ++tag)
             for (uint32_t i = 0; i < nr; ++i)
                 if ((p.expr_tagx[r0 + i] & 0x7F) == tag) p.row_perm[r0 + t++] = (uint8_t)i;
+        fx::BlockInfo bi{};
+        bi.sys0 = p.expr_sys[r0];
+        bool simple = want_structure;
+        for (uint32_t i = 0; i < nr; ++i) {
+            simple = simple && p.row_simple[r0 + i];
+            p.row_sysoff[r0 + i] = (uint8_t)(p.expr_sys[r0 + i] - bi.sys0);  // < 256: at most 256 rows per block
+        }
+        if (want_structure) {
+            bi.jbase = p.jrow_ptr[r0];
+            bi.jcount = p.jrow_ptr[r0 + nr] - p.jrow_ptr[r0];
+        }
+        bi.flags = simple ? 1u : 0u;
+        p.blk_info.push_back(bi);
     }
     return FX_OK;
 }
@@ -443,6 +470,8 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
     FX_UP(expr_param, batch->expr_param, p.n_exprs)
     FX_UP(expr_var0, p.expr_var0.data(), p.n_exprs)
+    FX_UP(row_sysoff, p.row_sysoff.data(), p.n_exprs)
+    FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(jrow_ptr, p.jrow_ptr.data(), (size_t)p.n_exprs + 1)
     FX_UP(jcol, p.jcol.data(), p.nnz)
     FX_UP(jslot, p.jslot.data(), p.n_exprs)

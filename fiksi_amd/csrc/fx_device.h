@@ -12,6 +12,14 @@ constexpr uint16_t VAR_COMP_MASK = 0x7FFF;
 constexpr uint16_t VAR_COMP_NONE = 0x7FFF;
 constexpr uint16_t VAR_FIXED_BIT = 0x8000;
 
+// Per 256-row block of the row-parallel kernels.
+struct BlockInfo {
+    uint32_t jbase;   // first CSR value of the block
+    uint32_t jcount;  // CSR values of the block
+    uint32_t sys0;    // System of the block's first row
+    uint32_t flags;   // bit 0: "simple" — every row has only free, distinct variables
+};
+
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
     uint32_t n_systems, n_vars, n_exprs;
@@ -35,7 +43,9 @@ struct DeviceBatch {
     uint16_t* expr_comp;   // [n_exprs]
     uint16_t* expr_idx;    // [4*n_exprs] system-local element fields (ushort4 per expression)
     double* expr_param;    // [n_exprs]
-    uint32_t* expr_var0;   // [n_exprs] var_off of the owning System (for the row-parallel kernels)
+    uint32_t* expr_var0;   // [n_exprs] var_off of the owning System (row-parallel kernels, non-simple blocks)
+    uint8_t* row_sysoff;   // [n_exprs] owning System minus the block's first System
+    BlockInfo* blk_info;   // [ceil(n_exprs / 256)]
     // CSR Jacobian (fixed pattern): rows global, columns = system-local free rank
     uint32_t* jrow_ptr;    // [n_exprs+1]
     uint32_t* jcol;        // [nnz]
