@@ -87,7 +87,7 @@ __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ?
 struct SolveLayout {
     uint32_t vt;   // padded variables per System
     uint32_t mr;   // padded rows per component
-    uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx, off_colof;
+    uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx, off_colof, off_vout;
     uint32_t total;
 };
 
@@ -99,7 +99,7 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     if (L.mr == 0) L.mr = 8;
     uint32_t o = 0;
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
-    L.off_xs = take(2u * L.vt * es > L.vt * 8u ? 2u * L.vt * es : L.vt * 8u);  // also holds nvt doubles at the end
+    L.off_xs = take(2u * L.vt * es);
     L.off_a = take(n_pad * (n_pad + 16u / es) * es);
     L.off_rhs = take(n_pad * es);
     L.off_g = take(2u * L.mr * 8u * es);
@@ -110,6 +110,7 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     L.off_rtag = take(L.mr);
     L.off_fidx = take(n_pad * 2u);
     L.off_colof = take(L.vt * 2u);
+    L.off_vout = take(L.vt * 8u);  // unscaled output values (f64) for the post-solve check
     L.total = o;
     return L;
 }
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     int8_t* gcol = reinterpret_cast<int8_t*>(smem + L.off_gcol);      // [mr][8] free column or -1
     uint8_t* rtag = reinterpret_cast<uint8_t*>(smem + L.off_rtag);    // [mr]
     uint16_t* fidx = reinterpret_cast<uint16_t*>(smem + L.off_fidx);  // [N] free column -> variable
+    double* VOUT = reinterpret_cast<double*>(smem + L.off_vout);       // [vt] unscaled values as written back
     const uint32_t vt = L.vt, mr = L.mr;
 
     const uint32_t v0 = b.var_off[s], nvt = b.var_off[s + 1] - v0;
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         double xsv = (prm.mode & 1u) ? v * scale_recip : v;
         XS[i] = (T)xsv;
         XS[vt + i] = (T)xsv;
+        VOUT[i] = v;
         b.vars[v0 + i] = v;  // fixed / unconstrained variables stay bit-identical
     }
     __syncthreads();
@@ -504,7 +507,9 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         if ((uint32_t)lane < nfree) {
             uint32_t vi = fidx[lane];
             double x = (double)XS[cur * vt + vi];
-            b.vars[v0 + vi] = (prm.mode & 1u) ? scale * x : x;
+            double xo = (prm.mode & 1u) ? scale * x : x;
+            b.vars[v0 + vi] = xo;
+            VOUT[vi] = xo;
             // later components are solved against the PRE-solve snapshot (only `system.variables` is
             // written back, quirk Q2): restore the perturbed start value in both halves
             XS[vi] = xstart;
@@ -521,9 +526,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
 
     // ---- post-solve check on unscaled variables (constraints/mod.rs:96-109) ------------------
     __syncthreads();
-    double* XD = reinterpret_cast<double*>(smem + L.off_xs);  // the XS area, reused as nvt doubles
-    for (uint32_t i = lane; i < nvt; i += 64) XD[i] = b.vars[v0 + i];
-    __syncthreads();
+    const double* XD = VOUT;
     double part = 0.0;
     for (uint32_t i = lane; i < net; i += 64) {
         int tag = b.expr_tag[e0 + i] & 0x7F;
