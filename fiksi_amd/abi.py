@@ -65,9 +65,10 @@ def lm_opts(f32: bool = False, **kw) -> FxLmOpts:
     return o
 
 
-def solving_opts(perturb: bool = True, f32: bool = False, **lm_kw) -> FxSolvingOpts:
+def solving_opts(perturb: bool = True, f32: bool = False, decomposer: int = 0, **lm_kw) -> FxSolvingOpts:
     o = FxSolvingOpts()
     lib.fx_solving_opts_default(C.byref(o))
+    o.decomposer = decomposer
     if f32:
         lib.fx_lm_opts_default_f32(C.byref(o.lm))
     o.perturb = 1 if perturb else 0
@@ -98,6 +99,27 @@ def jacobian_structure(arrays):
     col = np.zeros(nnz.value, dtype=np.uint32)
     check(lib.fx_jacobian_structure(C.byref(st), C.byref(nnz), _ptr(row_ptr), _ptr(col)), "fx_jacobian_structure")
     return row_ptr, col
+
+
+def single_pass_blocks(arrays, system: int = 0):
+    """The blocks Decomposer.SinglePass solves System ``system`` by, in solve order (host-side, no GPU
+    needed): a list of (component, expression ids, free variable ids)."""
+    a = normalize_batch(arrays)
+    st = as_struct(a)
+    if not 0 <= system < len(a["var_off"]) - 1:
+        raise IndexError(f"system {system} out of range ({len(a['var_off']) - 1} systems)")
+    ne = int(a["expr_off"][system + 1] - a["expr_off"][system])
+    nv = int(a["var_off"][system + 1] - a["var_off"][system])
+    nb = C.c_uint32(0)
+    comp = np.zeros(4 * ne + 1, dtype=np.uint32)
+    row_off = np.zeros(4 * ne + 1, dtype=np.uint32)
+    rows = np.zeros(4 * ne + 1, dtype=np.uint32)
+    var_off = np.zeros(4 * ne + 1, dtype=np.uint32)
+    vs = np.zeros(max(nv, 1), dtype=np.uint32)
+    check(lib.fx_single_pass_blocks(C.byref(st), system, C.byref(nb), _ptr(comp), _ptr(row_off), _ptr(rows),
+                                    _ptr(var_off), _ptr(vs)), "fx_single_pass_blocks")
+    return [(int(comp[k]), rows[row_off[k]:row_off[k + 1]].tolist(), vs[var_off[k]:var_off[k + 1]].tolist())
+            for k in range(nb.value)]
 
 
 class Context:

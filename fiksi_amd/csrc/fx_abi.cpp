@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "fx_decompose.h"
 #include "fx_device.h"
 #include "fx_expr.h"
 #include "fx_sparse.h"
@@ -292,6 +293,91 @@ int bind(fx_ctx* ctx) {
 }  // namespace
 
 namespace {
+// Builds the SinglePass blocks of every System that runs in the fused kernel (once per batch; the
+// structure is read back from the device arrays, so nothing extra is kept on the host for batches
+// that never ask for it). Large Systems get theirs inside the sparse path.
+int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
+    fx::DeviceBatch& d = db->d;
+    if (d.sys_unit_off) return FX_OK;
+    const uint32_t n = d.n_systems;
+    std::vector<uint32_t> var_off((size_t)n + 1), expr_off((size_t)n + 1);
+    std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs);
+    std::vector<uint8_t> expr_tag(d.n_exprs), sys_large(n);
+    std::vector<uint16_t> sys_ncomp(n);
+    FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_exprs) {
+        FX_HIP(hipMemcpyAsync(expr_idx.data(), d.expr_idx, expr_idx.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(expr_tag.data(), d.expr_tag, expr_tag.size(), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n) {
+        FX_HIP(hipMemcpyAsync(sys_large.data(), d.sys_large, n, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+
+    std::vector<uint32_t> sys_unit_off((size_t)n + 1, 0);
+    std::vector<fx::UnitDesc> desc;
+    std::vector<uint16_t> unit_rows, unit_vars;
+    uint32_t max_unit_free = 0, max_unit_rows = 0;
+    fx::Incidence inc;
+    fx::UnitList units;
+    std::vector<uint32_t> free_sorted;
+    for (uint32_t s = 0; s < n; ++s) {
+        sys_unit_off[s] = (uint32_t)desc.size();
+        if (sys_large[s]) continue;
+        const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0;
+        const uint32_t e0 = expr_off[s], net = expr_off[s + 1] - e0;
+        inc.build(nvt, net, expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0);
+        fx::SinglePassDecomposer dec(inc);
+        for (uint32_t c = 0; c < sys_ncomp[s]; ++c) {
+            free_sorted.clear();
+            bool any_var = false;
+            for (uint32_t i = 0; i < nvt; ++i) {
+                uint16_t info = var_info[v0 + i];
+                if ((info & fx::VAR_COMP_MASK) != c) continue;
+                any_var = true;
+                if (!(info & fx::VAR_FIXED_BIT)) free_sorted.push_back(i);
+            }
+            if (!any_var) continue;  // skipped by the reference (`elements.is_empty()`)
+            dec.run(free_sorted, units);
+            if (units.count() == 0) {
+                desc.push_back(fx::UnitDesc{0, 0, 0, 0, (uint16_t)c, (uint16_t)(fx::UNIT_FIRST | fx::UNIT_EMPTY)});
+                continue;
+            }
+            for (uint32_t u = 0; u < units.count(); ++u) {
+                fx::UnitDesc ud{};
+                ud.row_off = (uint32_t)unit_rows.size();
+                ud.var_off = (uint32_t)unit_vars.size();
+                ud.nrows = (uint16_t)(units.row_off[u + 1] - units.row_off[u]);
+                ud.nvars = (uint16_t)(units.var_off[u + 1] - units.var_off[u]);
+                ud.comp = (uint16_t)c;
+                ud.flags = u == 0 ? fx::UNIT_FIRST : 0;
+                for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k) unit_rows.push_back((uint16_t)units.rows[k]);
+                for (uint32_t k = units.var_off[u]; k < units.var_off[u + 1]; ++k) unit_vars.push_back((uint16_t)units.vars[k]);
+                max_unit_free = std::max<uint32_t>(max_unit_free, ud.nvars);
+                max_unit_rows = std::max<uint32_t>(max_unit_rows, ud.nrows);
+                desc.push_back(ud);
+            }
+        }
+    }
+    sys_unit_off[n] = (uint32_t)desc.size();
+    int rc = dev_alloc_copy(ctx, db, &d.unit_desc, desc.data(), desc.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.unit_rows, unit_rows.data(), unit_rows.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.unit_vars, unit_vars.data(), unit_vars.size());
+    uint32_t* off = nullptr;
+    if (!rc) rc = dev_alloc_copy(ctx, db, &off, sys_unit_off.data(), sys_unit_off.size());
+    if (rc) return rc;
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    d.max_unit_free = max_unit_free;
+    d.max_unit_rows = max_unit_rows;
+    if (fx::solve_lds_bytes_units(d) > 160u * 1024u)
+        return fail(FX_ERR_TOO_LARGE, "SinglePass blocks need %zu bytes of LDS per wavefront (limit 163840)", fx::solve_lds_bytes_units(d));
+    d.sys_unit_off = off;  // set last: marks the plan as complete
+    return FX_OK;
+}
+
 // Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (!db->n_large) return FX_OK;
@@ -566,10 +652,15 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     fx_solving_opts o;
     if (opts) o = *opts; else fx_solving_opts_default(&o);
     if (o.optimizer != 0) return fail(FX_ERR_UNSUPPORTED, "only Optimizer::LevenbergMarquardt runs on the device");
-    if (o.decomposer != 0) return fail(FX_ERR_UNSUPPORTED, "only Decomposer::None runs on the device");
+    if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
     fx::LmParams p;
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u);
+    if (o.decomposer == 1) {
+        rc = ensure_units(ctx, db);
+        if (rc) return rc;
+        p.mode |= fx::MODE_UNITS;
+    }
     FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
     return solve_large_systems(ctx, db, p);
 }
@@ -710,6 +801,48 @@ int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent) {
     if (d_dep) (void)hipFree(d_dep);
     fx_batch_free(ctx, db);
     if (e != hipSuccess) return fail(FX_ERR_HIP, "analyze failed: %s", hipGetErrorString(e));
+    return FX_OK;
+}
+
+int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_blocks, uint32_t* block_comp,
+                          uint32_t* row_off, uint32_t* rows, uint32_t* var_off, uint32_t* vars) {
+    int rc = analyze(batch, nullptr, false);
+    if (rc) return rc;
+    if (system >= batch->n_systems) return fail(FX_ERR_INVALID, "system %u out of range (%u systems)", system, batch->n_systems);
+    const uint32_t v0 = batch->var_off[system], nvt = batch->var_off[system + 1] - v0;
+    const uint32_t e0 = batch->expr_off[system], net = batch->expr_off[system + 1] - e0;
+    fx::Incidence inc;
+    inc.build(nvt, net, batch->expr_tag + e0, batch->expr_idx + 4 * (size_t)e0);
+    fx::SinglePassDecomposer dec(inc);
+    uint32_t ncomp = 0;
+    for (uint32_t i = 0; i < nvt; ++i) {
+        uint16_t c = batch->var_comp ? batch->var_comp[v0 + i] : 0;
+        if (c != FX_NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, c + 1u);
+    }
+    uint32_t nb = 0, nr = 0, nv = 0;
+    if (row_off) row_off[0] = 0;
+    if (var_off) var_off[0] = 0;
+    std::vector<uint32_t> free_sorted;
+    fx::UnitList units;
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        free_sorted.clear();
+        for (uint32_t i = 0; i < nvt; ++i)
+            if ((batch->var_comp ? batch->var_comp[v0 + i] : 0) == c && !batch->var_fixed[v0 + i]) free_sorted.push_back(i);
+        dec.run(free_sorted, units);
+        if (nb + units.count() > 4u * net || nr + units.rows.size() > 4u * (size_t)net || nv + units.vars.size() > nvt)
+            return fail(FX_ERR_INVALID, "system %u: decomposition exceeds the documented capacities", system);
+        for (uint32_t u = 0; u < units.count(); ++u) {
+            for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k, ++nr)
+                if (rows) rows[nr] = units.rows[k];
+            for (uint32_t k = units.var_off[u]; k < units.var_off[u + 1]; ++k, ++nv)
+                if (vars) vars[nv] = units.vars[k];
+            if (block_comp) block_comp[nb] = c;
+            ++nb;
+            if (row_off) row_off[nb] = nr;
+            if (var_off) var_off[nb] = nv;
+        }
+    }
+    if (n_blocks) *n_blocks = nb;
     return FX_OK;
 }
 

@@ -20,6 +20,18 @@ struct BlockInfo {
     uint32_t flags;   // bit 0: "simple" — every row has only free, distinct variables
 };
 
+// One block of the SinglePass decomposition (fx_decompose.h), in solve order per System.
+struct UnitDesc {
+    uint32_t row_off;  // into unit_rows
+    uint32_t var_off;  // into unit_vars
+    uint16_t nrows, nvars;
+    uint16_t comp;     // connected component the block belongs to
+    uint16_t flags;
+};
+constexpr uint16_t UNIT_FIRST = 1;  // first block of its component: the component is perturbed before it
+constexpr uint16_t UNIT_EMPTY = 2;  // placeholder of a component without any block
+constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
+
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
     uint32_t n_systems, n_vars, n_exprs;
@@ -54,11 +66,18 @@ struct DeviceBatch {
     double* resid;         // [n_exprs]
     fx_result* results;    // [n_systems]
     double* sse_unscaled;  // [n_systems] sum r^2 on the solved, unscaled variables
+    // SinglePass blocks, built on first use (null until then)
+    uint32_t max_unit_free;   // free variables per block
+    uint32_t max_unit_rows;   // expressions per block (a block may hold a neighbouring component's rows)
+    uint32_t* sys_unit_off;   // [n_systems+1] into unit_desc (large Systems own no entries)
+    UnitDesc* unit_desc;
+    uint16_t* unit_rows;      // system-local expression ids
+    uint16_t* unit_vars;      // system-local variable ids, ascending per block
 };
 
 struct LmParams {
     fx_lm_opts lm;
-    uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation
+    uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation, bit2: MODE_UNITS
     unsigned long long* prof = nullptr;  // diagnostic build only: 6 per-phase cycle sums
 };
 
@@ -67,6 +86,7 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);
 hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream);
 size_t solve_lds_bytes(const DeviceBatch& b);
+size_t solve_lds_bytes_units(const DeviceBatch& b);
 size_t analyze_lds_bytes(uint32_t max_vars, uint32_t max_exprs);
 hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_vars, uint32_t max_exprs,
                           uint8_t* dependent, hipStream_t stream);

@@ -79,6 +79,17 @@ template <> struct Lim<float> { static __device__ __forceinline__ float huge() {
 template <typename T> struct Vec16;  // 16-byte LDS vector of T
 template <> struct Vec16<double> { using type = double2; static constexpr int n = 2; };
 template <> struct Vec16<float> { using type = float4; static constexpr int n = 4; };
+// state after k steps of the reference LCG (rand.rs): the 2^i-step maps are composed bit by bit
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t st, uint32_t k) {
+    uint32_t a = 1664525u, c = 1013904223u;
+    while (k) {
+        if (k & 1u) st = a * st + c;
+        c = (a + 1u) * c;
+        a = a * a;
+        k >>= 1;
+    }
+    return st;
+}
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
 
 // ------------------------------------------------------------------------------------------
@@ -121,6 +132,9 @@ static uint32_t pad_n(uint32_t max_free) {
 }
 
 size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows, 8u).total; }
+size_t solve_lds_bytes_units(const DeviceBatch& b) {
+    return make_layout(pad_n(b.max_unit_free), b.max_vars, b.max_rows > b.max_unit_rows ? b.max_rows : b.max_unit_rows, 8u).total;
+}
 
 // ------------------------------------------------------------------------------------------
 // register-resident Cholesky of the N x N SPD matrix held one column per lane
@@ -180,7 +194,12 @@ enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4
 
 // T = double: the reference precision. T = float: BASELINE cfg5 (the HBM arrays stay f64; scale and
 // perturbation are computed in f64, everything after in f32).
-template <int N, typename T, bool PROF>
+//
+// UNITS = true is `Decomposer::SinglePass` (assemble/mod.rs:169-210): the loop runs over the blocks the
+// host decomposition produced (fx_decompose.h) instead of over whole components, the component's
+// perturbation happens before its first block, and a solved block is written through to the working
+// vectors so later blocks see it.
+template <int N, typename T, bool PROF, bool UNITS>
 __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -270,9 +289,73 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     double tot_sse0 = 0.0, tot_sse = 0.0;
     int16_t* colof = reinterpret_cast<int16_t*>(smem + L.off_colof);  // [vt] variable -> free column
 
-    for (uint32_t c = 0; c < ncomp; ++c) {
+    const uint32_t unit0 = UNITS ? b.sys_unit_off[s] : 0u;
+    const uint32_t n_iter = UNITS ? b.sys_unit_off[s + 1] - unit0 : ncomp;
+    for (uint32_t c = 0; c < n_iter; ++c) {
+        uint32_t nfree = 0, m_rows = 0;
+        if constexpr (UNITS) {
+        const UnitDesc ud = b.unit_desc[unit0 + c];
+        if (ud.flags & UNIT_FIRST) {  // the component's perturbation comes before its first block (:91-111)
+            comps_done += 1;
+            last_exit = FX_EXIT_SSE;
+            if (prm.mode & 2u) {
+                uint32_t rank0 = 0;
+                for (uint32_t base = 0; base < nvt; base += 64) {
+                    uint32_t i = base + lane;
+                    bool in = false;
+                    if (i < nvt) {
+                        uint16_t info = b.var_info[v0 + i];
+                        in = ((info & VAR_COMP_MASK) == ud.comp) && !(info & VAR_FIXED_BIT);
+                    }
+                    uint64_t mk = __ballot(in);
+                    if (in) {
+                        uint32_t st = lcg_jump(rng, 2u * (rank0 + (uint32_t)__popcll(mk & lanemask_lt(lane))));
+                        st = st * 1664525u + 1013904223u;
+                        double f1 = (1.0 / 4294967295.0) * (double)st;
+                        st = st * 1664525u + 1013904223u;
+                        double f2 = (1.0 / 4294967295.0) * (double)st;
+                        double x = b.vars0[v0 + i];
+                        if (prm.mode & 1u) x = x * scale_recip;
+                        x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                        XS[i] = (T)x;
+                        XS[vt + i] = (T)x;
+                    }
+                    rank0 += (uint32_t)__popcll(mk);
+                }
+                rng = lcg_jump(rng, 2u * rank0);
+            }
+        }
+        if (ud.flags & UNIT_EMPTY) continue;  // a component no expression could be matched in
+        nfree = ud.nvars;
+        m_rows = ud.nrows;
+        for (uint32_t i = lane; i < nvt; i += 64) colof[i] = (int16_t)-1;
+        __syncthreads();
+        if ((uint32_t)lane < nfree) {
+            uint32_t vi = b.unit_vars[ud.var_off + lane];
+            fidx[lane] = (uint16_t)vi;
+            colof[vi] = (int16_t)lane;
+        }
+        __syncthreads();
+        for (uint32_t pos = lane; pos < m_rows; pos += 64) {  // rows in block order
+            uint32_t i = b.unit_rows[ud.row_off + pos];
+            int tag = b.expr_tag[e0 + i] & 0x7F;
+            const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
+            uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+            uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int k = expand_vars(tag, ff, vars8);
+            double prm_e = b.expr_param[e0 + i];
+            if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+            rtag[pos] = (uint8_t)tag;
+            P[pos] = (T)prm_e;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
+            }
+        }
+        __syncthreads();
+        } else {
         // ---- free variables of the component, ascending (BTreeSet order, :91-111) -----------
-        uint32_t nfree = 0;
         for (uint32_t base = 0; base < nvt; base += 64) {
             uint32_t i = base + lane;
             bool in = false;
@@ -317,7 +400,6 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         }
 
         // ---- rows of the component: ascending expression id (:139-145) ----------------------
-        uint32_t m_rows = 0;
         for (uint32_t base = 0; base < net; base += 64) {
             uint32_t i = base + lane;
             bool in = (i < net) && (b.expr_comp[e0 + i] == c);
@@ -342,6 +424,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             m_rows += (uint32_t)__popcll(mk);
         }
         __syncthreads();
+        }  // !UNITS
 
         // evaluates all rows at XS[buf] into G[buf], R[buf]; returns SSE (wave-uniform)
         auto eval_rows = [&](int buf) -> T {
@@ -510,10 +593,16 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             double xo = (prm.mode & 1u) ? scale * x : x;
             b.vars[v0 + vi] = xo;
             VOUT[vi] = xo;
-            // later components are solved against the PRE-solve snapshot (only `system.variables` is
-            // written back, quirk Q2): restore the perturbed start value in both halves
-            XS[vi] = xstart;
-            XS[vt + vi] = xstart;
+            if (UNITS) {  // SinglePass also updates the working vector (:201-207)
+                T xv = XS[cur * vt + vi];
+                XS[vi] = xv;
+                XS[vt + vi] = xv;
+            } else {
+                // later components are solved against the PRE-solve snapshot (only `system.variables` is
+                // written back, quirk Q2): restore the perturbed start value in both halves
+                XS[vi] = xstart;
+                XS[vt + vi] = xstart;
+            }
         }
         __syncthreads();
         tot_accept += accepted;
@@ -521,7 +610,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         last_exit = exit_code;
         tot_sse0 += (double)sse_start;
         tot_sse += (double)sse;
-        comps_done += 1;
+        if (!UNITS) comps_done += 1;
     }
 
     // ---- post-solve check on unscaled variables (constraints/mod.rs:96-109) ------------------
@@ -837,28 +926,29 @@ hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_va
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int N, typename T, bool PROF>
+template <int N, typename T, bool PROF, bool UNITS>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF, UNITS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF, UNITS>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool UNITS>
 static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
-    uint32_t n = pad_n(b.max_free);
-    SolveLayout L = make_layout(n, b.max_vars, b.max_rows, (uint32_t)sizeof(T));
+    uint32_t n = pad_n(UNITS ? b.max_unit_free : b.max_free);
+    const uint32_t rows = (UNITS && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
+    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T));
     switch (n) {
-        case 8: return launch_solve_n<8, T, false>(b, p, L, stream);
-        case 16: return launch_solve_n<16, T, false>(b, p, L, stream);
-        case 24: return launch_solve_n<24, T, false>(b, p, L, stream);
-        case 32: return launch_solve_n<32, T, false>(b, p, L, stream);
-        case 40: return launch_solve_n<40, T, false>(b, p, L, stream);
-        case 48: return launch_solve_n<48, T, false>(b, p, L, stream);
-        case 56: return launch_solve_n<56, T, false>(b, p, L, stream);
-        case 64: return launch_solve_n<64, T, false>(b, p, L, stream);
+        case 8: return launch_solve_n<8, T, false, UNITS>(b, p, L, stream);
+        case 16: return launch_solve_n<16, T, false, UNITS>(b, p, L, stream);
+        case 24: return launch_solve_n<24, T, false, UNITS>(b, p, L, stream);
+        case 32: return launch_solve_n<32, T, false, UNITS>(b, p, L, stream);
+        case 40: return launch_solve_n<40, T, false, UNITS>(b, p, L, stream);
+        case 48: return launch_solve_n<48, T, false, UNITS>(b, p, L, stream);
+        case 56: return launch_solve_n<56, T, false, UNITS>(b, p, L, stream);
+        case 64: return launch_solve_n<64, T, false, UNITS>(b, p, L, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -867,11 +957,15 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
     if (b.n_systems == 0) return hipSuccess;
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);
-        if (n != 32 || p.lm.precision == 32) return hipErrorInvalidValue;
+        if (n != 32 || p.lm.precision == 32 || (p.mode & MODE_UNITS)) return hipErrorInvalidValue;
         SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u);
-        return launch_solve_n<32, double, true>(b, p, L, stream);
+        return launch_solve_n<32, double, true, false>(b, p, L, stream);
     }
-    return p.lm.precision == 32 ? launch_solve_t<float>(b, p, stream) : launch_solve_t<double>(b, p, stream);
+    if (p.mode & MODE_UNITS) {
+        if (!b.sys_unit_off) return hipErrorInvalidValue;
+        return p.lm.precision == 32 ? launch_solve_t<float, true>(b, p, stream) : launch_solve_t<double, true>(b, p, stream);
+    }
+    return p.lm.precision == 32 ? launch_solve_t<float, false>(b, p, stream) : launch_solve_t<double, false>(b, p, stream);
 }
 
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream) {

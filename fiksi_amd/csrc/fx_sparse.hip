@@ -20,9 +20,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <queue>
 #include <vector>
 
+#include "fx_decompose.h"
 #include "fx_device.h"
 #include "fx_expr.h"
 #include "fx_sparse.h"
@@ -639,6 +641,7 @@ inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block 
 // ------------------------------------------------------------------------------------------------
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
                                double* d_vars_out /* device, n_vars of the System */, fx_result* result) {
+    const bool single_pass = (prm.mode & MODE_UNITS) != 0;
     const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
     const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
     const fx_lm_opts o = prm.lm;
@@ -687,6 +690,9 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     uint32_t rng = 42u;  // Rng::from_seed(42), shared by the components (:47)
     double host3[4];
 
+    Incidence inc;
+    std::unique_ptr<SinglePassDecomposer> decomposer;
+
     for (uint32_t c = 0; c < ncomp; ++c) {
         std::vector<uint32_t> crow_ids, fvar;
         bool any_var = false;
@@ -700,8 +706,46 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         for (uint32_t i = 0; i < net; ++i)
             if ((b->expr_comp ? b->expr_comp[e0 + i] : 0) == c) crow_ids.push_back(i);
 
+        // ---- the component's perturbation (:91-111), before any of its blocks
+        if (prm.mode & 2u) {
+            const uint32_t nfv = (uint32_t)fvar.size();
+            if (nfv) {
+                Pool tmp;
+                tmp.stream = stream;
+                uint32_t* d_all = tmp.up(fvar);
+                if (tmp.err != hipSuccess) return tmp.err;
+                hipLaunchKernelGGL(sp_perturb_kernel, grid_for(nfv), dim3(256), 0, stream, d_all, nfv, rng, d_xs[0], d_xs[1]);
+                e = hipStreamSynchronize(stream);  // tmp is released at the end of this scope
+                if (e != hipSuccess) return e;
+            }
+            for (uint32_t k = 0; k < 2 * nfv; ++k) rng = rng * 1664525u + 1013904223u;  // integer bookkeeping only
+        }
+        e = hipMemcpyAsync(d_snap, d_xs[0], nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+
+        // ---- the blocks to solve: the whole component, or its SinglePass decomposition
+        UnitList units;
+        if (single_pass) {
+            if (!decomposer) {
+                inc.build(nvt, net, b->expr_tag + e0, b->expr_idx + 4 * (size_t)e0);
+                decomposer.reset(new SinglePassDecomposer(inc));
+            }
+            decomposer->run(fvar, units);
+        } else {
+            units.rows = crow_ids;
+            units.vars = fvar;
+            units.row_off.push_back((uint32_t)crow_ids.size());
+            units.var_off.push_back((uint32_t)fvar.size());
+        }
+        res.ncomp += 1;
+        res.exit = FX_EXIT_SSE;
+
+        for (uint32_t u = 0; u < units.count(); ++u) {
+        Pool pool;  // device memory of this block only
+        pool.stream = stream;
         ComponentPlan P;
-        plan_component(b, s, crow_ids, fvar, P);
+        plan_component(b, s, std::vector<uint32_t>(units.rows.begin() + units.row_off[u], units.rows.begin() + units.row_off[u + 1]),
+                       std::vector<uint32_t>(units.vars.begin() + units.var_off[u], units.vars.begin() + units.var_off[u + 1]), P);
         const uint32_t m = P.m, nv = P.nv;
 
         uint32_t* d_fvar = pool.up(P.fvar);
@@ -730,14 +774,6 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         double* d_rhs = pool.alloc<double>(nv);
         double* d_delta = pool.alloc<double>(nv);
         if (pool.err != hipSuccess) return pool.err;
-
-        if (prm.mode & 2u) {
-            if (nv) hipLaunchKernelGGL(sp_perturb_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, rng, d_xs[0], d_xs[1]);
-            for (uint32_t k = 0; k < 2 * nv; ++k) rng = rng * 1664525u + 1013904223u;  // integer bookkeeping only
-        }
-
-        e = hipMemcpyAsync(d_snap, d_xs[0], nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return e;
 
         auto eval = [&](int buf, bool want_j, double* sse_out) -> hipError_t {
             if (m) {
@@ -847,18 +883,25 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 }
             }
         }
-        // accepted point -> output; later components see the pre-solve snapshot (quirk Q2)
         if (nv) {
             hipLaunchKernelGGL(sp_writeback_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_scal, do_scale, d_vars_out);
-            hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[0]);
-            hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[1]);
+            if (single_pass) {
+                // SinglePass also updates the working vector (:201-207): later blocks see this one
+                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_xs[cur ^ 1]);
+            } else {
+                // accepted point -> output only; later components see the pre-solve snapshot (quirk Q2)
+                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[0]);
+                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[1]);
+            }
         }
+        e = hipStreamSynchronize(stream);  // the block's device memory is released when `pool` goes out of scope
+        if (e != hipSuccess) return e;
         res.accepted += accepted;
         res.trials += trials;
         res.exit = exit_code;
         res.sse0 += sse_start;
         res.sse += sse;
-        res.ncomp += 1;
+        }  // blocks
     }
 
     // ---- post-solve check on the unscaled variables

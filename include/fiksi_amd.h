@@ -18,6 +18,7 @@
  *   fx_system_solve*            == assemble::solve, Decomposer::None, LM           (assemble/mod.rs:46-167)
  *   fx_constraint_residuals*    == ConstraintHandle::calculate_residual            (constraints/mod.rs:88-110)
  *   fx_analyze_batch            == System::analyze (over-constraint detection)     (analyze/numerical/mod.rs:123-163)
+ *   fx_single_pass_blocks       == find_strongly_connected_expressions             (analyze/graph/equations.rs:186-221)
  *
  * Conventions
  *  - Plain C: pointers + sizes, no C++/torch types. All functions return 0 (FX_OK) or a negative
@@ -132,7 +133,9 @@ typedef struct fx_lm_opts {
 } fx_lm_opts;
 
 /* SolvingOptions (fiksi/src/lib.rs:205-237). optimizer: 0 = LevenbergMarquardt (only one
- * implemented on the device); decomposer: 0 = None (only one implemented). */
+ * implemented on the device); decomposer: 0 = None, 1 = SinglePass (assemble/mod.rs:169-210:
+ * maximum matching + strongly connected blocks, solved one after the other); 2 =
+ * RecursiveAssembly is reported as FX_ERR_UNSUPPORTED. */
 typedef struct fx_solving_opts {
     uint32_t optimizer;
     uint32_t decomposer;
@@ -236,6 +239,17 @@ int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent);
 /* == calculate_residual of every expression at batch->vars with all variables as given
  * (IdentityVariableMap, constraints/mod.rs:96-109). */
 int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
+/* == find_strongly_connected_expressions per connected component (analyze/graph/equations.rs:186-221),
+ * the structural plan Decomposer::SinglePass solves by: the blocks of System `system` in solve order.
+ * Host-only (no device needed). block_comp[k] = component of block k; its expressions are
+ * rows[row_off[k] .. row_off[k+1]) (system-local ids, block order), its free variables
+ * vars[var_off[k] .. var_off[k+1]) (ascending). Capacities the caller provides, with E / V the
+ * System's expression / variable counts: block_comp[4E], row_off[4E+1], rows[4E], var_off[4E+1],
+ * vars[V] — an expression joins at most one block per component it touches (at most four: the
+ * stale-label quirk of graph.rs:211-222 lets a component's matching claim a neighbour's expression),
+ * a free variable exactly one. Any output pointer may be NULL. */
+int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_blocks, uint32_t* block_comp,
+                          uint32_t* row_off, uint32_t* rows, uint32_t* var_off, uint32_t* vars);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@
 #include "fo_expressions.hpp"
 #include "fo_lm.hpp"
 #include "fo_qr.hpp"
+#include "fo_singlepass.hpp"
 #include "fo_rand.hpp"
 #include "fo_sparse.hpp"
 #include "fo_symbolic.hpp"
@@ -321,6 +322,72 @@ int fo_solve_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* 
         if (results) results[s] = res;
     });
     return 0;
+}
+
+// assemble::solve with Decomposer::SinglePass (assemble/mod.rs:169-210): scale, perturb, then one LM
+// per strongly connected block of expressions, in topological order, each seeing the previous results.
+int fo_solve_single_pass_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, double* vars,
+                               const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                               const double* expr_param, const uint16_t* var_comp, const uint16_t* expr_comp,
+                               uint32_t perturb, int ordering, uint32_t trial_cap, uint32_t nthreads, fo_result* results) {
+    QrOrdering ord = ordering ? QrOrdering::Colamd : QrOrdering::Natural;
+    parallel_for(n_systems, nthreads, [&](uint32_t s) {
+        FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, expr_comp);
+        SolveStats st = solve_single_pass(sys, perturb != 0, ord, trial_cap);
+        fo_result res{};
+        res.scale = st.scale;
+        for (const LmStats& c : st.components) {
+            res.accepted += c.accepted;
+            res.trials += c.trials;
+            res.exit = c.exit;
+            res.sse0 += c.sse_initial;
+            res.sse += c.sse_final;
+            res.ncomp += 1;
+        }
+        std::memcpy(vars + var_off[s], sys.variables.data(), sys.variables.size() * sizeof(double));
+        if (results) results[s] = res;
+    });
+    return 0;
+}
+
+// The SinglePass decomposition of component `comp` of one system: unit_of_expr[e] = position of the
+// block that solves expression e (or -1 when the expression is not matched and therefore skipped),
+// and for every block its free variables (ascending) flattened into unit_vars with unit_var_off.
+// Returns the number of blocks, or -1 if a capacity is too small.
+int fo_single_pass_units(uint32_t nvars, uint32_t nexprs, const uint8_t* var_fixed, const uint8_t* expr_tag,
+                         const uint32_t* expr_idx, const uint16_t* var_comp, uint16_t comp, int32_t* unit_of_expr,
+                         uint32_t* unit_row_off, uint32_t* unit_rows, uint32_t* unit_var_off, uint32_t* unit_vars,
+                         uint32_t cap) {
+    std::vector<Expression> ex(nexprs);
+    for (uint32_t e = 0; e < nexprs; ++e) {
+        ex[e].tag = expr_tag[e];
+        for (int k = 0; k < 4; ++k) ex[e].idx[k] = expr_idx[4 * static_cast<size_t>(e) + k];
+        ex[e].param = 0.;
+    }
+    ExpressionGraph g = ExpressionGraph::build(nvars, ex);
+    std::vector<uint32_t> free_sorted;
+    for (uint32_t v = 0; v < nvars; ++v)
+        if ((var_comp ? var_comp[v] : 0) == comp && !var_fixed[v]) free_sorted.push_back(v);
+    auto sccs = find_strongly_connected_expressions(g, free_sorted);
+    for (uint32_t e = 0; e < nexprs; ++e) unit_of_expr[e] = -1;
+    uint32_t nr = 0, nv = 0;
+    unit_row_off[0] = 0;
+    unit_var_off[0] = 0;
+    for (size_t u = 0; u < sccs.size(); ++u) {
+        if (u + 1 > cap) return -1;
+        for (uint32_t e : sccs[u].expressions) {
+            if (nr >= cap) return -1;
+            unit_of_expr[e] = static_cast<int32_t>(u);
+            unit_rows[nr++] = e;
+        }
+        for (uint32_t v : sccs[u].free_variables) {
+            if (nv >= cap) return -1;
+            unit_vars[nv++] = v;
+        }
+        unit_row_off[u + 1] = nr;
+        unit_var_off[u + 1] = nv;
+    }
+    return static_cast<int>(sccs.size());
 }
 
 // First LM step only (lambda = 0.5) of component 0 for every system, on the values as given:

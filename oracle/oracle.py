@@ -222,3 +222,34 @@ def analyze_batch(b):
     lib().fo_analyze_batch(C.c_uint32(n), _p(b["var_off"]), _p(b["expr_off"]), _p(b["vars"]), _p(b["expr_tag"]),
                            _p(b["expr_idx"]), _p(b["expr_param"]), _p(dep))
     return dep
+
+
+def solve_single_pass_batch(b, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, nthreads: int = 1):
+    """assemble::solve with Decomposer::SinglePass. Returns (solved variables, per-system results)."""
+    n, args = _batch_args(b)
+    vars_out = b["vars"].copy()
+    args[3] = _p(vars_out)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    lib().fo_solve_single_pass_batch(*args, _p(b.get("var_comp")), _p(b.get("expr_comp")), C.c_uint32(1 if perturb else 0),
+                                     C.c_int(1 if ordering == "colamd" else 0), C.c_uint32(trial_cap),
+                                     C.c_uint32(nthreads), _p(res))
+    return vars_out, res
+
+
+def single_pass_units(b, system: int = 0, comp: int = 0):
+    """The SinglePass blocks of one component: list of (expression ids in block order, free variables)."""
+    v0, v1 = int(b["var_off"][system]), int(b["var_off"][system + 1])
+    e0, e1 = int(b["expr_off"][system]), int(b["expr_off"][system + 1])
+    nv, ne = v1 - v0, e1 - e0
+    cap = 8 * ne + nv + 8
+    uoe = np.zeros(max(ne, 1), dtype=np.int32)
+    ro = np.zeros(cap + 1, dtype=np.uint32); rows = np.zeros(cap, dtype=np.uint32)
+    vo = np.zeros(cap + 1, dtype=np.uint32); vs = np.zeros(cap, dtype=np.uint32)
+    fixed = np.ascontiguousarray(b["var_fixed"][v0:v1])
+    tags = np.ascontiguousarray(b["expr_tag"][e0:e1])
+    idx = np.ascontiguousarray(b["expr_idx"][4 * e0:4 * e1])
+    vc = None if b.get("var_comp") is None else np.ascontiguousarray(b["var_comp"][v0:v1])
+    nu = lib().fo_single_pass_units(C.c_uint32(nv), C.c_uint32(ne), _p(fixed), _p(tags), _p(idx), _p(vc), C.c_uint16(comp),
+                                    _p(uoe), _p(ro), _p(rows), _p(vo), _p(vs), C.c_uint32(cap))
+    assert nu >= 0
+    return [(rows[ro[u]:ro[u + 1]].tolist(), vs[vo[u]:vo[u + 1]].tolist()) for u in range(nu)]

@@ -92,11 +92,30 @@ int main(int argc, char** argv) {
     CHECK(rms(u.constraint_residuals()) < RESIDUAL_THRESHOLD);
     CHECK(std::hypot(get_value(r2, u).x - 5., get_value(r2, u).y - 5.) < RESIDUAL_THRESHOLD);
 
+    // fixed.rs also runs the sketch with Decomposer::SinglePass
+    {
+        System w;
+        auto q0 = elements::create_point(w, 0., 0.);
+        auto q1 = elements::create_point(w, 1., 0.5);
+        auto q2 = elements::create_point(w, 2., 1.);
+        auto q3 = elements::create_point(w, 5., 5.);
+        fix(q3, w);
+        constraints::create_point_point_distance(w, q0, q1, 1.);
+        constraints::create_point_point_distance(w, q1, q2, 1.);
+        constraints::create_point_point_coincidence(w, q2, q3);
+        SolvingOptions o;
+        o.decomposer = Decomposer::SinglePass;
+        w.solve(o);
+        CHECK(rms(w.constraint_residuals()) < RESIDUAL_THRESHOLD);
+        CHECK(std::hypot(get_value(q2, w).x - 5., get_value(q2, w).y - 5.) < RESIDUAL_THRESHOLD);
+        CHECK(get_value(q3, w).x == 5. && get_value(q3, w).y == 5.);
+    }
+
     // unsupported arms are errors, not silent fallbacks
     threw = false;
     try {
         SolvingOptions o;
-        o.decomposer = Decomposer::SinglePass;
+        o.decomposer = Decomposer::RecursiveAssembly;
         u.solve(o);
     } catch (const Error& e) {
         threw = e.code == FX_ERR_UNSUPPORTED;

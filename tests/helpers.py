@@ -56,3 +56,52 @@ def csr_to_dense(row_ptr, col, vals, rows, ncols):
         for p in range(int(row_ptr[r]), int(row_ptr[r + 1])):
             d[r, int(col[p])] += vals[p]
     return d
+
+
+def random_sketch(seed: int) -> System:
+    """A sketch with random topology: 3..12 points, lines and circles over them, 2..14 constraints of
+    random kinds between random (distinct) elements, a few fixed elements — so the constraint graph
+    falls into several components, is under-, well- and over-constrained in places, and the SinglePass
+    decomposition produces blocks of many shapes."""
+    g = Lcg(seed)
+
+    def pick(seq, k=1):
+        pool = list(seq)
+        out = []
+        for _ in range(k):
+            out.append(pool.pop(int(g.u(0, len(pool) - 1e-9))))
+        return out[0] if k == 1 else out
+
+    s = System()
+    P = [elements.Point.create(s, g.u(-10, 10), g.u(-10, 10)) for _ in range(int(g.u(4, 12.99)))]
+    L = [elements.Line.create(s, *pick(P, 2)) for _ in range(int(g.u(2, 4.99)))]
+    C = [elements.Circle.create(s, pick(P), elements.Length.create(s, g.u(1, 4))) for _ in range(int(g.u(0, 2.99)))]
+    for p in P:
+        if g.u(0, 1) < 0.15:
+            p.fix(s)
+    for _ in range(int(g.u(2, 14.99))):
+        k = int(g.u(0, 10.99))
+        if k == 0:
+            constraints.PointPointDistance.create(s, *pick(P, 2), g.u(2, 8))
+        elif k == 1:
+            constraints.PointPointCoincidence.create(s, *pick(P, 2))
+        elif k == 2:
+            constraints.PointPointPointAngle.create(s, *pick(P, 3), g.u(-2, 2))
+        elif k == 3:
+            constraints.PointLineIncidence.create(s, pick(P), pick(L))
+        elif k == 4:
+            constraints.PointLineDistance.create(s, pick(P), pick(L), g.u(-3, 3))
+        elif k == 5 and C:
+            constraints.PointCircleIncidence.create(s, pick(P), pick(C))
+        elif k == 6:
+            a, b, c, d = pick(P, 4)
+            constraints.SegmentSegmentLengthEquality.create(s, a, b, c, d)
+        elif k == 7:
+            constraints.LineLineAngle.create(s, *pick(L, 2), g.u(-2, 2))
+        elif k == 8:
+            constraints.LineLineParallelism.create(s, *pick(L, 2))
+        elif k == 9:
+            constraints.LineLinePerpendicularity.create(s, *pick(L, 2))
+        elif k == 10 and C:
+            constraints.LineCircleTangency.create(s, pick(L), pick(C))
+    return s

@@ -143,7 +143,8 @@ def test_two_connected_components(F, oracle):  # basic.rs:152-170
 
 # ---- triangles.rs --------------------------------------------------------------------------------
 
-def test_single_triangle(F, oracle):  # triangles.rs:9-37 (Decomposer::None arm)
+@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass"])
+def test_single_triangle(F, oracle, decomposer):  # triangles.rs:9-37, both arms
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
@@ -151,21 +152,20 @@ def test_single_triangle(F, oracle):  # triangles.rs:9-37 (Decomposer::None arm)
     F.constraints.PointPointDistance.create(s, p0, p1, 1.)
     F.constraints.PointPointDistance.create(s, p0, p2, 1.)
     F.constraints.PointPointDistance.create(s, p1, p2, 1.)
-    s.solve(F.SolvingOptions(decomposer=F.Decomposer.NONE))
+    s.solve(F.SolvingOptions(decomposer=F.Decomposer[decomposer]))
     assert rms(c.calculate_residual(s) for c in s.get_constraint_handles()) < RESIDUAL_THRESHOLD
 
 
-def test_other_decomposers_are_reported_unsupported(F):
+def test_unimplemented_options_are_reported_unsupported(F):
     from fiksi_amd._lib import FiksiError
 
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
     F.constraints.PointPointDistance.create(s, p0, p1, 1.)
-    for dec in (F.Decomposer.SinglePass, F.Decomposer.RecursiveAssembly):
-        with pytest.raises(FiksiError) as e:
-            s.solve(F.SolvingOptions(decomposer=dec))
-        assert e.value.code == -6
+    with pytest.raises(FiksiError) as e:
+        s.solve(F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly))
+    assert e.value.code == -6
     with pytest.raises(FiksiError):
         s.solve(F.SolvingOptions(optimizer=F.Optimizer.LBfgs))
 
@@ -214,7 +214,8 @@ def test_collinear_points(F, oracle):  # singular.rs:19-40 (needs the perturbati
 
 # ---- fixed.rs ------------------------------------------------------------------------------------
 
-def test_single_triangle_with_fixed_point(F, oracle):  # fixed.rs:10-43
+@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass"])  # fixed.rs loops over both
+def test_single_triangle_with_fixed_point(F, oracle, decomposer):  # fixed.rs:10-43
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
@@ -223,12 +224,13 @@ def test_single_triangle_with_fixed_point(F, oracle):  # fixed.rs:10-43
     F.constraints.PointPointDistance.create(s, p0, p1, 1.)
     F.constraints.PointPointDistance.create(s, p0, p2, 1.)
     F.constraints.PointPointDistance.create(s, p1, p2, 1.)
-    s.solve(F.SolvingOptions.DEFAULT)
+    s.solve(F.SolvingOptions(decomposer=F.Decomposer[decomposer]))
     assert rms(c.calculate_residual(s) for c in s.get_constraint_handles()) < RESIDUAL_THRESHOLD
     assert p1.get_value(s) == (1., 0.5)  # bit-identical
 
 
-def test_fixed_point_and_circle_center_incidence(F, oracle):  # fixed.rs:47-82
+@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass"])  # fixed.rs loops over both
+def test_fixed_point_and_circle_center_incidence(F, oracle, decomposer):  # fixed.rs:47-82
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     center = F.elements.Point.create(s, 4., 3.)
@@ -237,13 +239,14 @@ def test_fixed_point_and_circle_center_incidence(F, oracle):  # fixed.rs:47-82
     p0.fix(s)
     center.fix(s)
     F.constraints.PointCircleIncidence.create(s, p0, circle)
-    s.solve(F.SolvingOptions.DEFAULT)
+    s.solve(F.SolvingOptions(decomposer=F.Decomposer[decomposer]))
     assert p0.get_value(s) == (0., 0.)
     assert center.get_value(s) == (4., 3.)
     assert abs(radius.get_value(s) - 5.) < RESIDUAL_THRESHOLD
 
 
-def test_fixed_with_coincidence(F, oracle):  # fixed.rs:94-127
+@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass"])  # fixed.rs loops over both
+def test_fixed_with_coincidence(F, oracle, decomposer):  # fixed.rs:94-127
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
@@ -253,7 +256,7 @@ def test_fixed_with_coincidence(F, oracle):  # fixed.rs:94-127
     F.constraints.PointPointDistance.create(s, p0, p1, 1.)
     F.constraints.PointPointDistance.create(s, p1, p2, 1.)
     F.constraints.PointPointCoincidence.create(s, p2, p3)
-    s.solve(F.SolvingOptions.DEFAULT)
+    s.solve(F.SolvingOptions(decomposer=F.Decomposer[decomposer]))
     assert rms(c.calculate_residual(s) for c in s.get_constraint_handles()) < RESIDUAL_THRESHOLD
     x, y = p2.get_value(s)
     assert math.hypot(x - 5., y - 5.) < RESIDUAL_THRESHOLD
