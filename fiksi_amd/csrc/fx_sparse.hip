@@ -236,14 +236,24 @@ struct SpChol {                  // symbolic factor (device)
     uint32_t nv;
 };
 
-// K4a: numeric sparse Cholesky of A + lambda I, left-looking by gather lists, one wavefront walks
-// the columns in order. flag[0] = 1 when a pivot is not positive and finite. Columns of up to 64
-// entries (the usual case) take one pass and one barrier: the pivot travels by v_readlane.
-__global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* __restrict__ a, double lambda,
+// Work lists of the elimination-tree schedule: list q holds columns cols[ptr[q] .. ptr[q+1]) in
+// ascending order. One wavefront walks one list; the lists of one launch are independent subtrees
+// ("domains"), the columns above them ("top") form a single list run afterwards.
+struct ColLists {
+    const uint32_t* ptr;
+    const uint32_t* cols;
+};
+
+// K4a: numeric sparse Cholesky of A + lambda I, left-looking by gather lists. flag[0] |= 1 when a
+// pivot is not positive and finite. Columns of up to 64 entries (the usual case) take one pass: the
+// pivot travels by v_readlane. Everything a column reads was written either by this wavefront
+// (descendants inside the same subtree) or by an earlier launch.
+__global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, ColLists cl, const double* __restrict__ a, double lambda,
                                                        double* __restrict__ l, uint32_t* __restrict__ flag) {
     const int lane = threadIdx.x;
     bool bad = false;
-    for (uint32_t j = 0; j < c.nv; ++j) {
+    for (uint32_t q = cl.ptr[blockIdx.x]; q < cl.ptr[blockIdx.x + 1]; ++q) {
+        const uint32_t j = cl.cols[q];
         const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
         if (end - beg <= 64u) {
             const uint32_t k = beg + lane;
@@ -288,53 +298,50 @@ __global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, const double* _
         }
         __syncthreads();
     }
-    if (lane == 0) flag[0] = bad ? 1u : 0u;
+    if (lane == 0 && bad) atomicOr(flag, 1u);
 }
 
-// K4b: L y = b (column sweep), Lt x = y (row gathers); x overwrites b; out[0] = |x|^2. With
-// IN_LDS the right-hand side lives in LDS for the two sweeps (nv * 8 bytes <= 160 KB).
-template <bool IN_LDS>
-__global__ __launch_bounds__(64) void sp_solve_kernel(SpChol c, const double* __restrict__ l, double* __restrict__ b,
-                                                      double* __restrict__ out) {
-    extern __shared__ __align__(16) double sb[];
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct SpRowsOfL {               // L by rows (strictly lower part), for the forward sweep
+    const uint32_t* rptr;        // [nv+1]
+    const uint32_t* ridx;        // index of the entry in L's value array
+    const uint32_t* rcol;        // its column
+};
+
+// K4b: L y = b by row gathers: y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj. A row only reads columns
+// below it in the elimination tree, so the factor's schedule applies unchanged. y overwrites b.
+__global__ __launch_bounds__(64) void sp_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl, const double* __restrict__ l,
+                                                        double* __restrict__ b) {
     const int lane = threadIdx.x;
-    if (IN_LDS) {
-        for (uint32_t i = lane; i < c.nv; i += 64) sb[i] = b[i];
+    for (uint32_t q = cl.ptr[blockIdx.x]; q < cl.ptr[blockIdx.x + 1]; ++q) {
+        const uint32_t j = cl.cols[q];
+        double part = 0.0;
+        for (uint32_t p = lr.rptr[j] + lane; p < lr.rptr[j + 1]; p += 64) part = fma(l[lr.ridx[p]], ld_l2(b + lr.rcol[p]), part);
+        part = wave_sum64(part);
+        if (lane == 0) b[j] = (ld_l2(b + j) - part) / l[c.lcolptr[j]];
+        __syncthreads();  // waits for the store: the next row of this list may read it
+    }
+}
+
+// K4c: Lt x = y by column gathers, lists walked backwards: x_j = (y_j - sum_{i>j} L_ij x_i) / L_jj
+// reads only ancestors of j — the top list runs first, then the subtrees. x overwrites y.
+__global__ __launch_bounds__(64) void sp_backward_kernel(SpChol c, ColLists cl, const double* __restrict__ l,
+                                                         double* __restrict__ b) {
+    const int lane = threadIdx.x;
+    for (uint32_t q = cl.ptr[blockIdx.x + 1]; q-- > cl.ptr[blockIdx.x];) {
+        const uint32_t j = cl.cols[q];
+        const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
+        double part = 0.0;
+        for (uint32_t k = beg + 1 + lane; k < end; k += 64) part = fma(l[k], ld_l2(b + c.lrow[k]), part);
+        part = wave_sum64(part);
+        if (lane == 0) b[j] = (ld_l2(b + j) - part) / l[beg];
         __syncthreads();
     }
-    auto get = [&](uint32_t i) -> double { return IN_LDS ? sb[i] : ld_l2(b + i); };
-    auto put = [&](uint32_t i, double v) {
-        if (IN_LDS) sb[i] = v; else b[i] = v;
-    };
-    for (uint32_t j = 0; j < c.nv; ++j) {
-        const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
-        // One wavefront: LDS operations retire in program order, so in LDS mode the sweeps need no
-        // barrier at all; the global-memory fallback waits for its stores at every column.
-        double yj = get(j) / l[beg];
-        for (uint32_t k = beg + 1 + lane; k < end; k += 64) {
-            uint32_t i = c.lrow[k];
-            put(i, get(i) - l[k] * yj);  // rows of one column are distinct: no conflicts
-        }
-        if (lane == 0) put(j, yj);
-        if (!IN_LDS) __syncthreads();
-    }
-    double n2 = 0.0;
-    for (uint32_t jj = c.nv; jj-- > 0;) {
-        const uint32_t beg = c.lcolptr[jj], end = c.lcolptr[jj + 1];
-        double part = 0.0;
-        for (uint32_t k = beg + 1 + lane; k < end; k += 64) part += l[k] * get(c.lrow[k]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        double xj = (get(jj) - part) / l[beg];
-        if (lane == 0) put(jj, xj);
-        n2 += xj * xj;
-        if (!IN_LDS) __syncthreads();
-    }
-    if (IN_LDS) __syncthreads();
-    if (IN_LDS) {
-        for (uint32_t i = lane; i < c.nv; i += 64) b[i] = sb[i];
-    }
-    if (lane == 0) out[0] = n2;
 }
 
 // trial point: xs_dst[fvar[perm[k]]] = xs_src[...] + delta[k]
@@ -460,6 +467,107 @@ std::vector<uint32_t> rcm_order(const std::vector<std::vector<uint32_t>>& adj) {
     return order;  // order[new] = old
 }
 
+// Nested-dissection order of the column graph (George's automatic scheme): split the level structure
+// of a breadth-first search from a pseudo-peripheral node at its median level, number the two halves
+// recursively and the separator last. Each half holds at most half of the nodes, so the recursion is
+// O(log n) deep; the separators become the top of the elimination tree and the halves independent
+// subtrees — that independence is what the device schedule runs in parallel. Pieces of up to `leaf`
+// nodes (and pieces a median level cannot split) are numbered by reverse Cuthill-McKee.
+std::vector<uint32_t> nd_order(const std::vector<std::vector<uint32_t>>& adj, uint32_t leaf = 48) {
+    const uint32_t n = (uint32_t)adj.size();
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<uint32_t> piece(n, 0);   // id of the piece a node currently belongs to
+    std::vector<uint32_t> level(n, 0), local(n, 0);
+    uint32_t next_piece = 1;
+
+    auto rcm_piece = [&](const std::vector<uint32_t>& nodes) {
+        std::vector<std::vector<uint32_t>> sub(nodes.size());
+        for (uint32_t k = 0; k < nodes.size(); ++k) local[nodes[k]] = k;
+        const uint32_t id = piece[nodes[0]];
+        for (uint32_t k = 0; k < nodes.size(); ++k)
+            for (uint32_t w : adj[nodes[k]])
+                if (piece[w] == id) sub[k].push_back(local[w]);
+        for (uint32_t k : rcm_order(sub)) order.push_back(nodes[k]);
+    };
+
+    struct Job { std::vector<uint32_t> nodes; bool emit_only; };  // emit_only: a separator, numbered as is
+    std::vector<Job> jobs;
+    {
+        std::vector<uint32_t> all(n);
+        for (uint32_t i = 0; i < n; ++i) all[i] = i;
+        if (n) jobs.push_back({std::move(all), false});
+    }
+    std::vector<uint32_t> queue;
+    while (!jobs.empty()) {
+        Job job = std::move(jobs.back());
+        jobs.pop_back();
+        if (job.emit_only) {
+            order.insert(order.end(), job.nodes.begin(), job.nodes.end());
+            continue;
+        }
+        const uint32_t id = next_piece++;
+        for (uint32_t v : job.nodes) piece[v] = id;
+        if (job.nodes.size() <= leaf) {
+            rcm_piece(job.nodes);
+            continue;
+        }
+        // one connected part at a time: the rest of the piece is pushed back untouched
+        auto bfs = [&](uint32_t root) {
+            queue.assign(1, root);
+            const uint32_t tag = next_piece++;
+            piece[root] = tag;
+            level[root] = 0;
+            for (size_t head = 0; head < queue.size(); ++head) {
+                uint32_t u = queue[head];
+                for (uint32_t w : adj[u])
+                    if (piece[w] == id) {
+                        piece[w] = tag;
+                        level[w] = level[u] + 1;
+                        queue.push_back(w);
+                    }
+            }
+            for (uint32_t v : queue) piece[v] = id;  // restore
+        };
+        bfs(job.nodes[0]);
+        if (queue.size() < job.nodes.size()) {  // disconnected: split off this part
+            std::vector<uint32_t> part = queue, rest;
+            const uint32_t tag = next_piece++;
+            for (uint32_t v : part) piece[v] = tag;
+            for (uint32_t v : job.nodes)
+                if (piece[v] == id) rest.push_back(v);
+            jobs.push_back({std::move(rest), false});
+            jobs.push_back({std::move(part), false});
+            continue;
+        }
+        bfs(queue.back());  // twice from the far end: a pseudo-peripheral root
+        bfs(queue.back());
+        const uint32_t depth = level[queue.back()];
+        uint32_t cut = 0;
+        {
+            std::vector<uint32_t> count(depth + 1, 0);
+            for (uint32_t v : queue) count[level[v]]++;
+            uint32_t below = 0;
+            while (cut < depth && 2 * (below + count[cut]) < queue.size()) below += count[cut++];
+        }
+        std::vector<uint32_t> lo, hi, sep;
+        for (uint32_t v : queue) {
+            if (level[v] < cut) lo.push_back(v);
+            else if (level[v] > cut) hi.push_back(v);
+            else sep.push_back(v);
+        }
+        if (lo.empty() || hi.empty()) {  // too few levels to cut (clique-like piece)
+            rcm_piece(job.nodes);
+            continue;
+        }
+        // numbered in pop order: lo, hi, then the separator
+        jobs.push_back({std::move(sep), true});
+        jobs.push_back({std::move(hi), false});
+        jobs.push_back({std::move(lo), false});
+    }
+    return order;  // order[new] = old
+}
+
 struct ComponentPlan {
     uint32_t m = 0, nv = 0, nnz_j = 0, nnz_a = 0, nnz_l = 0;
     std::vector<uint32_t> rows, fvar;
@@ -469,6 +577,9 @@ struct ComponentPlan {
     std::vector<uint32_t> cptr, cidx, crow;            // columns of J (permuted order) for the rhs
     std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs;
     std::vector<int32_t> l2a;
+    std::vector<uint32_t> rptr, ridx, rcol;            // strictly lower part of L by rows
+    std::vector<uint32_t> dom_ptr, dom_cols;           // independent subtrees of the elimination tree
+    std::vector<uint32_t> top_ptr, top_cols;           // the columns above them (one list)
 };
 
 // Builds every index structure of one component. `colof[v]` = free column of system variable v
@@ -506,7 +617,7 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
         std::sort(a.begin(), a.end());
         a.erase(std::unique(a.begin(), a.end()), a.end());
     }
-    P.perm = rcm_order(adj);
+    P.perm = nd_order(adj);
     std::vector<uint32_t> iperm(P.nv);
     for (uint32_t k = 0; k < P.nv; ++k) iperm[P.perm[k]] = k;
 
@@ -630,6 +741,79 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
                     P.lpairs[2 * (size_t)dst + 1] = P.lcolptr[k] + (uint32_t)p;  // L[j][k]
                 }
     }
+
+    // --- L by rows (forward sweep gathers)
+    P.rptr.assign((size_t)P.nv + 1, 0);
+    for (uint32_t j = 0; j < P.nv; ++j)
+        for (size_t t = 1; t < lcol[j].size(); ++t) P.rptr[lcol[j][t] + 1]++;
+    for (uint32_t j = 0; j < P.nv; ++j) P.rptr[j + 1] += P.rptr[j];
+    P.ridx.assign(P.rptr[P.nv], 0);
+    P.rcol.assign(P.rptr[P.nv], 0);
+    {
+        std::vector<uint32_t> fill(P.rptr.begin(), P.rptr.end() - 1);
+        for (uint32_t j = 0; j < P.nv; ++j)
+            for (size_t t = 1; t < lcol[j].size(); ++t) {
+                uint32_t dst = fill[lcol[j][t]]++;
+                P.ridx[dst] = P.lcolptr[j] + (uint32_t)t;
+                P.rcol[dst] = j;
+            }
+    }
+
+    // --- schedule: a column depends only on its descendants in the elimination tree (parent = first
+    // sub-diagonal row). Subtrees whose work fits under a cap become independent lists, one wavefront
+    // each; everything above them is the sequential top list. The cap minimising (largest subtree +
+    // top) — the length of the critical path of this two-phase schedule — is picked from a geometric
+    // ladder.
+    std::vector<uint64_t> work(P.nv, 0), subtree(P.nv, 0);
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        uint64_t w = 4;  // per-column latency floor
+        for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) w += 1 + (P.lpair_ptr[k + 1] - P.lpair_ptr[k]);
+        work[j] = w;
+        total += w;
+    }
+    auto parent_of = [&](uint32_t j) { return lcol[j].size() > 1 ? lcol[j][1] : 0xFFFFFFFFu; };
+    for (uint32_t j = 0; j < P.nv; ++j) subtree[j] = work[j];
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        uint32_t pa = parent_of(j);
+        if (pa != 0xFFFFFFFFu) subtree[pa] += subtree[j];  // children come before parents
+    }
+    uint64_t best_cap = total, best_cost = total;
+    for (uint64_t cap = total; cap >= 64; cap = cap * 3 / 4) {
+        uint64_t top = 0, biggest = 0;
+        for (uint32_t j = 0; j < P.nv; ++j) {
+            if (subtree[j] > cap) top += work[j];
+            else {
+                uint32_t pa = parent_of(j);
+                if (pa == 0xFFFFFFFFu || subtree[pa] > cap) biggest = std::max(biggest, subtree[j]);
+            }
+        }
+        if (top + biggest < best_cost) {
+            best_cost = top + biggest;
+            best_cap = cap;
+        }
+    }
+    std::vector<uint32_t> dom(P.nv, 0xFFFFFFFFu);
+    uint32_t ndom = 0;
+    for (uint32_t j = P.nv; j-- > 0;) {
+        if (subtree[j] > best_cap) continue;  // top
+        uint32_t pa = parent_of(j);
+        dom[j] = (pa == 0xFFFFFFFFu || subtree[pa] > best_cap) ? ndom++ : dom[pa];
+    }
+    P.dom_ptr.assign((size_t)ndom + 1, 0);
+    for (uint32_t j = 0; j < P.nv; ++j)
+        if (dom[j] != 0xFFFFFFFFu) P.dom_ptr[dom[j] + 1]++;
+    for (uint32_t d = 0; d < ndom; ++d) P.dom_ptr[d + 1] += P.dom_ptr[d];
+    P.dom_cols.assign(P.dom_ptr[ndom], 0);
+    {
+        std::vector<uint32_t> fill(P.dom_ptr.begin(), P.dom_ptr.end() - 1);
+        for (uint32_t j = 0; j < P.nv; ++j)
+            if (dom[j] != 0xFFFFFFFFu) P.dom_cols[fill[dom[j]]++] = j;  // ascending within a list
+    }
+    P.top_cols.clear();
+    for (uint32_t j = 0; j < P.nv; ++j)
+        if (dom[j] == 0xFFFFFFFFu) P.top_cols.push_back(j);
+    P.top_ptr = {0u, (uint32_t)P.top_cols.size()};
 }
 
 inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block ? (n + block - 1) / block : 1); }
@@ -767,6 +951,17 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         chol.lpair_ptr = pool.up(P.lpair_ptr);
         chol.lpairs = pool.up(P.lpairs);
         chol.nv = nv;
+        SpRowsOfL lrows;
+        lrows.rptr = pool.up(P.rptr);
+        lrows.ridx = pool.up(P.ridx);
+        lrows.rcol = pool.up(P.rcol);
+        ColLists doms, top;
+        doms.ptr = pool.up(P.dom_ptr);
+        doms.cols = pool.up(P.dom_cols);
+        top.ptr = pool.up(P.top_ptr);
+        top.cols = pool.up(P.top_cols);
+        const uint32_t ndom = (uint32_t)P.dom_ptr.size() - 1;
+        const bool has_top = !P.top_cols.empty();
         double* d_r[2] = {pool.alloc<double>(m), pool.alloc<double>(m)};
         double* d_j[2] = {pool.alloc<double>(P.nnz_j), pool.alloc<double>(P.nnz_j)};
         double* d_a = pool.alloc<double>(P.nnz_a);
@@ -819,18 +1014,19 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 trials += 1;
                 const int trial = cur ^ 1;
                 // factor, solve, trial point, trial residuals (+ Jacobian: it becomes J on acceptance)
-                hipLaunchKernelGGL(sp_factor_kernel, dim3(1), dim3(64), 0, stream, chol, d_a, lambda, d_l, d_flag);
+                e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream);
+                if (e != hipSuccess) return e;
+                if (ndom) hipLaunchKernelGGL(sp_factor_kernel, dim3(ndom), dim3(64), 0, stream, chol, doms, d_a, lambda, d_l, d_flag);
+                if (has_top) hipLaunchKernelGGL(sp_factor_kernel, dim3(1), dim3(64), 0, stream, chol, top, d_a, lambda, d_l, d_flag);
                 e = hipMemcpyAsync(d_delta, d_rhs, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
                 if (e != hipSuccess) return e;
-                if ((size_t)nv * sizeof(double) <= 150u * 1024u) {
-                    size_t lds = (size_t)nv * sizeof(double);
-                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_solve_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(sp_solve_kernel<true>, dim3(1), dim3(64), lds, stream, chol, d_l, d_delta, d_scal + 3);
-                } else {
-                    hipLaunchKernelGGL(sp_solve_kernel<false>, dim3(1), dim3(64), 0, stream, chol, d_l, d_delta, d_scal + 3);
+                if (ndom) hipLaunchKernelGGL(sp_forward_kernel, dim3(ndom), dim3(64), 0, stream, chol, lrows, doms, d_l, d_delta);
+                if (has_top) {
+                    hipLaunchKernelGGL(sp_forward_kernel, dim3(1), dim3(64), 0, stream, chol, lrows, top, d_l, d_delta);
+                    hipLaunchKernelGGL(sp_backward_kernel, dim3(1), dim3(64), 0, stream, chol, top, d_l, d_delta);
                 }
+                if (ndom) hipLaunchKernelGGL(sp_backward_kernel, dim3(ndom), dim3(64), 0, stream, chol, doms, d_l, d_delta);
+                hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_delta, nv, d_scal + 3);
                 if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);
                 if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[trial], d_r[trial], d_j[trial]);
                 hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[trial], m, d_scal + 2);

@@ -390,6 +390,15 @@ int fo_single_pass_units(uint32_t nvars, uint32_t nexprs, const uint8_t* var_fix
     return static_cast<int>(sccs.size());
 }
 
+// permutation.rs:41-80: applies the gather permutation to `values` in place through the swap
+// sequence; returns the number of swaps.
+int fo_permute(uint32_t n, const uint32_t* permutation, double* values) {
+    std::vector<size_t> p(permutation, permutation + n);
+    PermutationSequence seq = PermutationSequence::build_for_gather_permutation(p);
+    seq.permute_slice(values);
+    return static_cast<int>(seq.swap_sequence.size());
+}
+
 // First LM step only (lambda = 0.5) of component 0 for every system, on the values as given:
 // delta for the free variables (ascending order) written to delta[var_off[s] + k], k < nfree.
 int fo_first_step_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,

@@ -253,3 +253,11 @@ def single_pass_units(b, system: int = 0, comp: int = 0):
                                     _p(uoe), _p(ro), _p(rows), _p(vo), _p(vs), C.c_uint32(cap))
     assert nu >= 0
     return [(rows[ro[u]:ro[u + 1]].tolist(), vs[vo[u]:vo[u + 1]].tolist()) for u in range(nu)]
+
+
+def permute(permutation, values):
+    """PermutationSequence::build_for_gather_permutation + permute_slice. Returns (permuted values, swaps)."""
+    perm = np.ascontiguousarray(permutation, dtype=np.uint32)
+    vals = np.ascontiguousarray(values, dtype=np.float64).copy()
+    n = lib().fo_permute(C.c_uint32(len(perm)), _p(perm), _p(vals))
+    return vals, n
