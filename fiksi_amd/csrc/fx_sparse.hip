@@ -237,24 +237,48 @@ struct SpChol {                  // symbolic factor (device)
 };
 
 // Work lists of the elimination-tree schedule: list q holds columns cols[ptr[q] .. ptr[q+1]) in
-// ascending order. One wavefront walks one list; the lists of one launch are independent subtrees
-// ("domains"), the columns above them ("top") form a single list run afterwards.
+// ascending order; one wavefront walks one list. Lists are grouped in levels: level 0 are whole
+// subtrees, the columns above them form chains whose level is one more than the deepest list below.
+// One launch covers the lists [first, first + gridDim.x) of one level, which are independent.
 struct ColLists {
     const uint32_t* ptr;
     const uint32_t* cols;
+    uint32_t first;
 };
 
-// K4a: numeric sparse Cholesky of A + lambda I, left-looking by gather lists. flag[0] |= 1 when a
-// pivot is not positive and finite. Columns of up to 64 entries (the usual case) take one pass: the
-// pivot travels by v_readlane. Everything a column reads was written either by this wavefront
-// (descendants inside the same subtree) or by an earlier launch.
-__global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, ColLists cl, const double* __restrict__ a, double lambda,
-                                                       double* __restrict__ l, uint32_t* __restrict__ flag) {
+__device__ __forceinline__ double wave_sum64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+struct SpRowsOfL {               // L by rows (strictly lower part), for the forward sweep
+    const uint32_t* rptr;        // [nv+1]
+    const uint32_t* ridx;        // index of the entry in L's value array
+    const uint32_t* rcol;        // its column
+};
+
+// K4a + K4b: numeric sparse Cholesky of A + lambda I, left-looking by gather lists, with the forward
+// sweep L y = b riding along: once column j is factored, row j of L is complete (it only holds
+// columns below j in the elimination tree), so y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj follows at
+// once. flag[0] |= 1 when a pivot is not positive and finite. Columns of up to 64 entries (the usual
+// case) take one pass: the pivot travels by v_readlane. Everything a column reads was written either
+// by this wavefront or by an earlier launch (a lower level). y overwrites b.
+__global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl,
+                                                               const double* __restrict__ a, double lambda,
+                                                               double* __restrict__ l, double* __restrict__ b,
+                                                               uint32_t* __restrict__ flag) {
     const int lane = threadIdx.x;
+    const uint32_t list = cl.first + blockIdx.x;
     bool bad = false;
-    for (uint32_t q = cl.ptr[blockIdx.x]; q < cl.ptr[blockIdx.x + 1]; ++q) {
+    for (uint32_t q = cl.ptr[list]; q < cl.ptr[list + 1]; ++q) {
         const uint32_t j = cl.cols[q];
         const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
+        // forward-sweep gather for row j (all of its columns are final already)
+        double part = 0.0;
+        for (uint32_t p = lr.rptr[j] + lane; p < lr.rptr[j + 1]; p += 64)
+            part = fma(ld_l2(l + lr.ridx[p]), ld_l2(b + lr.rcol[p]), part);
+        double d;
         if (end - beg <= 64u) {
             const uint32_t k = beg + lane;
             double s = 0.0;
@@ -269,71 +293,46 @@ __global__ __launch_bounds__(64) void sp_factor_kernel(SpChol c, ColLists cl, co
             int hi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
             double piv = __hiloint2double(hi, lo);
             bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
-            double d = ::sqrt(piv);
+            d = ::sqrt(piv);
             if (k < end) l[k] = (k == beg) ? d : s / d;
+        } else {
+            for (uint32_t base = beg; base < end; base += 64) {
+                uint32_t k = base + lane;
+                if (k < end) {
+                    int32_t ai = c.l2a[k];
+                    double s = ai >= 0 ? a[ai] : 0.0;
+                    if (k == beg) s += lambda;
+                    for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
+                        s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
+                    l[k] = s;
+                }
+            }
             __syncthreads();
-            continue;
-        }
-        for (uint32_t base = beg; base < end; base += 64) {
-            uint32_t k = base + lane;
-            if (k < end) {
-                int32_t ai = c.l2a[k];
-                double s = ai >= 0 ? a[ai] : 0.0;
-                if (k == beg) s += lambda;
-                for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
-                    s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
-                l[k] = s;
+            double piv = ld_l2(l + beg);
+            bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
+            d = ::sqrt(piv);
+            for (uint32_t base = beg; base < end; base += 64) {
+                uint32_t k = base + lane;
+                if (k < end) {
+                    double raw = ld_l2(l + k);
+                    l[k] = (k == beg) ? d : raw / d;
+                }
             }
         }
-        __syncthreads();
-        double piv = ld_l2(l + beg);
-        bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
-        double d = ::sqrt(piv);
-        for (uint32_t base = beg; base < end; base += 64) {
-            uint32_t k = base + lane;
-            if (k < end) {
-                double raw = ld_l2(l + k);
-                l[k] = (k == beg) ? d : raw / d;
-            }
-        }
-        __syncthreads();
+        part = wave_sum64(part);
+        if (lane == 0) b[j] = (ld_l2(b + j) - part) / d;
+        __syncthreads();  // waits for the stores: the next column of this list may read them
     }
     if (lane == 0 && bad) atomicOr(flag, 1u);
 }
 
-__device__ __forceinline__ double wave_sum64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-struct SpRowsOfL {               // L by rows (strictly lower part), for the forward sweep
-    const uint32_t* rptr;        // [nv+1]
-    const uint32_t* ridx;        // index of the entry in L's value array
-    const uint32_t* rcol;        // its column
-};
-
-// K4b: L y = b by row gathers: y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj. A row only reads columns
-// below it in the elimination tree, so the factor's schedule applies unchanged. y overwrites b.
-__global__ __launch_bounds__(64) void sp_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl, const double* __restrict__ l,
-                                                        double* __restrict__ b) {
-    const int lane = threadIdx.x;
-    for (uint32_t q = cl.ptr[blockIdx.x]; q < cl.ptr[blockIdx.x + 1]; ++q) {
-        const uint32_t j = cl.cols[q];
-        double part = 0.0;
-        for (uint32_t p = lr.rptr[j] + lane; p < lr.rptr[j + 1]; p += 64) part = fma(l[lr.ridx[p]], ld_l2(b + lr.rcol[p]), part);
-        part = wave_sum64(part);
-        if (lane == 0) b[j] = (ld_l2(b + j) - part) / l[c.lcolptr[j]];
-        __syncthreads();  // waits for the store: the next row of this list may read it
-    }
-}
-
 // K4c: Lt x = y by column gathers, lists walked backwards: x_j = (y_j - sum_{i>j} L_ij x_i) / L_jj
-// reads only ancestors of j — the top list runs first, then the subtrees. x overwrites y.
+// reads only ancestors of j — the levels run from the top down. x overwrites y.
 __global__ __launch_bounds__(64) void sp_backward_kernel(SpChol c, ColLists cl, const double* __restrict__ l,
                                                          double* __restrict__ b) {
     const int lane = threadIdx.x;
-    for (uint32_t q = cl.ptr[blockIdx.x + 1]; q-- > cl.ptr[blockIdx.x];) {
+    const uint32_t list = cl.first + blockIdx.x;
+    for (uint32_t q = cl.ptr[list + 1]; q-- > cl.ptr[list];) {
         const uint32_t j = cl.cols[q];
         const uint32_t beg = c.lcolptr[j], end = c.lcolptr[j + 1];
         double part = 0.0;
@@ -578,8 +577,8 @@ struct ComponentPlan {
     std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs;
     std::vector<int32_t> l2a;
     std::vector<uint32_t> rptr, ridx, rcol;            // strictly lower part of L by rows
-    std::vector<uint32_t> dom_ptr, dom_cols;           // independent subtrees of the elimination tree
-    std::vector<uint32_t> top_ptr, top_cols;           // the columns above them (one list)
+    std::vector<uint32_t> list_ptr, list_cols;         // work lists of the elimination-tree schedule
+    std::vector<uint32_t> level_ptr;                   // lists of level v: [level_ptr[v], level_ptr[v+1])
 };
 
 // Builds every index structure of one component. `colof[v]` = free column of system variable v
@@ -760,60 +759,110 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
     }
 
     // --- schedule: a column depends only on its descendants in the elimination tree (parent = first
-    // sub-diagonal row). Subtrees whose work fits under a cap become independent lists, one wavefront
-    // each; everything above them is the sequential top list. The cap minimising (largest subtree +
-    // top) — the length of the critical path of this two-phase schedule — is picked from a geometric
-    // ladder.
+    // sub-diagonal row). Subtrees whose work fits under a cap become level-0 lists, one wavefront each.
+    // The columns above them are cut into chains (a column joins the chain of its only child above the
+    // cap; a column where several such chains meet starts a new one), and a chain's level is one more
+    // than the deepest list feeding it. Levels run as consecutive launches, lists of a level in
+    // parallel. The cap minimising the critical path (largest subtree + per level the longest chain +
+    // a launch overhead per level) is picked from a geometric ladder.
     std::vector<uint64_t> work(P.nv, 0), subtree(P.nv, 0);
     uint64_t total = 0;
     for (uint32_t j = 0; j < P.nv; ++j) {
-        uint64_t w = 4;  // per-column latency floor
+        uint64_t w = 8;  // per-column latency floor
         for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) w += 1 + (P.lpair_ptr[k + 1] - P.lpair_ptr[k]);
         work[j] = w;
         total += w;
     }
-    auto parent_of = [&](uint32_t j) { return lcol[j].size() > 1 ? lcol[j][1] : 0xFFFFFFFFu; };
+    constexpr uint32_t NOPARENT = 0xFFFFFFFFu;
+    constexpr uint64_t LAUNCH_COST = 24;  // in the same units: about three columns
+    std::vector<uint32_t> parent(P.nv, NOPARENT);
+    for (uint32_t j = 0; j < P.nv; ++j)
+        if (lcol[j].size() > 1) parent[j] = lcol[j][1];
     for (uint32_t j = 0; j < P.nv; ++j) subtree[j] = work[j];
-    for (uint32_t j = 0; j < P.nv; ++j) {
-        uint32_t pa = parent_of(j);
-        if (pa != 0xFFFFFFFFu) subtree[pa] += subtree[j];  // children come before parents
-    }
-    uint64_t best_cap = total, best_cost = total;
-    for (uint64_t cap = total; cap >= 64; cap = cap * 3 / 4) {
-        uint64_t top = 0, biggest = 0;
-        for (uint32_t j = 0; j < P.nv; ++j) {
-            if (subtree[j] > cap) top += work[j];
-            else {
-                uint32_t pa = parent_of(j);
-                if (pa == 0xFFFFFFFFu || subtree[pa] > cap) biggest = std::max(biggest, subtree[j]);
+    for (uint32_t j = 0; j < P.nv; ++j)
+        if (parent[j] != NOPARENT) subtree[parent[j]] += subtree[j];  // children come before parents
+
+    std::vector<uint32_t> list_of(P.nv), list_level, upper_children(P.nv), feeder(P.nv), below(P.nv);
+    std::vector<uint64_t> list_work;
+    // builds the lists for a cap; returns the critical-path estimate
+    auto build = [&](uint64_t cap) -> uint64_t {
+        list_level.clear();
+        list_work.clear();
+        std::fill(upper_children.begin(), upper_children.end(), 0u);
+        std::fill(below.begin(), below.end(), 0u);  // deepest level among the lists feeding column j, plus one
+        for (uint32_t j = 0; j < P.nv; ++j)
+            if (subtree[j] > cap && parent[j] != NOPARENT) {
+                upper_children[parent[j]]++;
+                feeder[parent[j]] = j;
+            }
+        // level-0 lists: subtrees under the cap, numbered from their roots downwards
+        for (uint32_t j = P.nv; j-- > 0;) {
+            if (subtree[j] > cap) continue;
+            uint32_t pa = parent[j];
+            if (pa == NOPARENT || subtree[pa] > cap) {
+                list_of[j] = (uint32_t)list_level.size();
+                list_level.push_back(0);
+                list_work.push_back(subtree[j]);
+                if (pa != NOPARENT) below[pa] = std::max(below[pa], 1u);
+            } else {
+                list_of[j] = list_of[pa];
             }
         }
-        if (top + biggest < best_cost) {
-            best_cost = top + biggest;
+        // chains above the cap, bottom-up (children have smaller numbers)
+        for (uint32_t j = 0; j < P.nv; ++j) {
+            if (subtree[j] <= cap) continue;
+            uint32_t q;
+            if (upper_children[j] == 1) {
+                // extends its only upper child's chain (its other children are level-0 subtrees, and a
+                // chain is never below level 1)
+                q = list_of[feeder[j]];
+                list_work[q] += work[j];
+            } else {
+                uint32_t lvl = below[j];
+                q = (uint32_t)list_level.size();
+                list_level.push_back(lvl ? lvl : 1u);
+                list_work.push_back(work[j]);
+            }
+            list_of[j] = q;
+            if (parent[j] != NOPARENT) below[parent[j]] = std::max(below[parent[j]], list_level[q] + 1);
+        }
+        uint32_t nlevels = 0;
+        for (uint32_t v : list_level) nlevels = std::max(nlevels, v + 1);
+        std::vector<uint64_t> longest(nlevels, 0);
+        for (size_t q = 0; q < list_level.size(); ++q) longest[list_level[q]] = std::max(longest[list_level[q]], list_work[q]);
+        uint64_t cost = 0;
+        for (uint64_t w : longest) cost += w + LAUNCH_COST;
+        return cost;
+    };
+    uint64_t best_cap = total, best_cost = ~0ull;
+    for (uint64_t cap = total; cap >= 32; cap = cap * 3 / 4) {
+        uint64_t cost = build(cap);
+        if (cost < best_cost) {
+            best_cost = cost;
             best_cap = cap;
         }
     }
-    std::vector<uint32_t> dom(P.nv, 0xFFFFFFFFu);
-    uint32_t ndom = 0;
-    for (uint32_t j = P.nv; j-- > 0;) {
-        if (subtree[j] > best_cap) continue;  // top
-        uint32_t pa = parent_of(j);
-        dom[j] = (pa == 0xFFFFFFFFu || subtree[pa] > best_cap) ? ndom++ : dom[pa];
-    }
-    P.dom_ptr.assign((size_t)ndom + 1, 0);
-    for (uint32_t j = 0; j < P.nv; ++j)
-        if (dom[j] != 0xFFFFFFFFu) P.dom_ptr[dom[j] + 1]++;
-    for (uint32_t d = 0; d < ndom; ++d) P.dom_ptr[d + 1] += P.dom_ptr[d];
-    P.dom_cols.assign(P.dom_ptr[ndom], 0);
+    build(best_cap);
+    // lists sorted by level (stable), columns ascending within a list
+    const uint32_t nlists = (uint32_t)list_level.size();
+    uint32_t nlevels = 0;
+    for (uint32_t v : list_level) nlevels = std::max(nlevels, v + 1);
+    P.level_ptr.assign((size_t)nlevels + 1, 0);
+    for (uint32_t v : list_level) P.level_ptr[v + 1]++;
+    for (uint32_t v = 0; v < nlevels; ++v) P.level_ptr[v + 1] += P.level_ptr[v];
+    std::vector<uint32_t> new_id(nlists);
     {
-        std::vector<uint32_t> fill(P.dom_ptr.begin(), P.dom_ptr.end() - 1);
-        for (uint32_t j = 0; j < P.nv; ++j)
-            if (dom[j] != 0xFFFFFFFFu) P.dom_cols[fill[dom[j]]++] = j;  // ascending within a list
+        std::vector<uint32_t> fill(P.level_ptr.begin(), P.level_ptr.end() - 1);
+        for (uint32_t q = 0; q < nlists; ++q) new_id[q] = fill[list_level[q]]++;
     }
-    P.top_cols.clear();
-    for (uint32_t j = 0; j < P.nv; ++j)
-        if (dom[j] == 0xFFFFFFFFu) P.top_cols.push_back(j);
-    P.top_ptr = {0u, (uint32_t)P.top_cols.size()};
+    P.list_ptr.assign((size_t)nlists + 1, 0);
+    for (uint32_t j = 0; j < P.nv; ++j) P.list_ptr[new_id[list_of[j]] + 1]++;
+    for (uint32_t q = 0; q < nlists; ++q) P.list_ptr[q + 1] += P.list_ptr[q];
+    P.list_cols.assign(P.nv, 0);
+    {
+        std::vector<uint32_t> fill(P.list_ptr.begin(), P.list_ptr.end() - 1);
+        for (uint32_t j = 0; j < P.nv; ++j) P.list_cols[fill[new_id[list_of[j]]]++] = j;
+    }
 }
 
 inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block ? (n + block - 1) / block : 1); }
@@ -955,13 +1004,11 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         lrows.rptr = pool.up(P.rptr);
         lrows.ridx = pool.up(P.ridx);
         lrows.rcol = pool.up(P.rcol);
-        ColLists doms, top;
-        doms.ptr = pool.up(P.dom_ptr);
-        doms.cols = pool.up(P.dom_cols);
-        top.ptr = pool.up(P.top_ptr);
-        top.cols = pool.up(P.top_cols);
-        const uint32_t ndom = (uint32_t)P.dom_ptr.size() - 1;
-        const bool has_top = !P.top_cols.empty();
+        ColLists lists;
+        lists.ptr = pool.up(P.list_ptr);
+        lists.cols = pool.up(P.list_cols);
+        lists.first = 0;
+        const uint32_t nlevels = (uint32_t)P.level_ptr.size() - 1;
         double* d_r[2] = {pool.alloc<double>(m), pool.alloc<double>(m)};
         double* d_j[2] = {pool.alloc<double>(P.nnz_j), pool.alloc<double>(P.nnz_j)};
         double* d_a = pool.alloc<double>(P.nnz_a);
@@ -1016,16 +1063,20 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 // factor, solve, trial point, trial residuals (+ Jacobian: it becomes J on acceptance)
                 e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream);
                 if (e != hipSuccess) return e;
-                if (ndom) hipLaunchKernelGGL(sp_factor_kernel, dim3(ndom), dim3(64), 0, stream, chol, doms, d_a, lambda, d_l, d_flag);
-                if (has_top) hipLaunchKernelGGL(sp_factor_kernel, dim3(1), dim3(64), 0, stream, chol, top, d_a, lambda, d_l, d_flag);
                 e = hipMemcpyAsync(d_delta, d_rhs, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
                 if (e != hipSuccess) return e;
-                if (ndom) hipLaunchKernelGGL(sp_forward_kernel, dim3(ndom), dim3(64), 0, stream, chol, lrows, doms, d_l, d_delta);
-                if (has_top) {
-                    hipLaunchKernelGGL(sp_forward_kernel, dim3(1), dim3(64), 0, stream, chol, lrows, top, d_l, d_delta);
-                    hipLaunchKernelGGL(sp_backward_kernel, dim3(1), dim3(64), 0, stream, chol, top, d_l, d_delta);
+                for (uint32_t v = 0; v < nlevels; ++v) {
+                    ColLists cl = lists;
+                    cl.first = P.level_ptr[v];
+                    hipLaunchKernelGGL(sp_factor_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream,
+                                       chol, lrows, cl, d_a, lambda, d_l, d_delta, d_flag);
                 }
-                if (ndom) hipLaunchKernelGGL(sp_backward_kernel, dim3(ndom), dim3(64), 0, stream, chol, doms, d_l, d_delta);
+                for (uint32_t v = nlevels; v-- > 0;) {
+                    ColLists cl = lists;
+                    cl.first = P.level_ptr[v];
+                    hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl,
+                                       d_l, d_delta);
+                }
                 hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_delta, nv, d_scal + 3);
                 if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);
                 if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[trial], d_r[trial], d_j[trial]);
