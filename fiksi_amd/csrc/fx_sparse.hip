@@ -18,7 +18,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <queue>
@@ -875,6 +878,7 @@ inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block 
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
                                double* d_vars_out /* device, n_vars of the System */, fx_result* result) {
     const bool single_pass = (prm.mode & MODE_UNITS) != 0;
+    const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;  // diagnostics on stderr
     const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
     const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
     const fx_lm_opts o = prm.lm;
@@ -977,8 +981,10 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         Pool pool;  // device memory of this block only
         pool.stream = stream;
         ComponentPlan P;
+        const auto t_plan0 = std::chrono::steady_clock::now();
         plan_component(b, s, std::vector<uint32_t>(units.rows.begin() + units.row_off[u], units.rows.begin() + units.row_off[u + 1]),
                        std::vector<uint32_t>(units.vars.begin() + units.var_off[u], units.vars.begin() + units.var_off[u + 1]), P);
+        const auto t_plan1 = std::chrono::steady_clock::now();
         const uint32_t m = P.m, nv = P.nv;
 
         uint32_t* d_fvar = pool.up(P.fvar);
@@ -1143,6 +1149,14 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         }
         e = hipStreamSynchronize(stream);  // the block's device memory is released when `pool` goes out of scope
         if (e != hipSuccess) return e;
+        if (trace) {
+            const auto t_end = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+            fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u, %zu lists in %zu levels; plan %.2f ms, "
+                            "upload+LM %.2f ms (%u trials)\n",
+                    m, nv, P.nnz_j, P.nnz_a, P.nnz_l, P.list_ptr.size() - 1, P.level_ptr.size() - 1, ms(t_plan0, t_plan1),
+                    ms(t_plan1, t_end), trials);
+        }
         res.accepted += accepted;
         res.trials += trials;
         res.exit = exit_code;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
+#   tools/collect_profiles.sh <tag>        e.g. round1
+# Kernel timing and the PMC counters are separate runs (never --pmc together with other trace domains).
+set -e
+TAG=${1:-round1}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_write.log 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json 100000 > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg2 -- python3 tools/cfg2.py 5000 > $OUT/cfg2.log 2>&1
+cp $(find $OUT/cfg2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg2_kernel_stats.csv
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+tail -c 600 $OUT/${TAG}_bench.json
