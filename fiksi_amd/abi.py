@@ -65,10 +65,12 @@ def lm_opts(f32: bool = False, **kw) -> FxLmOpts:
     return o
 
 
-def solving_opts(perturb: bool = True, f32: bool = False, decomposer: int = 0, **lm_kw) -> FxSolvingOpts:
+def solving_opts(perturb: bool = True, f32: bool = False, decomposer: int = 0, optimizer: int = 0, **lm_kw) -> FxSolvingOpts:
+    """fx_solving_opts: decomposer 0 = None, 1 = SinglePass; optimizer 0 = LevenbergMarquardt, 1 = LBfgs."""
     o = FxSolvingOpts()
     lib.fx_solving_opts_default(C.byref(o))
     o.decomposer = decomposer
+    o.optimizer = optimizer
     if f32:
         lib.fx_lm_opts_default_f32(C.byref(o.lm))
     o.perturb = 1 if perturb else 0

@@ -651,11 +651,16 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
     fx_solving_opts o;
     if (opts) o = *opts; else fx_solving_opts_default(&o);
-    if (o.optimizer != 0) return fail(FX_ERR_UNSUPPORTED, "only Optimizer::LevenbergMarquardt runs on the device");
+    if (o.optimizer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown optimizer %u (0 = LevenbergMarquardt, 1 = LBfgs)", o.optimizer);
+    if (o.optimizer == 1 && o.lm.precision == 32)
+        return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs runs in f64 only");
+    if (o.optimizer == 1 && db->n_large)
+        return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs is implemented for Systems within the one-wavefront limits only "
+                                        "(%u System(s) of this batch exceed them)", db->n_large);
     if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
     fx::LmParams p;
     p.lm = o.lm;
-    p.mode = 1u | (o.perturb ? 2u : 0u);
+    p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u);
     if (o.decomposer == 1) {
         rc = ensure_units(ctx, db);
         if (rc) return rc;

@@ -31,6 +31,7 @@ struct UnitDesc {
 constexpr uint16_t UNIT_FIRST = 1;  // first block of its component: the component is perturbed before it
 constexpr uint16_t UNIT_EMPTY = 2;  // placeholder of a component without any block
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
+constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
@@ -77,7 +78,7 @@ struct DeviceBatch {
 
 struct LmParams {
     fx_lm_opts lm;
-    uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation, bit2: MODE_UNITS
+    uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation, bit2: MODE_UNITS, bit3: MODE_LBFGS
     unsigned long long* prof = nullptr;  // diagnostic build only: 6 per-phase cycle sums
 };
 

@@ -16,6 +16,7 @@
 
 #include "fx_device.h"
 #include "fx_expr.h"
+#include "fx_lbfgs.h"
 
 namespace fx {
 
@@ -102,7 +103,8 @@ struct SolveLayout {
     uint32_t total;
 };
 
-static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows, uint32_t es /* sizeof(T) */) {
+static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows, uint32_t es /* sizeof(T) */,
+                               bool lbfgs = false) {
     SolveLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -111,7 +113,9 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     uint32_t o = 0;
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
     L.off_xs = take(2u * L.vt * es);
-    L.off_a = take(n_pad * (n_pad + 16u / es) * es);
+    // LM: the N x LD normal matrix. L-BFGS: 5 + 5 history vectors, a dot-product scratch vector, rho[5]
+    // (padded to 16 doubles) and one "overwritten entry" byte mask per row.
+    L.off_a = take(lbfgs ? (11u * n_pad + 16u) * 8u + L.mr : n_pad * (n_pad + 16u / es) * es);
     L.off_rhs = take(n_pad * es);
     L.off_g = take(2u * L.mr * 8u * es);
     L.off_r = take(2u * L.mr * es);
@@ -199,7 +203,13 @@ enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4
 // host decomposition produced (fx_decompose.h) instead of over whole components, the component's
 // perturbation happens before its first block, and a solved block is written through to the working
 // vectors so later blocks see it.
-template <int N, typename T, bool PROF, bool UNITS>
+//
+// OPT = 1 is `Optimizer::LBfgs` (fiksi/src/solve/lbfgs.rs) in place of the LM loop: same scaling,
+// perturbation, row lists and write-back; the optimizer keeps one variable per lane, the 5 + 5
+// history vectors in LDS, and sums every dot product in index order (the reference's order) by
+// reading the lane products back from LDS. The line search is the fx::HzMachine state machine
+// around the single evaluation site.
+template <int N, typename T, bool PROF, bool UNITS, int OPT = 0>
 __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -478,7 +488,169 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         const T xstart = ((uint32_t)lane < nfree) ? XS[fidx[lane]] : T(0);  // perturbed start of this lane's variable
         stamp(PH_SETUP);
         T sse = eval_rows(0);
-        const T sse_start = sse;
+        T sse_start = sse;
+        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
+        if constexpr (OPT == 1) {
+        // ================= Optimizer::LBfgs (lbfgs.rs:20-193) =================
+        double* SH = reinterpret_cast<double*>(Amat);  // [5][N] s_k ring
+        double* YH = SH + 5 * N;                        // [5][N] y_k ring
+        double* DOT = YH + 5 * N;                       // [N] lane products of the dot product in flight
+        double* RHO = DOT + N;                          // [5] (+ padding)
+        uint8_t* rdead = reinterpret_cast<uint8_t*>(RHO + 16);  // [mr] bit e: entry e is overwritten by a later one
+        double* GR = reinterpret_cast<double*>(rhsv);   // [N] gradient accumulator
+        for (uint32_t i = lane; i < (uint32_t)(11 * N + 16); i += 64) SH[i] = 0.0;
+        for (uint32_t row = lane; row < m_rows; row += 64) {
+            // dense Jacobian scatter (expressions.rs:993-1008): a later entry of the same column wins
+            uint32_t dead = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int e2 = e + 1; e2 < 8; ++e2)
+                    if (gcol[row * 8 + e] >= 0 && gcol[row * 8 + e] == gcol[row * 8 + e2]) dead |= 1u << e;
+            }
+            rdead[row] = (uint8_t)dead;
+        }
+        __syncthreads();
+        // sum_k u_k w_k in index order (lbfgs.rs:213-216 and the explicit loops of :86-133)
+        auto seq_dot = [&](double u, double w) -> double {
+            if (lane < N) DOT[lane] = u * w;
+            __syncthreads();
+            double acc = 0.0;
+            for (uint32_t j = 0; j < nfree; ++j) acc += DOT[j];
+            __syncthreads();
+            return bcast(acc, 0);  // every lane holds the same sum: tell the compiler it is wave-uniform
+        };
+        // sum of squared residuals in row order (utils.rs:11-19)
+        auto seq_sse = [&](int buf) -> double {
+            double acc = 0.0;
+            for (uint32_t row = 0; row < m_rows; ++row) {
+                double r = (double)R[buf * mr + row];
+                acc += r * r;
+            }
+            return bcast(acc, 0);
+        };
+        // gradient J^T r, rows added in order (lbfgs.rs:199-210); zero entries of the dense J add nothing
+        auto form_gradient = [&](int buf) -> double {
+            if (lane < N) GR[lane] = 0.0;
+            __syncthreads();
+            const int e = lane & 7;
+            constexpr int RB = 4;
+            for (uint32_t row0 = 0; row0 < m_rows; row0 += RB) {
+                int col[RB];
+                double val[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    uint32_t row = min(row0 + q, m_rows - 1);
+                    col[q] = gcol[row * 8 + e];
+                    bool dead = (rdead[row] >> e) & 1;
+                    val[q] = (double)G[(buf * mr + row) * 8 + e] * (double)R[buf * mr + row];
+                    if (row0 + q >= m_rows || lane >= 8 || dead) col[q] = -1;
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q)
+                    if (col[q] >= 0) lds_add(&GR[col[q]], val[q]);  // one row per instruction: row order
+            }
+            __syncthreads();
+            double g = (lane < N) ? GR[lane] : 0.0;
+            __syncthreads();
+            return g;
+        };
+
+        trials = 1;
+        double prev = seq_sse(0);
+        sse = (T)prev;
+        sse_start = sse;
+        double x = ((uint32_t)lane < nfree) ? (double)XS[fidx[lane]] : 0.0;
+        if (!(prev == prev)) {
+            exit_code = FX_EXIT_NAN;
+        } else if (prev < LbfgsConst::START_THRESHOLD) {  // :54-56
+            exit_code = FX_EXIT_SSE;
+        } else {
+            double grad = form_gradient(0);
+            for (uint32_t k = 0; k < LbfgsConst::MAX_ITERATIONS; ++k) {
+                const uint32_t hl = k < 5u ? k : 5u;
+                // two-loop recursion (:86-139); note the ring index (k + i) % 5 of the reference
+                double dir = grad;
+                double alpha[5] = {0., 0., 0., 0., 0.};
+#pragma unroll
+                for (int i = 4; i >= 0; --i) {
+                    if ((uint32_t)i < hl) {
+                        const uint32_t h = (k + (uint32_t)i) % 5u;
+                        double dp = seq_dot((lane < N) ? SH[h * N + lane] : 0.0, dir);
+                        alpha[i] = RHO[h] * dp;
+                        dir -= alpha[i] * ((lane < N) ? YH[h * N + lane] : 0.0);
+                    }
+                }
+                if (k > 0) {
+                    const uint32_t h = (k - 1u) % 5u;
+                    double sv = (lane < N) ? SH[h * N + lane] : 0.0, yv = (lane < N) ? YH[h * N + lane] : 0.0;
+                    double s_dot_y = seq_dot(sv, yv);
+                    double y_dot_y = seq_dot(yv, yv);
+                    if (y_dot_y > 0.) dir *= s_dot_y / y_dot_y;
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    if ((uint32_t)i < hl) {
+                        const uint32_t h = (k + (uint32_t)i) % 5u;
+                        double dp = seq_dot((lane < N) ? YH[h * N + lane] : 0.0, dir);
+                        double beta = RHO[h] * dp;
+                        dir += ((lane < N) ? SH[h * N + lane] : 0.0) * (alpha[i] - beta);
+                    }
+                }
+                dir *= -1.;
+                if ((uint32_t)lane >= nfree) dir = 0.0;
+                const uint32_t h = k % 5u;
+                if (lane < N) YH[h * N + lane] = grad;  // the old gradient, turned into y_k below (:143-146)
+
+                // Hager-Zhang line search (:148-163) around the one evaluation site
+                HzMachine hz;
+                double step = hz.start(prev, seq_dot(grad, dir));
+                HzParam acc_pt{0., 0., 0.};
+                for (;;) {
+                    if ((uint32_t)lane < nfree) XS[vt + fidx[lane]] = (T)(x + step * dir);  // calculate_phi (:270-284)
+                    __syncthreads();
+                    eval_rows(1);
+                    trials += 1;
+                    double phi = seq_sse(1);
+                    grad = form_gradient(1);
+                    double dphi = seq_dot(grad, dir);
+                    if (hz.feed(HzParam{step, phi, dphi}, step, acc_pt)) break;
+                }
+                x = x + acc_pt.p * dir;  // == the scratch vector of the last evaluation (:166)
+                double sk = acc_pt.p * dir;
+                double yk = grad - ((lane < N) ? YH[h * N + lane] : 0.0);
+                if (lane < N) {
+                    SH[h * N + lane] = sk;
+                    YH[h * N + lane] = yk;
+                }
+                double s_dot_y = seq_dot(sk, yk);
+                if (lane == 0) RHO[h] = 1.0 / s_dot_y;
+                __syncthreads();
+                accepted += 1;
+                sse = (T)acc_pt.phi;
+                if (hz.capped) {
+                    exit_code = FX_EXIT_TRIAL_CAP;
+                    break;
+                }
+                if (!(acc_pt.phi == acc_pt.phi)) {
+                    exit_code = FX_EXIT_NAN;
+                    break;
+                }
+                if (::fabs(prev - acc_pt.phi) < LbfgsConst::CONVERGENCE_THRESHOLD) {  // :183-185
+                    exit_code = FX_EXIT_FTOL;
+                    break;
+                }
+                if (acc_pt.phi < LbfgsConst::RESIDUAL_THRESHOLD) {  // :186-188
+                    exit_code = FX_EXIT_SSE;
+                    break;
+                }
+                prev = acc_pt.phi;
+            }
+            if ((uint32_t)lane < nfree) XS[fidx[lane]] = (T)x;
+            __syncthreads();
+        }
+        } else {
+        // ================= Optimizer::LevenbergMarquardt (lm.rs:21-193) =================
         stamp(PH_EVAL);
         form_normal(0);
         stamp(PH_FORM);
@@ -486,7 +658,6 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         T rhs_l = (lane < N) ? rhsv[lane] : T(0);
 
         double lambda = o.lambda0;
-        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
         bool done = false;
         if (!(sse == sse) || !(sse < Lim<T>::huge())) {
             exit_code = FX_EXIT_NAN;
@@ -585,6 +756,8 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 }
             }
         }
+
+        }  // optimizer
 
         // ---- K6: write back scale * x for the free variables (:161-166) ----------------------
         if ((uint32_t)lane < nfree) {
@@ -926,29 +1099,30 @@ hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_va
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-template <int N, typename T, bool PROF, bool UNITS>
+template <int N, typename T, bool PROF, bool UNITS, int OPT>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF, UNITS>),
+    if (L.total > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF, UNITS, OPT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF, UNITS>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF, UNITS, OPT>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
 }
 
-template <typename T, bool UNITS>
+template <typename T, bool UNITS, int OPT>
 static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     uint32_t n = pad_n(UNITS ? b.max_unit_free : b.max_free);
     const uint32_t rows = (UNITS && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
-    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T));
+    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1);
     switch (n) {
-        case 8: return launch_solve_n<8, T, false, UNITS>(b, p, L, stream);
-        case 16: return launch_solve_n<16, T, false, UNITS>(b, p, L, stream);
-        case 24: return launch_solve_n<24, T, false, UNITS>(b, p, L, stream);
-        case 32: return launch_solve_n<32, T, false, UNITS>(b, p, L, stream);
-        case 40: return launch_solve_n<40, T, false, UNITS>(b, p, L, stream);
-        case 48: return launch_solve_n<48, T, false, UNITS>(b, p, L, stream);
-        case 56: return launch_solve_n<56, T, false, UNITS>(b, p, L, stream);
-        case 64: return launch_solve_n<64, T, false, UNITS>(b, p, L, stream);
+        case 8: return launch_solve_n<8, T, false, UNITS, OPT>(b, p, L, stream);
+        case 16: return launch_solve_n<16, T, false, UNITS, OPT>(b, p, L, stream);
+        case 24: return launch_solve_n<24, T, false, UNITS, OPT>(b, p, L, stream);
+        case 32: return launch_solve_n<32, T, false, UNITS, OPT>(b, p, L, stream);
+        case 40: return launch_solve_n<40, T, false, UNITS, OPT>(b, p, L, stream);
+        case 48: return launch_solve_n<48, T, false, UNITS, OPT>(b, p, L, stream);
+        case 56: return launch_solve_n<56, T, false, UNITS, OPT>(b, p, L, stream);
+        case 64: return launch_solve_n<64, T, false, UNITS, OPT>(b, p, L, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -957,15 +1131,18 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
     if (b.n_systems == 0) return hipSuccess;
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);
-        if (n != 32 || p.lm.precision == 32 || (p.mode & MODE_UNITS)) return hipErrorInvalidValue;
+        if (n != 32 || p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS))) return hipErrorInvalidValue;
         SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u);
-        return launch_solve_n<32, double, true, false>(b, p, L, stream);
+        return launch_solve_n<32, double, true, false, 0>(b, p, L, stream);
     }
-    if (p.mode & MODE_UNITS) {
-        if (!b.sys_unit_off) return hipErrorInvalidValue;
-        return p.lm.precision == 32 ? launch_solve_t<float, true>(b, p, stream) : launch_solve_t<double, true>(b, p, stream);
+    const bool units = (p.mode & MODE_UNITS) != 0;
+    if (units && !b.sys_unit_off) return hipErrorInvalidValue;
+    if (p.mode & MODE_LBFGS) {  // f64 only (checked at the ABI)
+        if (p.lm.precision == 32) return hipErrorInvalidValue;
+        return units ? launch_solve_t<double, true, 1>(b, p, stream) : launch_solve_t<double, false, 1>(b, p, stream);
     }
-    return p.lm.precision == 32 ? launch_solve_t<float, false>(b, p, stream) : launch_solve_t<double, false>(b, p, stream);
+    if (units) return p.lm.precision == 32 ? launch_solve_t<float, true, 0>(b, p, stream) : launch_solve_t<double, true, 0>(b, p, stream);
+    return p.lm.precision == 32 ? launch_solve_t<float, false, 0>(b, p, stream) : launch_solve_t<double, false, 0>(b, p, stream);
 }
 
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream) {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "fo_expressions.hpp"
+#include "fo_lbfgs.hpp"
 #include "fo_lm.hpp"
 #include "fo_rand.hpp"
 
@@ -54,8 +55,24 @@ struct SolveStats {
 };
 
 // assemble/mod.rs:46-167 (None arm). Mutates `s.variables` like `System::solve`.
+// `optimizer`: 0 = LevenbergMarquardt, 1 = LBfgs (solve/mod.rs:17-27; dispatch assemble/mod.rs:148-158).
+inline LmStats run_optimizer(int optimizer, const Subsystem& subsystem, double* free_values, QrOrdering ordering,
+                             uint32_t trial_cap) {
+    if (optimizer == 1) {
+        LbfgsStats b = lbfgs(subsystem, free_values);
+        LmStats st;
+        st.accepted = b.iterations;
+        st.trials = b.evaluations;
+        st.exit = b.exit;
+        st.sse_initial = b.sse_initial;
+        st.sse_final = b.sse_final;
+        return st;
+    }
+    return levenberg_marquardt(subsystem, free_values, ordering, trial_cap);
+}
+
 inline SolveStats solve(FlatSystem& s, bool perturb, QrOrdering ordering = QrOrdering::Colamd,
-                        uint32_t trial_cap = 0) {
+                        uint32_t trial_cap = 0, int optimizer = 0) {
     SolveStats out;
     Rng rng = Rng::from_seed(42);  // :47
 
@@ -97,7 +114,7 @@ inline SolveStats solve(FlatSystem& s, bool perturb, QrOrdering ordering = QrOrd
         subsystem.free_index.assign(s.variables.size(), -1);
         for (size_t k = 0; k < free_variables.size(); ++k) subsystem.free_index[free_variables[k]] = static_cast<int32_t>(k);
 
-        LmStats st = levenberg_marquardt(subsystem, free_values.data(), ordering, trial_cap);
+        LmStats st = run_optimizer(optimizer, subsystem, free_values.data(), ordering, trial_cap);
         out.components.push_back(st);
 
         // :161-166 — only `system.variables` is written back (quirk Q2).

@@ -278,7 +278,7 @@ int fo_solve_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* 
         FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, expr_comp);
         fo_result res{};
         if (mode & 1u) {
-            SolveStats st = solve(sys, (mode & 2u) != 0, ord, trial_cap);
+            SolveStats st = solve(sys, (mode & 2u) != 0, ord, trial_cap, (mode & 4u) ? 1 : 0);  // bit 2: Optimizer::LBfgs
             res.scale = st.scale;
             for (const LmStats& c : st.components) {
                 res.accepted += c.accepted;
@@ -333,7 +333,7 @@ int fo_solve_single_pass_batch(uint32_t n_systems, const uint32_t* var_off, cons
     QrOrdering ord = ordering ? QrOrdering::Colamd : QrOrdering::Natural;
     parallel_for(n_systems, nthreads, [&](uint32_t s) {
         FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, expr_comp);
-        SolveStats st = solve_single_pass(sys, perturb != 0, ord, trial_cap);
+        SolveStats st = solve_single_pass(sys, (perturb & 1u) != 0, ord, trial_cap, (perturb & 4u) ? 1 : 0);  // bit 2: LBfgs
         fo_result res{};
         res.scale = st.scale;
         for (const LmStats& c : st.components) {

@@ -191,7 +191,7 @@ inline std::vector<StronglyConnectedExpressions> find_strongly_connected_express
             if (mt.a_to_b[a] == UNMATCHED) dfs(m, mt, distance, dummy, a);
         }
     }
-    Tarjan t{m, mt};
+    Tarjan t{m, mt, 1, 0, {}, {}, {}};
     t.root_index.assign(g.expressions.size(), 0);
     // `c` starts at len_vertices - 1; every root_index value stored is either a visit index
     // (>= 1, < len + 1) or a component number counted down from there. To keep "0 = unvisited"
@@ -220,7 +220,7 @@ inline std::vector<StronglyConnectedExpressions> find_strongly_connected_express
 
 // assemble/mod.rs:46-124 + the SinglePass arm :169-210.
 inline SolveStats solve_single_pass(FlatSystem& s, bool perturb, QrOrdering ordering = QrOrdering::Colamd,
-                                    uint32_t trial_cap = 0) {
+                                    uint32_t trial_cap = 0, int optimizer = 0) {
     SolveStats out;
     Rng rng = Rng::from_seed(42);
     double system_scale = calculate_system_scale(s);
@@ -257,7 +257,7 @@ inline SolveStats solve_single_pass(FlatSystem& s, bool perturb, QrOrdering orde
             subsystem.free_variables = scc.free_variables;
             subsystem.free_index.assign(s.variables.size(), -1);
             for (size_t k = 0; k < scc.free_variables.size(); ++k) subsystem.free_index[scc.free_variables[k]] = static_cast<int32_t>(k);
-            LmStats st = levenberg_marquardt(subsystem, free_values.data(), ordering, trial_cap);
+            LmStats st = run_optimizer(optimizer, subsystem, free_values.data(), ordering, trial_cap);
             total.accepted += st.accepted;
             total.trials += st.trials;
             total.exit = st.exit;

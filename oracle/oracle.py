@@ -176,7 +176,7 @@ def eval_batch(b):
 
 
 def solve_batch(b, mode: int = 3, ordering: str = "colamd", trial_cap: int = 0, nthreads: int = 1):
-    """assemble::solve (mode 3 = scale+perturb, the reference default) or the bare LM (mode 0).
+    """assemble::solve (mode 3 = scale+perturb, the reference default; +4 = Optimizer::LBfgs) or the bare LM (mode 0).
 
     Returns (solved variables, per-system results); the input batch is not modified.
     """
@@ -224,13 +224,15 @@ def analyze_batch(b):
     return dep
 
 
-def solve_single_pass_batch(b, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, nthreads: int = 1):
+def solve_single_pass_batch(b, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, nthreads: int = 1,
+                            lbfgs: bool = False):
     """assemble::solve with Decomposer::SinglePass. Returns (solved variables, per-system results)."""
     n, args = _batch_args(b)
     vars_out = b["vars"].copy()
     args[3] = _p(vars_out)
     res = np.zeros(n, dtype=RESULT_DTYPE)
-    lib().fo_solve_single_pass_batch(*args, _p(b.get("var_comp")), _p(b.get("expr_comp")), C.c_uint32(1 if perturb else 0),
+    lib().fo_solve_single_pass_batch(*args, _p(b.get("var_comp")), _p(b.get("expr_comp")),
+                                     C.c_uint32((1 if perturb else 0) | (4 if lbfgs else 0)),
                                      C.c_int(1 if ordering == "colamd" else 0), C.c_uint32(trial_cap),
                                      C.c_uint32(nthreads), _p(res))
     return vars_out, res

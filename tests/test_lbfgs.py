@@ -1,0 +1,161 @@
+"""Optimizer::LBfgs (fiksi/src/solve/lbfgs.rs): the product's line-search state machine against the
+oracle's line-by-line restatement (CPU), and the device solve against the oracle (GPU).
+
+No test of the reference selects this optimizer, so the oracle is parity-unpinned here (see
+oracle/fo_lbfgs.hpp); what these tests hold is product == oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import mixed_sketch, random_sketch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory, oracle):
+    so = str(tmp_path_factory.mktemp("hz") / "libhz_harness.so")
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wall",
+           os.path.join(ROOT, "tests", "cpp", "hz_harness.cpp"), "-o", so]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return C.CDLL(so)
+
+
+def _run(harness, b, which):
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    n = len(b["var_off"]) - 1
+    v = b["vars"].copy()
+    it, ev, ex = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+    harness.hz_lbfgs_batch(C.c_uint32(n), p(b["var_off"]), p(b["expr_off"]), p(v), p(b["var_fixed"]), p(b["expr_tag"]),
+                           p(b["expr_idx"]), p(b["expr_param"]), p(b.get("var_comp")), p(b.get("expr_comp")),
+                           C.c_int(which), p(it), p(ev), p(ex))
+    return v, it, ev, ex
+
+
+def test_line_search_machine_takes_the_reference_decisions(harness, fiksi):
+    """Same trial points in the same order: identical evaluation counts and bit-identical results,
+    including the searches that run into the U3 cap (angle wrap-arounds make phi discontinuous)."""
+    from fiksi_amd import workloads
+
+    flats = [workloads.ring16(60), workloads.ring16(30, inconsistent=True), workloads.hinged_triangles(4, 11),
+             workloads.quadrilateral(), workloads.quadrilateral(consistent=False)]
+    flats += [mixed_sketch(s, fix_some=s % 2 == 0).flatten() for s in range(40)]
+    flats += [random_sketch(s).flatten() for s in range(150)]
+    b = workloads.concat(flats)
+    v0, it0, ev0, ex0 = _run(harness, b, 0)
+    v1, it1, ev1, ex1 = _run(harness, b, 1)
+    assert np.array_equal(it0, it1) and np.array_equal(ev0, ev1) and np.array_equal(ex0, ex1)
+    assert np.array_equal(v0, v1, equal_nan=True)
+    # the sample exercises every way out of the optimizer, the cap included
+    assert set(np.unique(ex0).tolist()) >= {0, 2, 4}
+    assert ev0.max() > 200 and it0.max() >= 20
+
+
+# ---- GPU: the device optimizer against the oracle ------------------------------------------------
+
+def _rms(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.sqrt(np.mean(x * x))) if len(x) else 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_lbfgs_distance_only_sketches_follow_the_oracle_exactly(fiksi, oracle, ctx):
+    """Without angle constraints every residual and partial is bit-identical to the oracle's, the dot
+    products are summed in the same order, and the line search takes the same decisions: identical
+    iteration and evaluation counts, positions equal to rounding of the final scale multiply."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.concat([workloads.hinged_triangles(64, 8), workloads.quadrilateral(), workloads.quadrilateral(consistent=False)])
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1))
+    v_o, res_o = oracle.solve_batch(b, mode=7, nthreads=8)
+    assert np.array_equal(res["scale"], res_o["scale"])
+    assert np.array_equal(res["accepted"], res_o["accepted"])   # L-BFGS iterations
+    assert np.array_equal(res["trials"], res_o["trials"])       # residual + Jacobian evaluations
+    assert np.array_equal(res["exit"], res_o["exit"])
+    assert np.array_equal(res["sse0"], res_o["sse0"]) and np.array_equal(res["sse"], res_o["sse"])
+    assert np.array_equal(v, v_o)
+
+
+@pytest.mark.gpu
+def test_gpu_lbfgs_ring16_batch(fiksi, oracle, ctx):
+    from fiksi_amd import abi, workloads
+
+    b = workloads.ring16(2000)
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1))
+    v_o, res_o = oracle.solve_batch(b, mode=7, nthreads=8)
+    assert np.array_equal(res["scale"], res_o["scale"]) and np.allclose(res["sse0"], res_o["sse0"], rtol=1e-12, atol=0)
+    # the angle rows' atan2 differs by an ulp between device and host libm; the line search amplifies
+    # that on some systems (a different trial count), never the verdict
+    same = (res["accepted"] == res_o["accepted"]) & (res["trials"] == res_o["trials"])
+    assert same.mean() > 0.9, same.mean()
+    assert np.allclose(res["sse"][same], res_o["sse"][same], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(v.reshape(-1, 32)[same] - v_o.reshape(-1, 32)[same])) < 1e-6
+    assert np.mean(res["exit"] == res_o["exit"]) > 0.97
+    # solved means solved: SSE < 1e-6 in scaled units (lbfgs.rs:186-188); this optimizer gives up on a
+    # good third of the ring sketches (stalls or loses the bracket at an angle wrap) — in the oracle too
+    ok, ok_o = res["exit"] == 0, res_o["exit"] == 0
+    assert abs(ok.mean() - ok_o.mean()) < 0.02 and ok.mean() > 0.5
+    assert np.all(res["sse"][ok] < 1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_lbfgs_mixed_and_random_sketches(fiksi, oracle, ctx):
+    from fiksi_amd import abi, workloads
+
+    flats = [mixed_sketch(100 + s, fix_some=s % 3 == 0).flatten() for s in range(48)]
+    flats += [random_sketch(s).flatten() for s in range(200)]
+    b = workloads.concat(flats)
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1))
+    v_o, res_o = oracle.solve_batch(b, mode=7, nthreads=8)
+    assert np.array_equal(res["ncomp"], res_o["ncomp"])
+    assert np.array_equal(res["scale"], res_o["scale"])
+    nan = np.isnan(res_o["sse"]) | np.isnan(res["sse"])
+    same = (res["accepted"] == res_o["accepted"]) & (res["trials"] == res_o["trials"]) & ~nan
+    # arbitrary sketches with angle rows: an ulp of atan2 moves a secant step, and from there the two
+    # runs count differently on about a third of them; where they count the same they agree closely
+    assert same.mean() > 0.6, same.mean()
+    d = np.abs(res["sse"][same] - res_o["sse"][same])
+    assert np.all(d <= 1e-9 + 0.25 * np.abs(res_o["sse"][same])), d.max()  # the LM tests' bar for such sketches
+    assert np.median(d / (1e-12 + np.abs(res_o["sse"][same]))) <= 1e-6
+    assert np.mean((res["exit"] == 0) == (res_o["exit"] == 0)) > 0.9
+    fx = b["var_fixed"] == 1
+    assert np.array_equal(v[fx], b["vars"][fx])
+
+
+@pytest.mark.gpu
+def test_gpu_lbfgs_with_single_pass(fiksi, oracle, ctx):
+    from fiksi_amd import abi, workloads
+
+    b = workloads.hinged_triangles(32, 10)
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1, decomposer=1))
+    v_o, res_o = oracle.solve_single_pass_batch(b, lbfgs=True, nthreads=8)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.array_equal(res["trials"], res_o["trials"])
+    assert np.array_equal(v, v_o)
+
+
+@pytest.mark.gpu
+def test_gpu_lbfgs_through_the_system_api_and_limits(fiksi, oracle, ctx):
+    F = fiksi
+    from fiksi_amd import abi, workloads
+    from fiksi_amd._lib import FiksiError
+
+    s = F.System()
+    p0 = F.elements.Point.create(s, 0., 0.)
+    p1 = F.elements.Point.create(s, 1., 0.5)
+    p2 = F.elements.Point.create(s, 1.5, 1.)  # (2, 1) would be collinear: L-BFGS stays on that saddle
+    for a, c in ((p0, p1), (p0, p2), (p1, p2)):
+        F.constraints.PointPointDistance.create(s, a, c, 1.)
+    before = s.flatten()
+    s.solve(F.SolvingOptions(optimizer=F.Optimizer.LBfgs))
+    v_o, res_o = oracle.solve_batch(before, mode=7)
+    assert np.array_equal(s.flatten()["vars"], v_o)
+    assert _rms([c.calculate_residual(s) for c in s.get_constraint_handles()]) < 1e-2  # SSE < 1e-6 scaled
+    # beyond the one-wavefront limits: reported, not silently solved by another method
+    with pytest.raises(FiksiError) as e:
+        ctx.system_solve_batch(workloads.large_sketch(100), abi.solving_opts(optimizer=1))
+    assert e.value.code == -6

@@ -166,8 +166,9 @@ def test_unimplemented_options_are_reported_unsupported(F):
     with pytest.raises(FiksiError) as e:
         s.solve(F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly))
     assert e.value.code == -6
-    with pytest.raises(FiksiError):
-        s.solve(F.SolvingOptions(optimizer=F.Optimizer.LBfgs))
+    with pytest.raises(FiksiError) as e:  # L-BFGS is f64 only
+        F.default_context().system_solve_batch(s.flatten(), F.abi.solving_opts(optimizer=1, f32=True))
+    assert e.value.code == -6
 
 
 def test_connected_triangles(F, oracle):  # triangles.rs:40-70
