@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fx_decompose.h"
@@ -54,18 +55,113 @@ struct HostPlan {
     std::vector<uint8_t> row_sysoff;
     std::vector<uint32_t> expr_sys;
     std::vector<fx::BlockInfo> blk_info;
+};
+
+// CSR structure of the Jacobian (fixed pattern): built on demand, from the compact arrays.
+struct CsrPlan {
     std::vector<uint32_t> jrow_ptr, jcol, jslot;
 };
 
-// Checks the batch and (optionally) builds the plan. Mirrors the data invariants the reference
-// enforces by construction (handles of the same System, indices < variables.len()).
-int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
+// Runs fn(t, begin, end) over [0, n) cut into contiguous ranges, on up to 16 host threads when the
+// work is worth it (the per-expression analysis is ~0.1 us; a thread costs ~50 us to start).
+template <typename F>
+void parallel_ranges(uint32_t n, uint64_t work_items, F&& fn, uint32_t* n_ranges_out = nullptr) {
+    uint32_t nt = std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (work_items < 200000) nt = 1;
+    nt = std::min<uint32_t>(nt, std::max(1u, n));
+    if (n_ranges_out) *n_ranges_out = nt;
+    if (nt == 1) {
+        fn(0u, 0u, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nt; ++t) {
+        uint32_t lo = (uint32_t)((uint64_t)n * t / nt), hi = (uint32_t)((uint64_t)n * (t + 1) / nt);
+        th.emplace_back([&fn, t, lo, hi] { fn(t, lo, hi); });
+    }
+    for (auto& x : th) x.join();
+}
+constexpr uint32_t MAX_RANGES = 16;
+
+// distinct free columns of a row (ascending) and the slot of each gradient entry; returns the count
+inline int row_columns(const uint32_t vars8[8], int k, const int32_t* free_rank, int32_t cols[8], uint32_t* slots_out) {
+    int ncols = 0;
+    for (int q = 0; q < k; ++q) {
+        int32_t col = free_rank[vars8[q]];
+        if (col < 0) continue;
+        bool seen = false;
+        for (int t = 0; t < ncols; ++t) seen = seen || cols[t] == col;
+        if (!seen) cols[ncols++] = col;
+    }
+    std::sort(cols, cols + ncols);
+    if (slots_out) {
+        uint32_t slots = 0;
+        for (int q = 0; q < 8; ++q) {
+            uint32_t sl = 0xFu;
+            if (q < k) {
+                int32_t col = free_rank[vars8[q]];
+                if (col >= 0) sl = (uint32_t)(std::find(cols, cols + ncols, col) - cols);
+            }
+            slots |= sl << (4 * q);
+        }
+        *slots_out = slots;
+    }
+    return ncols;
+}
+
+// CSR pattern from the compact per-variable / per-expression arrays (host copies of what the device
+// holds): columns = system-local rank among the free variables, ascending inside a row, duplicates
+// merged (sparse_col_mat.rs:690-737 after the row/column transposition).
+void build_csr(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, const uint16_t* var_info,
+               const uint8_t* expr_tag, const uint16_t* expr_idx16, CsrPlan& out) {
+    const uint32_t ne = n ? expr_off[n] : 0;
+    out.jrow_ptr.assign((size_t)ne + 1, 0);
+    out.jslot.assign(ne, 0xFFFFFFFFu);
+    std::vector<uint32_t> local_cols[MAX_RANGES];
+    uint32_t range_lo[MAX_RANGES + 1] = {0};
+    uint32_t nr = 1;
+    parallel_ranges(n, ne, [&](uint32_t t, uint32_t s_lo, uint32_t s_hi) {
+        range_lo[t] = s_lo;
+        std::vector<int32_t> free_rank;
+        auto& lc = local_cols[t];
+        lc.reserve((size_t)(expr_off[s_hi] - expr_off[s_lo]) * 5);
+        for (uint32_t s = s_lo; s < s_hi; ++s) {
+            const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0;
+            const uint32_t e0 = expr_off[s], net = expr_off[s + 1] - e0;
+            free_rank.assign(nvt, -1);
+            int32_t rank = 0;
+            for (uint32_t i = 0; i < nvt; ++i) {
+                uint16_t info = var_info[v0 + i];
+                if ((info & fx::VAR_COMP_MASK) != fx::VAR_COMP_NONE && !(info & fx::VAR_FIXED_BIT)) free_rank[i] = rank++;
+            }
+            for (uint32_t i = 0; i < net; ++i) {
+                const uint32_t e = e0 + i;
+                uint32_t vars8[8];
+                int k = fx::expand_vars((int)(expr_tag[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
+                int32_t cols[8];
+                uint32_t slots;
+                int ncols = row_columns(vars8, k, free_rank.data(), cols, &slots);
+                out.jslot[e] = slots;
+                for (int q = 0; q < ncols; ++q) lc.push_back((uint32_t)cols[q]);
+                out.jrow_ptr[(size_t)e + 1] = (uint32_t)ncols;  // count; prefix-summed below
+            }
+        }
+    }, &nr);
+    for (uint32_t e = 0; e < ne; ++e) out.jrow_ptr[e + 1] += out.jrow_ptr[e];
+    out.jcol.resize(out.jrow_ptr[ne]);
+    for (uint32_t t = 0; t < nr; ++t)
+        if (!local_cols[t].empty())
+            std::copy(local_cols[t].begin(), local_cols[t].end(), out.jcol.begin() + out.jrow_ptr[expr_off[range_lo[t]]]);
+}
+
+// Checks the batch and builds the plan. Mirrors the data invariants the reference enforces by
+// construction (handles of the same System, indices < variables.len()).
+int analyze(const fx_batch* b, HostPlan* plan) {
     if (!b) return fail(FX_ERR_INVALID, "batch is NULL");
     const uint32_t n = b->n_systems;
     if (n > 0 && (!b->var_off || !b->expr_off)) return fail(FX_ERR_INVALID, "var_off/expr_off is NULL");
     if (n == 0) {
         if (plan) *plan = HostPlan();
-        if (plan) plan->jrow_ptr.assign(1, 0);
         return FX_OK;
     }
     if (b->var_off[0] != 0 || b->expr_off[0] != 0) return fail(FX_ERR_INVALID, "offset arrays must start at 0");
@@ -94,152 +190,171 @@ int analyze(const fx_batch* b, HostPlan* plan, bool want_structure) {
     p.row_simple.assign(ne, 0);
     p.row_sysoff.assign(ne, 0);
     p.expr_sys.assign(ne, 0);
-    if (want_structure) {
-        p.jrow_ptr.assign((size_t)ne + 1, 0);
-        p.jslot.assign(ne, 0xFFFFFFFFu);
-        p.jcol.reserve((size_t)ne * 5);
-    }
 
-    std::vector<int32_t> free_rank;     // per variable of the current system: system-wide free rank
-    std::vector<uint32_t> comp_free, comp_rows;
-    for (uint32_t s = 0; s < n; ++s) {
-        const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
-        const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
-        if (nvt > FX_MAX_LARGE_SYSTEM_VARS)
-            return fail(FX_ERR_TOO_LARGE, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_LARGE_SYSTEM_VARS);
-        bool large = nvt > FX_MAX_SYSTEM_VARS;
-        p.max_vars_all = std::max(p.max_vars_all, nvt);
-        p.max_exprs_all = std::max(p.max_exprs_all, net);
-
-        uint32_t ncomp = 0;
-        free_rank.assign(nvt, -1);
-        int32_t rank = 0;
-        for (uint32_t i = 0; i < nvt; ++i) {
-            uint16_t c = b->var_comp ? b->var_comp[v0 + i] : 0;
-            bool fixed = b->var_fixed[v0 + i] != 0;
-            uint16_t info;
-            if (c == FX_NO_COMPONENT) {
-                info = fx::VAR_COMP_NONE;
-            } else {
-                if (c >= fx::VAR_COMP_NONE) return fail(FX_ERR_INVALID, "system %u: component id %u too large", s, c);
-                info = c;
-                ncomp = std::max<uint32_t>(ncomp, c + 1u);
-                if (!fixed) free_rank[i] = rank++;
+    struct Partial {
+        uint64_t nnz = 0;
+        uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0, n_large = 0;
+        int err = FX_OK;
+        uint32_t err_system = 0;
+        char msg[192] = {0};
+    } part[MAX_RANGES];
+    uint32_t nr = 1;
+    parallel_ranges(n, (uint64_t)ne + nv, [&](uint32_t t, uint32_t s_lo, uint32_t s_hi) {
+        Partial& pt = part[t];
+        auto bad = [&](int code, uint32_t s, const char* fmt, unsigned a0 = 0, unsigned a1 = 0, unsigned a2 = 0, unsigned a3 = 0) {
+            pt.err = code;
+            pt.err_system = s;
+            snprintf(pt.msg, sizeof(pt.msg), fmt, a0, a1, a2, a3);
+        };
+        std::vector<int32_t> free_rank;  // per variable of the current system: system-wide free rank
+        std::vector<uint32_t> comp_free, comp_rows;
+        for (uint32_t s = s_lo; s < s_hi && pt.err == FX_OK; ++s) {
+            const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
+            const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
+            if (nvt > FX_MAX_LARGE_SYSTEM_VARS) {
+                bad(FX_ERR_TOO_LARGE, s, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_LARGE_SYSTEM_VARS);
+                break;
             }
-            if (fixed) info |= fx::VAR_FIXED_BIT;
-            p.var_info[v0 + i] = info;
-        }
-        for (uint32_t i = 0; i < net; ++i) {
-            uint16_t c = b->expr_comp ? b->expr_comp[e0 + i] : 0;
-            if (c == FX_NO_COMPONENT) {
-                c = fx::VAR_COMP_NONE;  // never selected by any component loop
-            } else {
-                if (c >= fx::VAR_COMP_NONE) return fail(FX_ERR_INVALID, "system %u: component id %u too large", s, c);
-                ncomp = std::max<uint32_t>(ncomp, c + 1u);
-            }
-            p.expr_comp[e0 + i] = c;
-        }
-        p.sys_ncomp[s] = (uint16_t)ncomp;
+            bool large = nvt > FX_MAX_SYSTEM_VARS;
+            pt.max_vars_all = std::max(pt.max_vars_all, nvt);
+            pt.max_exprs_all = std::max(pt.max_exprs_all, net);
 
-        comp_free.assign(ncomp, 0);
-        comp_rows.assign(ncomp, 0);
-        for (uint32_t i = 0; i < nvt; ++i) {
-            uint16_t info = p.var_info[v0 + i];
-            uint16_t c = info & fx::VAR_COMP_MASK;
-            if (c != fx::VAR_COMP_NONE && !(info & fx::VAR_FIXED_BIT)) comp_free[c] += 1;
-        }
-
-        for (uint32_t i = 0; i < net; ++i) {
-            const uint32_t e = e0 + i;
-            const int tag = b->expr_tag[e];
-            if (tag < 0 || tag >= FX_NTAGS) return fail(FX_ERR_INVALID, "expression %u of system %u: bad tag %d", i, s, tag);
-            const uint32_t* f = b->expr_idx + 4 * (size_t)e;
-            uint32_t vars8[8];
-            int k = fx::expand_vars(tag, f, vars8);
-            for (int q = 0; q < k; ++q) {
-                if (vars8[q] >= nvt)
-                    return fail(FX_ERR_INVALID, "expression %u of system %u reads variable %u >= %u", i, s, vars8[q], nvt);
+            uint32_t ncomp = 0;
+            free_rank.assign(nvt, -1);
+            int32_t rank = 0;
+            for (uint32_t i = 0; i < nvt; ++i) {
+                uint16_t c = b->var_comp ? b->var_comp[v0 + i] : 0;
+                bool fixed = b->var_fixed[v0 + i] != 0;
+                uint16_t info;
+                if (c == FX_NO_COMPONENT) {
+                    info = fx::VAR_COMP_NONE;
+                } else {
+                    if (c >= fx::VAR_COMP_NONE) {
+                        bad(FX_ERR_INVALID, s, "system %u: component id %u too large", s, c);
+                        break;
+                    }
+                    info = c;
+                    ncomp = std::max<uint32_t>(ncomp, c + 1u);
+                    if (!fixed) free_rank[i] = rank++;
+                }
+                if (fixed) info |= fx::VAR_FIXED_BIT;
+                p.var_info[v0 + i] = info;
             }
-            for (int q = 0; q < 4; ++q) p.expr_idx16[4 * (size_t)e + q] = (uint16_t)(f[q] < nvt ? f[q] : 0);
-            p.expr_var0[e] = v0;
-            p.expr_tagx[e] = (uint8_t)tag;
-            {
-                bool dup = false;
-                for (int q = 0; q < k; ++q)
-                    for (int t = q + 1; t < k; ++t) dup = dup || (vars8[q] == vars8[t] && free_rank[vars8[q]] >= 0);
-                if (dup) p.expr_tagx[e] |= 0x80;
-                bool all_free = true, distinct = true;
+            for (uint32_t i = 0; i < net && pt.err == FX_OK; ++i) {
+                uint16_t c = b->expr_comp ? b->expr_comp[e0 + i] : 0;
+                if (c == FX_NO_COMPONENT) {
+                    c = fx::VAR_COMP_NONE;  // never selected by any component loop
+                } else {
+                    if (c >= fx::VAR_COMP_NONE) {
+                        bad(FX_ERR_INVALID, s, "system %u: component id %u too large", s, c);
+                        break;
+                    }
+                    ncomp = std::max<uint32_t>(ncomp, c + 1u);
+                }
+                p.expr_comp[e0 + i] = c;
+            }
+            if (pt.err != FX_OK) break;
+            p.sys_ncomp[s] = (uint16_t)ncomp;
+
+            comp_free.assign(ncomp, 0);
+            comp_rows.assign(ncomp, 0);
+            for (uint32_t i = 0; i < nvt; ++i) {
+                uint16_t info = p.var_info[v0 + i];
+                uint16_t c = info & fx::VAR_COMP_MASK;
+                if (c != fx::VAR_COMP_NONE && !(info & fx::VAR_FIXED_BIT)) comp_free[c] += 1;
+            }
+
+            for (uint32_t i = 0; i < net; ++i) {
+                const uint32_t e = e0 + i;
+                const int tag = b->expr_tag[e];
+                if (tag < 0 || tag >= FX_NTAGS) {
+                    bad(FX_ERR_INVALID, s, "expression %u of system %u: bad tag %d", i, s, (unsigned)tag);
+                    break;
+                }
+                const uint32_t* f = b->expr_idx + 4 * (size_t)e;
+                uint32_t vars8[8];
+                int k = fx::expand_vars(tag, f, vars8);
+                bool in_range = true;
+                for (int q = 0; q < k; ++q) {
+                    if (vars8[q] >= nvt) {
+                        bad(FX_ERR_INVALID, s, "expression %u of system %u reads variable %u >= %u", i, s, vars8[q], nvt);
+                        in_range = false;
+                        break;
+                    }
+                }
+                if (!in_range) break;
+                for (int q = 0; q < 4; ++q) p.expr_idx16[4 * (size_t)e + q] = (uint16_t)(f[q] < nvt ? f[q] : 0);
+                p.expr_var0[e] = v0;
+                p.expr_tagx[e] = (uint8_t)tag;
+                bool dup = false, all_free = true, distinct = true;
                 for (int q = 0; q < k; ++q) {
                     all_free = all_free && free_rank[vars8[q]] >= 0;
-                    for (int t = q + 1; t < k; ++t) distinct = distinct && vars8[q] != vars8[t];
+                    for (int u = q + 1; u < k; ++u) {
+                        distinct = distinct && vars8[q] != vars8[u];
+                        dup = dup || (vars8[q] == vars8[u] && free_rank[vars8[q]] >= 0);
+                    }
                 }
+                if (dup) p.expr_tagx[e] |= 0x80;
                 p.row_simple[e] = (all_free && distinct) ? 1 : 0;
                 p.expr_sys[e] = s;
+                uint16_t c = p.expr_comp[e];
+                if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
+                if (all_free && distinct) {
+                    pt.nnz += (uint64_t)k;
+                } else {
+                    int32_t cols[8];
+                    pt.nnz += (uint64_t)row_columns(vars8, k, free_rank.data(), cols, nullptr);
+                }
             }
-            uint16_t c = p.expr_comp[e];
-            if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
-
-            if (want_structure) {
-                // distinct free columns of the row, ascending; slot of each gradient entry
-                int32_t cols[8];
-                int ncols = 0;
-                for (int q = 0; q < k; ++q) {
-                    int32_t col = free_rank[vars8[q]];
-                    if (col < 0) continue;
-                    bool seen = false;
-                    for (int t = 0; t < ncols; ++t) seen = seen || cols[t] == col;
-                    if (!seen) cols[ncols++] = col;
+            if (pt.err != FX_OK) break;
+            for (uint32_t c = 0; c < ncomp; ++c)
+                large = large || comp_free[c] > FX_MAX_FREE_VARS || comp_rows[c] > FX_MAX_ROWS;
+            if (large) {
+                p.sys_large[s] = 1;
+                pt.n_large += 1;
+            } else {  // LDS layout and kernel instantiation are sized by the one-wavefront systems only
+                pt.max_vars = std::max(pt.max_vars, nvt);
+                pt.max_exprs = std::max(pt.max_exprs, net);
+                for (uint32_t c = 0; c < ncomp; ++c) {
+                    pt.max_free = std::max(pt.max_free, comp_free[c]);
+                    pt.max_rows = std::max(pt.max_rows, comp_rows[c]);
                 }
-                std::sort(cols, cols + ncols);
-                uint32_t slots = 0;
-                for (int q = 0; q < 8; ++q) {
-                    uint32_t sl = 0xFu;
-                    if (q < k) {
-                        int32_t col = free_rank[vars8[q]];
-                        if (col >= 0) sl = (uint32_t)(std::find(cols, cols + ncols, col) - cols);
-                    }
-                    slots |= sl << (4 * q);
-                }
-                p.jslot[e] = slots;
-                for (int t = 0; t < ncols; ++t) p.jcol.push_back((uint32_t)cols[t]);
-                p.jrow_ptr[(size_t)e + 1] = p.jrow_ptr[e] + (uint32_t)ncols;
             }
         }
-        for (uint32_t c = 0; c < ncomp; ++c)
-            large = large || comp_free[c] > FX_MAX_FREE_VARS || comp_rows[c] > FX_MAX_ROWS;
-        if (large) {
-            p.sys_large[s] = 1;
-            p.n_large += 1;
-        } else {  // LDS layout and kernel instantiation are sized by the one-wavefront systems only
-            p.max_vars = std::max(p.max_vars, nvt);
-            p.max_exprs = std::max(p.max_exprs, net);
-            for (uint32_t c = 0; c < ncomp; ++c) {
-                p.max_free = std::max(p.max_free, comp_free[c]);
-                p.max_rows = std::max(p.max_rows, comp_rows[c]);
-            }
-        }
+    }, &nr);
+    for (uint32_t t = 0; t < nr; ++t)  // ranges are in system order: the first failing System is reported
+        if (part[t].err != FX_OK) return fail(part[t].err, "%s", part[t].msg);
+    for (uint32_t t = 0; t < nr; ++t) {
+        p.nnz += part[t].nnz;
+        p.n_large += part[t].n_large;
+        p.max_free = std::max(p.max_free, part[t].max_free);
+        p.max_rows = std::max(p.max_rows, part[t].max_rows);
+        p.max_vars = std::max(p.max_vars, part[t].max_vars);
+        p.max_exprs = std::max(p.max_exprs, part[t].max_exprs);
+        p.max_vars_all = std::max(p.max_vars_all, part[t].max_vars_all);
+        p.max_exprs_all = std::max(p.max_exprs_all, part[t].max_exprs_all);
     }
-    if (want_structure) p.nnz = p.jcol.size();
     // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
-    for (uint32_t r0 = 0; r0 < ne; r0 += 256) {
-        uint32_t nr = std::min<uint32_t>(256, ne - r0), t = 0;
-        for (int tag = 0; tag < FX_NTAGS; ++tag)
-            for (uint32_t i = 0; i < nr; ++i)
-                if ((p.expr_tagx[r0 + i] & 0x7F) == tag) p.row_perm[r0 + t++] = (uint8_t)i;
-        fx::BlockInfo bi{};
-        bi.sys0 = p.expr_sys[r0];
-        bool simple = want_structure;
-        for (uint32_t i = 0; i < nr; ++i) {
-            simple = simple && p.row_simple[r0 + i];
-            p.row_sysoff[r0 + i] = (uint8_t)(p.expr_sys[r0 + i] - bi.sys0);  // < 256: at most 256 rows per block
+    const uint32_t nblk = (ne + 255u) / 256u;
+    p.blk_info.assign(nblk, fx::BlockInfo{});
+    parallel_ranges(nblk, ne, [&](uint32_t, uint32_t b_lo, uint32_t b_hi) {
+        for (uint32_t blk = b_lo; blk < b_hi; ++blk) {
+            const uint32_t r0 = blk * 256u;
+            uint32_t nrw = std::min<uint32_t>(256, ne - r0), t = 0;
+            for (int tag = 0; tag < FX_NTAGS; ++tag)
+                for (uint32_t i = 0; i < nrw; ++i)
+                    if ((p.expr_tagx[r0 + i] & 0x7F) == tag) p.row_perm[r0 + t++] = (uint8_t)i;
+            fx::BlockInfo bi{};
+            bi.sys0 = p.expr_sys[r0];
+            bool simple = true;
+            for (uint32_t i = 0; i < nrw; ++i) {
+                simple = simple && p.row_simple[r0 + i];
+                p.row_sysoff[r0 + i] = (uint8_t)(p.expr_sys[r0 + i] - bi.sys0);  // < 256: at most 256 rows per block
+            }
+            bi.flags = simple ? 1u : 0u;  // jbase / jcount are filled when the CSR structure is built
+            p.blk_info[blk] = bi;
         }
-        if (want_structure) {
-            bi.jbase = p.jrow_ptr[r0];
-            bi.jcount = p.jrow_ptr[r0 + nr] - p.jrow_ptr[r0];
-        }
-        bi.flags = simple ? 1u : 0u;
-        p.blk_info.push_back(bi);
-    }
+    });
     return FX_OK;
 }
 
@@ -293,6 +408,54 @@ int bind(fx_ctx* ctx) {
 }  // namespace
 
 namespace {
+int ensure_resid(fx_ctx* ctx, fx_dbatch* db) {
+    if (db->d.resid) return FX_OK;
+    int rc = dev_alloc_copy(ctx, db, &db->d.resid, (const double*)nullptr, db->d.n_exprs);
+    return rc;
+}
+
+// The CSR Jacobian structure of a resident batch, built on first use from the device's own compact
+// arrays (nothing is kept on the host for batches that are only ever solved).
+int ensure_csr(fx_ctx* ctx, fx_dbatch* db) {
+    fx::DeviceBatch& d = db->d;
+    if (d.jrow_ptr) return FX_OK;
+    int rc = ensure_resid(ctx, db);
+    if (rc) return rc;
+    const uint32_t n = d.n_systems;
+    std::vector<uint32_t> var_off((size_t)n + 1, 0), expr_off((size_t)n + 1, 0);
+    std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs);
+    std::vector<uint8_t> expr_tag(d.n_exprs);
+    const size_t nblk = ((size_t)d.n_exprs + 255) / 256;
+    std::vector<fx::BlockInfo> blk(nblk);
+    FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_exprs) {
+        FX_HIP(hipMemcpyAsync(expr_idx.data(), d.expr_idx, expr_idx.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(expr_tag.data(), d.expr_tag, expr_tag.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(blk.data(), d.blk_info, nblk * sizeof(fx::BlockInfo), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    CsrPlan csr;
+    build_csr(n, var_off.data(), expr_off.data(), var_info.data(), expr_tag.data(), expr_idx.data(), csr);
+    if (csr.jcol.size() != d.nnz) return fail(FX_ERR_INVALID, "internal: CSR size %zu != counted %llu", csr.jcol.size(), (unsigned long long)d.nnz);
+    for (size_t k = 0; k < nblk; ++k) {
+        const size_t r0 = k * 256, r1 = std::min<size_t>(r0 + 256, d.n_exprs);
+        blk[k].jbase = csr.jrow_ptr[r0];
+        blk[k].jcount = csr.jrow_ptr[r1] - csr.jrow_ptr[r0];
+    }
+    uint32_t* jrow_ptr = nullptr;
+    rc = dev_alloc_copy(ctx, db, &jrow_ptr, csr.jrow_ptr.data(), csr.jrow_ptr.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.jcol, csr.jcol.data(), csr.jcol.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.jslot, csr.jslot.data(), csr.jslot.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.jvals, (const double*)nullptr, d.nnz);
+    if (rc) return rc;
+    if (nblk) FX_HIP(hipMemcpyAsync(d.blk_info, blk.data(), nblk * sizeof(fx::BlockInfo), hipMemcpyHostToDevice, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    d.jrow_ptr = jrow_ptr;  // set last: marks the structure as complete
+    return FX_OK;
+}
+
 // Builds the SinglePass blocks of every System that runs in the fused kernel (once per batch; the
 // structure is read back from the device arrays, so nothing extra is kept on the host for batches
 // that never ask for it). Large Systems get theirs inside the sparse path.
@@ -501,15 +664,18 @@ void fx_solving_opts_default(fx_solving_opts* o) {
     fx_lm_opts_default(&o->lm);
 }
 
-int fx_batch_validate(const fx_batch* batch) { return analyze(batch, nullptr, false); }
+int fx_batch_validate(const fx_batch* batch) { return analyze(batch, nullptr); }
 
 int fx_jacobian_structure(const fx_batch* batch, uint64_t* nnz, uint32_t* row_ptr, uint32_t* col_idx) {
     HostPlan p;
-    int rc = analyze(batch, &p, true);
+    int rc = analyze(batch, &p);
     if (rc) return rc;
     if (nnz) *nnz = p.nnz;
-    if (row_ptr) std::copy(p.jrow_ptr.begin(), p.jrow_ptr.end(), row_ptr);
-    if (col_idx) std::copy(p.jcol.begin(), p.jcol.end(), col_idx);
+    if (!row_ptr && !col_idx) return FX_OK;
+    CsrPlan csr;
+    build_csr(p.n_systems, batch->var_off, batch->expr_off, p.var_info.data(), p.expr_tagx.data(), p.expr_idx16.data(), csr);
+    if (row_ptr) std::copy(csr.jrow_ptr.begin(), csr.jrow_ptr.end(), row_ptr);
+    if (col_idx) std::copy(csr.jcol.begin(), csr.jcol.end(), col_idx);
     return FX_OK;
 }
 
@@ -519,7 +685,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     int rc = bind(ctx);
     if (rc) return rc;
     HostPlan p;
-    rc = analyze(batch, &p, true);
+    rc = analyze(batch, &p);
     if (rc) return rc;
     fx_dbatch* db = new (std::nothrow) fx_dbatch();
     if (!db) return fail(FX_ERR_NOMEM, "out of host memory");
@@ -558,12 +724,10 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(expr_var0, p.expr_var0.data(), p.n_exprs)
     FX_UP(row_sysoff, p.row_sysoff.data(), p.n_exprs)
     FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
-    FX_UP(jrow_ptr, p.jrow_ptr.data(), (size_t)p.n_exprs + 1)
-    FX_UP(jcol, p.jcol.data(), p.nnz)
-    FX_UP(jslot, p.jslot.data(), p.n_exprs)
-    FX_UP(jvals, (const double*)nullptr, p.nnz)
-    FX_UP(resid, (const double*)nullptr, p.n_exprs)
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
+    // jrow_ptr / jcol / jslot / jvals (the CSR Jacobian) and resid are only needed by the standalone
+    // evaluation entry points: they are built on first use (ensure_csr / ensure_resid), so a plain
+    // solve neither computes nor uploads them.
 #undef FX_UP
     // the host plan lives on this stack frame: finish the copies before returning
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -708,6 +872,8 @@ int fx_eval_residual_jacobian_device(fx_ctx* ctx, fx_dbatch* db, int which) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    rc = ensure_csr(ctx, db);
+    if (rc) return rc;
     FX_HIP(fx::launch_eval(db->d, which ? db->d.vars : db->d.vars0, true, ctx->stream));
     return FX_OK;
 }
@@ -716,6 +882,8 @@ int fx_eval_residual_device(fx_ctx* ctx, fx_dbatch* db, int which) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    rc = ensure_resid(ctx, db);
+    if (rc) return rc;
     FX_HIP(fx::launch_eval(db->d, which ? db->d.vars : db->d.vars0, false, ctx->stream));
     return FX_OK;
 }
@@ -724,6 +892,7 @@ int fx_batch_get_residuals(fx_ctx* ctx, fx_dbatch* db, double* r) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!db || !r) return fail(FX_ERR_INVALID, "bad argument");
+    if (!db->d.resid) return fail(FX_ERR_INVALID, "no residuals have been evaluated on this batch yet");
     FX_HIP(hipMemcpyAsync(r, db->d.resid, (size_t)db->d.n_exprs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FX_HIP(hipStreamSynchronize(ctx->stream));
     return FX_OK;
@@ -733,6 +902,7 @@ int fx_batch_get_jacobian_values(fx_ctx* ctx, fx_dbatch* db, double* jvals) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!db || !jvals) return fail(FX_ERR_INVALID, "bad argument");
+    if (!db->d.jvals) return fail(FX_ERR_INVALID, "no Jacobian has been evaluated on this batch yet");
     FX_HIP(hipMemcpyAsync(jvals, db->d.jvals, (size_t)db->d.nnz * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FX_HIP(hipStreamSynchronize(ctx->stream));
     return FX_OK;
@@ -811,7 +981,7 @@ int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent) {
 
 int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_blocks, uint32_t* block_comp,
                           uint32_t* row_off, uint32_t* rows, uint32_t* var_off, uint32_t* vars) {
-    int rc = analyze(batch, nullptr, false);
+    int rc = analyze(batch, nullptr);
     if (rc) return rc;
     if (system >= batch->n_systems) return fail(FX_ERR_INVALID, "system %u out of range (%u systems)", system, batch->n_systems);
     const uint32_t v0 = batch->var_off[system], nvt = batch->var_off[system + 1] - v0;
@@ -856,7 +1026,8 @@ int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r) {
     fx_dbatch* db = nullptr;
     int rc = fx_batch_upload(ctx, batch, &db);
     if (rc) return rc;
-    hipError_t e = fx::launch_identity_residuals(db->d, db->d.vars0, db->d.resid, ctx->stream);
+    rc = ensure_resid(ctx, db);
+    hipError_t e = rc ? hipSuccess : fx::launch_identity_residuals(db->d, db->d.vars0, db->d.resid, ctx->stream);
     if (e != hipSuccess) rc = fail(FX_ERR_HIP, "launch failed: %s", hipGetErrorString(e));
     if (!rc && db->d.n_exprs) rc = fx_batch_get_residuals(ctx, db, r);
     fx_batch_free(ctx, db);
