@@ -375,6 +375,7 @@ struct fx_dbatch {
     std::vector<uint32_t> h_var_off, h_expr_off, h_expr_idx;
     std::vector<double> h_vars, h_expr_param;
     std::vector<uint8_t> h_var_fixed, h_expr_tag, h_sys_large;
+    std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
     uint32_t n_large = 0;
@@ -482,14 +483,23 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
 
     std::vector<uint32_t> sys_unit_off((size_t)n + 1, 0);
     std::vector<fx::UnitDesc> desc;
-    std::vector<uint16_t> unit_rows, unit_vars;
+    std::vector<uint32_t> unit_rows;
+    std::vector<uint16_t> unit_vars;
     uint32_t max_unit_free = 0, max_unit_rows = 0;
     fx::Incidence inc;
     fx::UnitList units;
     std::vector<uint32_t> free_sorted;
+    // Large Systems: if every block fits the one-wavefront limits the System is walked on the device
+    // with its System-wide vectors in an HBM scratch area (the GLOBAL instantiation); otherwise it
+    // stays with the host-driven sparse path.
+    std::vector<uint32_t> g_list, g_off;
+    std::vector<uint8_t> g_ok(n, 0);
+    uint32_t g_total = 0, max_unit_free_g = 0, max_unit_rows_g = 0;
     for (uint32_t s = 0; s < n; ++s) {
         sys_unit_off[s] = (uint32_t)desc.size();
-        if (sys_large[s]) continue;
+        const size_t desc_mark = desc.size(), rows_mark = unit_rows.size(), vars_mark = unit_vars.size();
+        bool fits = true;
+        uint32_t mf = 0, mrw = 0;
         const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0;
         const uint32_t e0 = expr_off[s], net = expr_off[s + 1] - e0;
         inc.build(nvt, net, expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0);
@@ -517,12 +527,29 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
                 ud.nvars = (uint16_t)(units.var_off[u + 1] - units.var_off[u]);
                 ud.comp = (uint16_t)c;
                 ud.flags = u == 0 ? fx::UNIT_FIRST : 0;
-                for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k) unit_rows.push_back((uint16_t)units.rows[k]);
+                for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k) unit_rows.push_back(units.rows[k]);
                 for (uint32_t k = units.var_off[u]; k < units.var_off[u + 1]; ++k) unit_vars.push_back((uint16_t)units.vars[k]);
-                max_unit_free = std::max<uint32_t>(max_unit_free, ud.nvars);
-                max_unit_rows = std::max<uint32_t>(max_unit_rows, ud.nrows);
+                const uint32_t bf = units.var_off[u + 1] - units.var_off[u], br = units.row_off[u + 1] - units.row_off[u];
+                fits = fits && bf <= FX_MAX_FREE_VARS && br <= FX_MAX_ROWS;
+                mf = std::max(mf, bf);
+                mrw = std::max(mrw, br);
                 desc.push_back(ud);
             }
+        }
+        if (!sys_large[s]) {
+            max_unit_free = std::max(max_unit_free, mf);
+            max_unit_rows = std::max(max_unit_rows, mrw);
+        } else if (fits) {
+            g_ok[s] = 1;
+            g_list.push_back(s);
+            g_off.push_back(g_total);
+            g_total += nvt;
+            max_unit_free_g = std::max(max_unit_free_g, mf);
+            max_unit_rows_g = std::max(max_unit_rows_g, mrw);
+        } else {  // some block is itself too large: the System keeps the sparse path, drop its entries
+            desc.resize(desc_mark);
+            unit_rows.resize(rows_mark);
+            unit_vars.resize(vars_mark);
         }
     }
     sys_unit_off[n] = (uint32_t)desc.size();
@@ -533,6 +560,19 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     if (!rc) rc = dev_alloc_copy(ctx, db, &off, sys_unit_off.data(), sys_unit_off.size());
     if (rc) return rc;
     FX_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    if (!g_list.empty()) {
+        rc = dev_alloc_copy(ctx, db, &d.g_list, g_list.data(), g_list.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &d.g_off, g_off.data(), g_off.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &d.g_xs, (const double*)nullptr, 2 * (size_t)g_total);
+        if (!rc) rc = dev_alloc_copy(ctx, db, &d.g_vout, (const double*)nullptr, g_total);
+        if (!rc) rc = dev_alloc_copy(ctx, db, &d.g_colof, (const int16_t*)nullptr, g_total);
+        if (rc) return rc;
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        d.n_g = (uint32_t)g_list.size();
+        d.max_unit_free_g = max_unit_free_g;
+        d.max_unit_rows_g = max_unit_rows_g;
+    }
+    db->h_units_on_device = g_ok;
     d.max_unit_free = max_unit_free;
     d.max_unit_rows = max_unit_rows;
     if (fx::solve_lds_bytes_units(d) > 160u * 1024u)
@@ -544,8 +584,10 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
 // Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (!db->n_large) return FX_OK;
+    const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
     for (uint32_t s = 0; s < db->d.n_systems; ++s) {
         if (!db->h_sys_large[s]) continue;
+        if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
         fx_result res{};
         hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, ctx->stream, db->d.vars + db->h_var_off[s], &res);
         if (e == hipSuccess)

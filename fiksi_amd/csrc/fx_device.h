@@ -72,8 +72,15 @@ struct DeviceBatch {
     uint32_t max_unit_rows;   // expressions per block (a block may hold a neighbouring component's rows)
     uint32_t* sys_unit_off;   // [n_systems+1] into unit_desc (large Systems own no entries)
     UnitDesc* unit_desc;
-    uint16_t* unit_rows;      // system-local expression ids
+    uint32_t* unit_rows;      // system-local expression ids
     uint16_t* unit_vars;      // system-local variable ids, ascending per block
+    // large Systems whose blocks all fit one wavefront: walked by the GLOBAL kernel instantiation
+    uint32_t n_g, max_unit_free_g, max_unit_rows_g;
+    uint32_t* g_list;         // [n_g] System ids
+    uint32_t* g_off;          // [n_g] offset of the System's slice in the scratch arrays (in variables)
+    double* g_xs;             // [2 * total] working variables, two halves per System
+    double* g_vout;           // [total] unscaled output values
+    int16_t* g_colof;         // [total] variable -> free column of the block in flight
 };
 
 struct LmParams {

@@ -209,7 +209,12 @@ enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4
 // history vectors in LDS, and sums every dot product in index order (the reference's order) by
 // reading the lane products back from LDS. The line search is the fx::HzMachine state machine
 // around the single evaluation site.
-template <int N, typename T, bool PROF, bool UNITS, int OPT = 0>
+//
+// GLOBAL = true (with UNITS) serves Systems too large for LDS whose SinglePass blocks are all small:
+// the System-wide vectors (working variables, output values, variable -> column map) live in an
+// HBM scratch area instead of LDS — L2-resident for the one wavefront that walks the blocks — while
+// everything per block stays in LDS and registers as before.
+template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false>
 __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -223,11 +228,11 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     };
     if (PROF) t_last = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x;
-    const uint32_t s = blockIdx.x;
-    if (b.sys_large[s]) return;  // handled by the sparse path (fx_sparse.hip)
+    const uint32_t s = GLOBAL ? b.g_list[blockIdx.x] : blockIdx.x;
+    if (!GLOBAL && b.sys_large[s]) return;  // handled by the GLOBAL launch or the sparse path (fx_sparse.hip)
     constexpr int LD = N + Vec16<T>::n;  // 16-byte aligned columns, conflict-free ds_read_b128
 
-    T* XS = reinterpret_cast<T*>(smem + L.off_xs);       // [2][vt] full variable vectors
+    T* XS = reinterpret_cast<T*>(smem + L.off_xs);       // [2][vt] full variable vectors (GLOBAL: re-pointed below)
     T* Amat = reinterpret_cast<T*>(smem + L.off_a);      // [N][LD] JtJ (lambda on demand)
     T* rhsv = reinterpret_cast<T*>(smem + L.off_rhs);    // [N] -Jt r
     T* G = reinterpret_cast<T*>(smem + L.off_g);         // [2][mr][8] Jacobian rows
@@ -238,9 +243,17 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     uint8_t* rtag = reinterpret_cast<uint8_t*>(smem + L.off_rtag);    // [mr]
     uint16_t* fidx = reinterpret_cast<uint16_t*>(smem + L.off_fidx);  // [N] free column -> variable
     double* VOUT = reinterpret_cast<double*>(smem + L.off_vout);       // [vt] unscaled values as written back
-    const uint32_t vt = L.vt, mr = L.mr;
+    const uint32_t mr = L.mr;
 
     const uint32_t v0 = b.var_off[s], nvt = b.var_off[s + 1] - v0;
+    int16_t* colof = reinterpret_cast<int16_t*>(smem + L.off_colof);  // [vt] variable -> free column
+    const uint32_t vt = GLOBAL ? nvt : L.vt;  // distance between the two halves of XS
+    if constexpr (GLOBAL) {
+        const size_t go = b.g_off[blockIdx.x];
+        XS = reinterpret_cast<T*>(b.g_xs + 2 * go);
+        VOUT = b.g_vout + go;
+        colof = b.g_colof + go;
+    }
     const uint32_t e0 = b.expr_off[s], net = b.expr_off[s + 1] - e0;
     const uint32_t ncomp = b.sys_ncomp[s];
     const fx_lm_opts o = prm.lm;
@@ -297,7 +310,10 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     uint32_t rng = 42u;  // one Rng::from_seed(42) per solve, shared by the components (:47)
     uint32_t tot_accept = 0, tot_trials = 0, last_exit = FX_EXIT_SSE, comps_done = 0;
     double tot_sse0 = 0.0, tot_sse = 0.0;
-    int16_t* colof = reinterpret_cast<int16_t*>(smem + L.off_colof);  // [vt] variable -> free column
+    if constexpr (UNITS) {  // blocks set and clear their own entries
+        for (uint32_t i = lane; i < nvt; i += 64) colof[i] = (int16_t)-1;
+        __syncthreads();
+    }
 
     const uint32_t unit0 = UNITS ? b.sys_unit_off[s] : 0u;
     const uint32_t n_iter = UNITS ? b.sys_unit_off[s + 1] - unit0 : ncomp;
@@ -338,8 +354,6 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         if (ud.flags & UNIT_EMPTY) continue;  // a component no expression could be matched in
         nfree = ud.nvars;
         m_rows = ud.nrows;
-        for (uint32_t i = lane; i < nvt; i += 64) colof[i] = (int16_t)-1;
-        __syncthreads();
         if ((uint32_t)lane < nfree) {
             uint32_t vi = b.unit_vars[ud.var_off + lane];
             fidx[lane] = (uint16_t)vi;
@@ -770,6 +784,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 T xv = XS[cur * vt + vi];
                 XS[vi] = xv;
                 XS[vt + vi] = xv;
+                colof[vi] = (int16_t)-1;
             } else {
                 // later components are solved against the PRE-solve snapshot (only `system.variables` is
                 // written back, quirk Q2): restore the perturbed start value in both halves
@@ -1099,6 +1114,33 @@ hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_va
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+// the GLOBAL instantiation: one wavefront per listed large System
+template <int N>
+static hipError_t launch_solve_global_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
+    if (L.total > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, double, false, true, 0, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((lm_solve_kernel<N, double, false, true, 0, true>), dim3(b.n_g), dim3(64), L.total, stream, b, p, L);
+    return hipGetLastError();
+}
+
+static hipError_t launch_solve_global(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    uint32_t n = pad_n(b.max_unit_free_g);
+    SolveLayout L = make_layout(n, 8u, b.max_unit_rows_g, 8u);  // System-wide vectors are not in LDS
+    switch (n) {
+        case 8: return launch_solve_global_n<8>(b, p, L, stream);
+        case 16: return launch_solve_global_n<16>(b, p, L, stream);
+        case 24: return launch_solve_global_n<24>(b, p, L, stream);
+        case 32: return launch_solve_global_n<32>(b, p, L, stream);
+        case 40: return launch_solve_global_n<40>(b, p, L, stream);
+        case 48: return launch_solve_global_n<48>(b, p, L, stream);
+        case 56: return launch_solve_global_n<56>(b, p, L, stream);
+        case 64: return launch_solve_global_n<64>(b, p, L, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 template <int N, typename T, bool PROF, bool UNITS, int OPT>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
@@ -1141,7 +1183,12 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
         if (p.lm.precision == 32) return hipErrorInvalidValue;
         return units ? launch_solve_t<double, true, 1>(b, p, stream) : launch_solve_t<double, false, 1>(b, p, stream);
     }
-    if (units) return p.lm.precision == 32 ? launch_solve_t<float, true, 0>(b, p, stream) : launch_solve_t<double, true, 0>(b, p, stream);
+    if (units) {
+        if (p.lm.precision == 32) return launch_solve_t<float, true, 0>(b, p, stream);
+        hipError_t e = launch_solve_t<double, true, 0>(b, p, stream);
+        if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);
+        return e;
+    }
     return p.lm.precision == 32 ? launch_solve_t<float, false, 0>(b, p, stream) : launch_solve_t<double, false, 0>(b, p, stream);
 }
 

@@ -277,9 +277,33 @@ def test_gpu_single_pass_device_batch_and_repeatability(fiksi, oracle, ctx):
 
 
 @pytest.mark.gpu
-def test_gpu_single_pass_large_sketch_takes_the_sparse_path(fiksi, oracle, ctx):
-    """A sketch beyond the one-wavefront limits: blocks are found on the host and solved one by one
-    with the sparse device numerics; mixed with small Systems in the same batch."""
+def test_gpu_single_pass_large_system_with_a_large_block(fiksi, oracle, ctx):
+    """A closed chain of 40 points with only neighbour distances: 80 variables, one block of 40
+    expressions and 80 free variables — the System is too large for LDS AND its block is too large for
+    one wavefront, so it is solved block by block through the sparse path."""
+    from fiksi_amd import System, abi, constraints, elements, workloads
+
+    s = System()
+    n = 40
+    pts = [elements.Point.create(s, 10. * math.cos(2 * math.pi * i / n) + 0.3 * math.sin(7. * i),
+                                 10. * math.sin(2 * math.pi * i / n) + 0.3 * math.cos(5. * i)) for i in range(n)]
+    for i in range(n):
+        constraints.PointPointDistance.create(s, pts[i], pts[(i + 1) % n], 1.6)
+    flat = s.flatten()
+    blocks = abi.single_pass_blocks(flat, 0)
+    assert len(blocks) == 1 and len(blocks[0][2]) == 80
+    b = workloads.concat([flat, workloads.hinged_triangles(2, 4)])
+    v, res = ctx.system_solve_batch(b, _sp_opts(fiksi))
+    v_o, res_o = oracle.solve_single_pass_batch(b, trial_cap=4096)
+    assert np.array_equal(res["accepted"], res_o["accepted"]) and np.array_equal(res["exit"], res_o["exit"])
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-5, atol=1e-12)
+    assert np.max(np.abs(v - v_o)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_single_pass_large_sketch_is_walked_on_the_device(fiksi, oracle, ctx):
+    """A sketch beyond the LDS limits whose blocks are all small: one wavefront walks its blocks with
+    the System-wide vectors in HBM scratch; mixed with small Systems in the same batch."""
     from fiksi_amd import workloads
 
     b = workloads.concat([workloads.hinged_triangles(3, 5), workloads.large_sketch(150), workloads.ring16(2)])
