@@ -486,71 +486,113 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     std::vector<uint32_t> unit_rows;
     std::vector<uint16_t> unit_vars;
     uint32_t max_unit_free = 0, max_unit_rows = 0;
-    fx::Incidence inc;
-    fx::UnitList units;
-    std::vector<uint32_t> free_sorted;
     // Large Systems: if every block fits the one-wavefront limits the System is walked on the device
     // with its System-wide vectors in an HBM scratch area (the GLOBAL instantiation); otherwise it
     // stays with the host-driven sparse path.
     std::vector<uint32_t> g_list, g_off;
     std::vector<uint8_t> g_ok(n, 0);
     uint32_t g_total = 0, max_unit_free_g = 0, max_unit_rows_g = 0;
-    for (uint32_t s = 0; s < n; ++s) {
-        sys_unit_off[s] = (uint32_t)desc.size();
-        const size_t desc_mark = desc.size(), rows_mark = unit_rows.size(), vars_mark = unit_vars.size();
-        bool fits = true;
-        uint32_t mf = 0, mrw = 0;
-        const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0;
-        const uint32_t e0 = expr_off[s], net = expr_off[s + 1] - e0;
-        inc.build(nvt, net, expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0);
-        fx::SinglePassDecomposer dec(inc);
-        for (uint32_t c = 0; c < sys_ncomp[s]; ++c) {
-            free_sorted.clear();
-            bool any_var = false;
-            for (uint32_t i = 0; i < nvt; ++i) {
-                uint16_t info = var_info[v0 + i];
-                if ((info & fx::VAR_COMP_MASK) != c) continue;
-                any_var = true;
-                if (!(info & fx::VAR_FIXED_BIT)) free_sorted.push_back(i);
+
+    // Systems are independent: ranges of them are decomposed on separate host threads into local
+    // lists (offsets relative to the range), stitched together in System order afterwards.
+    struct Range {
+        uint32_t s_lo = 0, s_hi = 0;
+        std::vector<fx::UnitDesc> desc;
+        std::vector<uint32_t> rows, desc_count;  // desc_count[s - s_lo]: entries of System s
+        std::vector<uint16_t> vars;
+        std::vector<uint32_t> g_sys, g_nvt;
+        uint32_t max_free = 0, max_rows = 0, max_free_g = 0, max_rows_g = 0;
+    } ranges[MAX_RANGES];
+    uint32_t n_ranges = 1;
+    parallel_ranges(n, (uint64_t)d.n_exprs * 4, [&](uint32_t t, uint32_t s_lo, uint32_t s_hi) {
+        Range& R = ranges[t];
+        R.s_lo = s_lo;
+        R.s_hi = s_hi;
+        R.desc_count.assign(s_hi - s_lo, 0);
+        fx::Incidence inc;
+        fx::UnitList units;
+        std::vector<uint32_t> free_sorted;
+        for (uint32_t s = s_lo; s < s_hi; ++s) {
+            const size_t desc_mark = R.desc.size(), rows_mark = R.rows.size(), vars_mark = R.vars.size();
+            bool fits = true;
+            uint32_t mf = 0, mrw = 0;
+            const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0;
+            const uint32_t e0 = expr_off[s], net = expr_off[s + 1] - e0;
+            inc.build(nvt, net, expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0);
+            fx::SinglePassDecomposer dec(inc);
+            for (uint32_t c = 0; c < sys_ncomp[s]; ++c) {
+                free_sorted.clear();
+                bool any_var = false;
+                for (uint32_t i = 0; i < nvt; ++i) {
+                    uint16_t info = var_info[v0 + i];
+                    if ((info & fx::VAR_COMP_MASK) != c) continue;
+                    any_var = true;
+                    if (!(info & fx::VAR_FIXED_BIT)) free_sorted.push_back(i);
+                }
+                if (!any_var) continue;  // skipped by the reference (`elements.is_empty()`)
+                dec.run(free_sorted, units);
+                if (units.count() == 0) {
+                    R.desc.push_back(fx::UnitDesc{0, 0, 0, 0, (uint16_t)c, (uint16_t)(fx::UNIT_FIRST | fx::UNIT_EMPTY)});
+                    continue;
+                }
+                for (uint32_t u = 0; u < units.count(); ++u) {
+                    fx::UnitDesc ud{};
+                    ud.row_off = (uint32_t)R.rows.size();
+                    ud.var_off = (uint32_t)R.vars.size();
+                    ud.nrows = (uint16_t)(units.row_off[u + 1] - units.row_off[u]);
+                    ud.nvars = (uint16_t)(units.var_off[u + 1] - units.var_off[u]);
+                    ud.comp = (uint16_t)c;
+                    ud.flags = u == 0 ? fx::UNIT_FIRST : 0;
+                    for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k) R.rows.push_back(units.rows[k]);
+                    for (uint32_t k = units.var_off[u]; k < units.var_off[u + 1]; ++k) R.vars.push_back((uint16_t)units.vars[k]);
+                    const uint32_t bf = units.var_off[u + 1] - units.var_off[u], br = units.row_off[u + 1] - units.row_off[u];
+                    fits = fits && bf <= FX_MAX_FREE_VARS && br <= FX_MAX_ROWS;
+                    mf = std::max(mf, bf);
+                    mrw = std::max(mrw, br);
+                    R.desc.push_back(ud);
+                }
             }
-            if (!any_var) continue;  // skipped by the reference (`elements.is_empty()`)
-            dec.run(free_sorted, units);
-            if (units.count() == 0) {
-                desc.push_back(fx::UnitDesc{0, 0, 0, 0, (uint16_t)c, (uint16_t)(fx::UNIT_FIRST | fx::UNIT_EMPTY)});
-                continue;
+            if (!sys_large[s]) {
+                R.max_free = std::max(R.max_free, mf);
+                R.max_rows = std::max(R.max_rows, mrw);
+            } else if (fits) {
+                R.g_sys.push_back(s);
+                R.g_nvt.push_back(nvt);
+                R.max_free_g = std::max(R.max_free_g, mf);
+                R.max_rows_g = std::max(R.max_rows_g, mrw);
+            } else {  // some block is itself too large: the System keeps the sparse path, drop its entries
+                R.desc.resize(desc_mark);
+                R.rows.resize(rows_mark);
+                R.vars.resize(vars_mark);
             }
-            for (uint32_t u = 0; u < units.count(); ++u) {
-                fx::UnitDesc ud{};
-                ud.row_off = (uint32_t)unit_rows.size();
-                ud.var_off = (uint32_t)unit_vars.size();
-                ud.nrows = (uint16_t)(units.row_off[u + 1] - units.row_off[u]);
-                ud.nvars = (uint16_t)(units.var_off[u + 1] - units.var_off[u]);
-                ud.comp = (uint16_t)c;
-                ud.flags = u == 0 ? fx::UNIT_FIRST : 0;
-                for (uint32_t k = units.row_off[u]; k < units.row_off[u + 1]; ++k) unit_rows.push_back(units.rows[k]);
-                for (uint32_t k = units.var_off[u]; k < units.var_off[u + 1]; ++k) unit_vars.push_back((uint16_t)units.vars[k]);
-                const uint32_t bf = units.var_off[u + 1] - units.var_off[u], br = units.row_off[u + 1] - units.row_off[u];
-                fits = fits && bf <= FX_MAX_FREE_VARS && br <= FX_MAX_ROWS;
-                mf = std::max(mf, bf);
-                mrw = std::max(mrw, br);
-                desc.push_back(ud);
-            }
+            R.desc_count[s - s_lo] = (uint32_t)(R.desc.size() - desc_mark);
         }
-        if (!sys_large[s]) {
-            max_unit_free = std::max(max_unit_free, mf);
-            max_unit_rows = std::max(max_unit_rows, mrw);
-        } else if (fits) {
-            g_ok[s] = 1;
-            g_list.push_back(s);
+    }, &n_ranges);
+    for (uint32_t t = 0; t < n_ranges; ++t) {
+        Range& R = ranges[t];
+        const uint32_t row_base = (uint32_t)unit_rows.size(), var_base = (uint32_t)unit_vars.size();
+        uint32_t at = (uint32_t)desc.size();
+        for (uint32_t s = R.s_lo; s < R.s_hi; ++s) {
+            sys_unit_off[s] = at;
+            at += R.desc_count[s - R.s_lo];
+        }
+        for (fx::UnitDesc ud : R.desc) {
+            ud.row_off += row_base;
+            ud.var_off += var_base;
+            desc.push_back(ud);
+        }
+        unit_rows.insert(unit_rows.end(), R.rows.begin(), R.rows.end());
+        unit_vars.insert(unit_vars.end(), R.vars.begin(), R.vars.end());
+        for (size_t k = 0; k < R.g_sys.size(); ++k) {
+            g_ok[R.g_sys[k]] = 1;
+            g_list.push_back(R.g_sys[k]);
             g_off.push_back(g_total);
-            g_total += nvt;
-            max_unit_free_g = std::max(max_unit_free_g, mf);
-            max_unit_rows_g = std::max(max_unit_rows_g, mrw);
-        } else {  // some block is itself too large: the System keeps the sparse path, drop its entries
-            desc.resize(desc_mark);
-            unit_rows.resize(rows_mark);
-            unit_vars.resize(vars_mark);
+            g_total += R.g_nvt[k];
         }
+        max_unit_free = std::max(max_unit_free, R.max_free);
+        max_unit_rows = std::max(max_unit_rows, R.max_rows);
+        max_unit_free_g = std::max(max_unit_free_g, R.max_free_g);
+        max_unit_rows_g = std::max(max_unit_rows_g, R.max_rows_g);
     }
     sys_unit_off[n] = (uint32_t)desc.size();
     int rc = dev_alloc_copy(ctx, db, &d.unit_desc, desc.data(), desc.size());

@@ -972,7 +972,8 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
         }
     }
     __syncthreads();
-    if (live) b.resid[row0 + threadIdx.x] = rstage[threadIdx.x];
+    // results are written once and not read back by this kernel: streaming (non-temporal) stores
+    if (live) __builtin_nontemporal_store(rstage[threadIdx.x], &b.resid[row0 + threadIdx.x]);
     if (WANT_J) {
         // 16-byte stores on the 16-byte-aligned body of [jbase, jend), scalar head / tail
         const uint32_t n = bi.jcount;
@@ -982,10 +983,9 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
         const uint32_t pairs = (n - min(n, head)) >> 1;
         double2* dst = reinterpret_cast<double2*>(b.jvals + jbase + head);
         for (uint32_t i = threadIdx.x; i < pairs; i += 256u) {
-            double2 t;
-            t.x = jstage[head + 2 * i];
-            t.y = jstage[head + 2 * i + 1];
-            dst[i] = t;
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d t = {jstage[head + 2 * i], jstage[head + 2 * i + 1]};
+            __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(dst + i));
         }
         if (((n - min(n, head)) & 1u) && threadIdx.x == 1) b.jvals[jend - 1] = jstage[n - 1];
     }
