@@ -201,6 +201,8 @@ def main() -> int:
                         "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d)",
             },
         }
+        if world == 1:
+            out["other_workloads"] = other_workloads(ctx, abi, workloads, np, n_sys)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -211,6 +213,31 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def other_workloads(ctx, abi, workloads, np, n_sys: int):
+    """Reported beside the headline, never part of `value`: the reference's own bench generator
+    (`add_hinged_triangles(n = 11)`, fiksi_bench.rs:15-40: 33 distance constraints, 46 variables) as a
+    batch of the same size, with Decomposer::None and Decomposer::SinglePass; N = 1 runs only."""
+    out = {}
+    b = workloads.hinged_triangles(n_sys, 11)
+    db = ctx.upload(b)
+    for label, opts in (("none", abi.solving_opts()), ("single_pass", abi.solving_opts(decomposer=1))):
+        db.system_solve(opts)  # warm-up (SinglePass: builds the block plan)
+        ctx.synchronize()
+        reps = 3
+        ctx.timer_begin()
+        for _ in range(reps):
+            db.system_solve(opts)
+        ms = ctx.timer_end() / reps
+        res = db.get_results()
+        conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+        out[f"hinged_triangles_11_{label}"] = {
+            "systems": n_sys, "ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3),
+            "converged_fraction": conv / n_sys, "gn_iters_per_sec": int(res["accepted"].sum()) / (ms * 1e-3),
+        }
+    db.free()
+    return out
 
 
 def pmc_traffic(kernel_substr: str, n_sys: int):
