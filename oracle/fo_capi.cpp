@@ -390,6 +390,27 @@ int fo_single_pass_units(uint32_t nvars, uint32_t nexprs, const uint8_t* var_fix
     return static_cast<int>(sccs.size());
 }
 
+// equations.rs:293-320 on a raw bipartite graph: expression e reads variables evars[eptr[e] .. eptr[e+1]).
+// a_to_b[v] = matched expression or 0xFFFFFFFF. Returns the cardinality.
+int fo_maximum_matching(uint32_t nvars, uint32_t nexprs, const uint32_t* eptr, const uint32_t* evars, uint32_t nfree,
+                        const uint32_t* free_sorted, uint32_t* a_to_b) {
+    ExpressionGraph g;
+    g.variables.resize(nvars);
+    g.expressions.resize(nexprs);
+    for (uint32_t e = 0; e < nexprs; ++e)
+        for (uint32_t p = eptr[e]; p < eptr[e + 1]; ++p) {
+            g.expressions[e].push_back(evars[p]);
+            g.variables[evars[p]].push_back(e);
+        }
+    std::vector<uint32_t> m = find_maximum_matching(g, std::vector<uint32_t>(free_sorted, free_sorted + nfree));
+    int card = 0;
+    for (uint32_t v = 0; v < nvars; ++v) {
+        a_to_b[v] = m[v];
+        card += m[v] != 0xFFFFFFFFu;
+    }
+    return card;
+}
+
 // permutation.rs:41-80: applies the gather permutation to `values` in place through the swap
 // sequence; returns the number of swaps.
 int fo_permute(uint32_t n, const uint32_t* permutation, double* values) {

@@ -174,6 +174,25 @@ struct Tarjan {  // equations.rs:465-549 (Pearce's Algorithm 3)
 
 }  // namespace sp_detail
 
+// equations.rs:293-320 (`find_maximum_matching`): variable -> expression (UNMATCHED = 0xFFFFFFFF).
+inline std::vector<uint32_t> find_maximum_matching(const ExpressionGraph& g, const std::vector<uint32_t>& free_sorted) {
+    using namespace sp_detail;
+    std::vector<uint8_t> is_free(g.variables.size(), 0);
+    for (uint32_t v : free_sorted) is_free[v] = 1;
+    Masked m{g, free_sorted, is_free};
+    Matching mt;
+    mt.a_to_b.assign(g.variables.size(), UNMATCHED);
+    mt.b_to_a.assign(g.expressions.size(), UNMATCHED);
+    std::vector<uint32_t> distance(g.variables.size(), INF);
+    uint32_t dummy = INF;
+    while (bfs(m, mt, distance, dummy)) {
+        for (uint32_t a : free_sorted) {
+            if (mt.a_to_b[a] == UNMATCHED) dfs(m, mt, distance, dummy, a);
+        }
+    }
+    return mt.a_to_b;
+}
+
 // equations.rs:186-221
 inline std::vector<StronglyConnectedExpressions> find_strongly_connected_expressions(
     const ExpressionGraph& g, const std::vector<uint32_t>& free_sorted) {

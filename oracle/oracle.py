@@ -263,3 +263,16 @@ def permute(permutation, values):
     vals = np.ascontiguousarray(values, dtype=np.float64).copy()
     n = lib().fo_permute(C.c_uint32(len(perm)), _p(perm), _p(vals))
     return vals, n
+
+
+def maximum_matching(nvars: int, expressions, free=None):
+    """find_maximum_matching on a raw bipartite graph: `expressions` = list of variable lists.
+    Returns (cardinality, variable -> expression or -1)."""
+    eptr = np.zeros(len(expressions) + 1, dtype=np.uint32)
+    eptr[1:] = np.cumsum([len(e) for e in expressions])
+    evars = np.asarray([v for e in expressions for v in e], dtype=np.uint32)
+    fr = np.asarray(sorted(range(nvars) if free is None else free), dtype=np.uint32)
+    out = np.zeros(max(nvars, 1), dtype=np.uint32)
+    card = lib().fo_maximum_matching(C.c_uint32(nvars), C.c_uint32(len(expressions)), _p(eptr), _p(evars),
+                                     C.c_uint32(len(fr)), _p(fr), _p(out))
+    return card, [int(x) if x != 0xFFFFFFFF else -1 for x in out[:nvars]]

@@ -65,6 +65,19 @@ def _oracle_blocks(oracle, b, system=0):
 
 # ---- CPU: the oracle against the reference's own SinglePass tests --------------------------------
 
+def test_oracle_maximum_matching_known_answer(oracle):
+    """equations.rs:574-601: three variables, expressions on (0,1), (0,2), (1): a perfect matching of
+    size 3, every pair an edge of the graph, no expression used twice."""
+    exprs = [[0, 1], [0, 2], [1]]
+    card, a_to_b = oracle.maximum_matching(3, exprs)
+    assert card == 3
+    assert sorted(a_to_b) == [0, 1, 2]
+    assert all(v in exprs[e] for v, e in enumerate(a_to_b))
+    # masking a variable out (fixed) leaves a maximum matching of the rest
+    card, a_to_b = oracle.maximum_matching(3, exprs, free=[0, 2])
+    assert card == 2 and a_to_b[1] == -1
+
+
 def test_oracle_single_pass_meets_reference_test_thresholds(oracle, fiksi):
     sk = _reference_sketches(fiksi)
     for name, s in sk.items():
