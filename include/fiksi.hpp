@@ -69,6 +69,21 @@ struct ConstraintHandle {  // constraints/mod.rs:62-69
     uint32_t system_id, id;
 };
 
+// AnyElementHandle / AnyConstraintHandle (elements/mod.rs:114-245, constraints/mod.rs:170-315): a handle
+// whose kind is only known at run time.
+struct AnyElementHandle {
+    uint32_t system_id, id;
+    fxs_element_tag tag;
+};
+struct AnyConstraintHandle {
+    uint32_t system_id, id;
+    fxs_constraint_tag tag;
+};
+// System::analyze's result (analyze/mod.rs): the constraints found to over-constrain the System.
+struct Analysis {
+    std::vector<AnyConstraintHandle> overconstrained;
+};
+
 class System {
   public:
     System() {
@@ -92,6 +107,32 @@ class System {
         o.perturb = opts.perturb ? 1u : 0u;
         int rc = fxs_system_solve(h_, ctx ? ctx : default_context(), &o, &last_result);
         if (rc) throw Error(rc, "System::solve");
+    }
+
+    // lib.rs:331-345, :347-361
+    std::vector<AnyElementHandle> get_element_handles() const {
+        std::vector<AnyElementHandle> out;
+        for (uint32_t i = 0, n = fxs_num_elements(h_); i < n; ++i)
+            out.push_back({id(), i, static_cast<fxs_element_tag>(fxs_element_tag_of(h_, i))});
+        return out;
+    }
+    std::vector<AnyConstraintHandle> get_constraint_handles() const {
+        std::vector<AnyConstraintHandle> out;
+        for (uint32_t i = 0, n = fxs_num_constraints(h_); i < n; ++i)
+            out.push_back({id(), i, static_cast<fxs_constraint_tag>(fxs_constraint_tag_of(h_, i))});
+        return out;
+    }
+
+    // lib.rs:454-459 (doc-hidden in the reference: all variables are treated as free)
+    Analysis analyze(fx_ctx* ctx = nullptr) const {
+        std::vector<uint32_t> ids(fxs_num_expressions(h_) + 1, 0u);
+        uint32_t n = 0;
+        int rc = fxs_system_analyze(h_, ctx ? ctx : default_context(), ids.data(), &n);
+        if (rc) throw Error(rc, "System::analyze");
+        Analysis a;
+        for (uint32_t k = 0; k < n; ++k)
+            a.overconstrained.push_back({id(), ids[k], static_cast<fxs_constraint_tag>(fxs_constraint_tag_of(h_, ids[k]))});
+        return a;
     }
 
     std::vector<double> constraint_residuals(fx_ctx* ctx = nullptr) const {

@@ -111,6 +111,27 @@ int main(int argc, char** argv) {
         CHECK(get_value(q3, w).x == 5. && get_value(q3, w).y == 5.);
     }
 
+    // System::analyze, the reference's `overconstrained` test (tests/basic.rs:88-112): four points, six
+    // pairwise distances -> the constraint added last is designated
+    {
+        System w;
+        auto q0 = elements::create_point(w, 0.123, 0.1);
+        auto q1 = elements::create_point(w, 1.2, 0.);
+        auto q2 = elements::create_point(w, -0.5, 1.1);
+        auto q3 = elements::create_point(w, 1.599, 1.2);
+        constraints::create_point_point_distance(w, q0, q1, 1.);
+        constraints::create_point_point_distance(w, q0, q2, 1.5);
+        constraints::create_point_point_distance(w, q1, q3, 1.7);
+        constraints::create_point_point_distance(w, q2, q3, 1.2);
+        constraints::create_point_point_distance(w, q1, q2, 2.);
+        auto q0q3 = constraints::create_point_point_distance(w, q0, q3, 5.);
+        CHECK(w.get_element_handles().size() == 4 && w.get_element_handles()[1].tag == FXS_POINT);
+        CHECK(w.get_constraint_handles().size() == 6);
+        Analysis an = w.analyze();
+        CHECK(an.overconstrained.size() == 1 && an.overconstrained[0].id == q0q3.id);
+        CHECK(an.overconstrained.size() == 1 && an.overconstrained[0].tag == FXS_POINT_POINT_DISTANCE);
+    }
+
     // unsupported arms are errors, not silent fallbacks
     threw = false;
     try {
