@@ -236,6 +236,7 @@ struct SpChol {                  // symbolic factor (device)
     const int32_t* l2a;          // [nnzL] index into A or -1 (fill-in)
     const uint32_t* lpair_ptr;   // [nnzL+1]
     const uint32_t* lpairs;      // [2*npairs] indices into L
+    const uint8_t* coop;         // [nv] 1 = the column's gather lists are long: the whole wavefront sums each one
     uint32_t nv;
 };
 
@@ -289,6 +290,18 @@ __global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsO
                 int32_t ai = c.l2a[k];
                 s = ai >= 0 ? a[ai] : 0.0;
                 if (k == beg) s += lambda;
+            }
+            if (c.coop[j]) {
+                // separator columns: few entries, each the sum of hundreds of products (every column of
+                // the neighbouring subtrees contributes) — lanes stride over one list at a time
+                for (uint32_t t = beg; t < end; ++t) {
+                    double part = 0.0;
+                    for (uint32_t p = c.lpair_ptr[t] + lane; p < c.lpair_ptr[t + 1]; p += 64)
+                        part = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), part);
+                    part = wave_sum64(part);
+                    if (k == t) s += part;
+                }
+            } else if (k < end) {
                 for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
                     s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
             }
@@ -579,6 +592,7 @@ struct ComponentPlan {
     std::vector<uint32_t> cptr, cidx, crow;            // columns of J (permuted order) for the rhs
     std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs;
     std::vector<int32_t> l2a;
+    std::vector<uint8_t> coop;                         // per column: sum its gather lists cooperatively
     std::vector<uint32_t> rptr, ridx, rcol;            // strictly lower part of L by rows
     std::vector<uint32_t> list_ptr, list_cols;         // work lists of the elimination-tree schedule
     std::vector<uint32_t> level_ptr;                   // lists of level v: [level_ptr[v], level_ptr[v+1])
@@ -744,6 +758,19 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
                 }
     }
 
+    // --- how a column sums its gather lists: one lane per entry (cost ~ the longest list), or the whole
+    // wavefront on one list after the other (cost ~ sum over entries of ceil(len / 64) + a reduction)
+    P.coop.assign(P.nv, 0);
+    for (uint32_t j = 0; j < P.nv; ++j) {
+        uint64_t longest = 0, coop_cost = 0;
+        for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) {
+            uint64_t len = P.lpair_ptr[k + 1] - P.lpair_ptr[k];
+            longest = std::max(longest, len);
+            coop_cost += (len + 63) / 64 + 4;
+        }
+        P.coop[j] = (P.lcolptr[j + 1] - P.lcolptr[j] <= 64u && longest > 2 * coop_cost) ? 1 : 0;
+    }
+
     // --- L by rows (forward sweep gathers)
     P.rptr.assign((size_t)P.nv + 1, 0);
     for (uint32_t j = 0; j < P.nv; ++j)
@@ -771,8 +798,15 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
     std::vector<uint64_t> work(P.nv, 0), subtree(P.nv, 0);
     uint64_t total = 0;
     for (uint32_t j = 0; j < P.nv; ++j) {
-        uint64_t w = 8;  // per-column latency floor
-        for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) w += 1 + (P.lpair_ptr[k + 1] - P.lpair_ptr[k]);
+        // critical-path cost of the column in "list elements": lanes work in parallel, so what counts is
+        // the longest list (per-lane mode) or the strided passes over all lists (cooperative mode)
+        uint64_t longest = 0, coop_cost = 0;
+        for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) {
+            uint64_t len = P.lpair_ptr[k + 1] - P.lpair_ptr[k];
+            longest = std::max(longest, len);
+            coop_cost += (len + 63) / 64 + 4;
+        }
+        uint64_t w = 8 + (P.coop[j] ? coop_cost : longest);  // 8 = per-column latency floor
         work[j] = w;
         total += w;
     }
@@ -1005,6 +1039,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         chol.l2a = pool.up(P.l2a);
         chol.lpair_ptr = pool.up(P.lpair_ptr);
         chol.lpairs = pool.up(P.lpairs);
+        chol.coop = pool.up(P.coop);
         chol.nv = nv;
         SpRowsOfL lrows;
         lrows.rptr = pool.up(P.rptr);
@@ -1152,9 +1187,11 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         if (trace) {
             const auto t_end = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
-            fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u, %zu lists in %zu levels; plan %.2f ms, "
-                            "upload+LM %.2f ms (%u trials)\n",
-                    m, nv, P.nnz_j, P.nnz_a, P.nnz_l, P.list_ptr.size() - 1, P.level_ptr.size() - 1, ms(t_plan0, t_plan1),
+            fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u (%zu products, %u cooperative columns), "
+                            "%zu lists in %zu levels; plan %.2f ms, upload+LM %.2f ms (%u trials)\n",
+                    m, nv, P.nnz_j, P.nnz_a, P.nnz_l, P.lpairs.size() / 2,
+                    (unsigned)std::count(P.coop.begin(), P.coop.end(), (uint8_t)1), P.list_ptr.size() - 1,
+                    P.level_ptr.size() - 1, ms(t_plan0, t_plan1),
                     ms(t_plan1, t_end), trials);
         }
         res.accepted += accepted;
