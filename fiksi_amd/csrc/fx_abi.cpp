@@ -902,9 +902,7 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     if (o.optimizer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown optimizer %u (0 = LevenbergMarquardt, 1 = LBfgs)", o.optimizer);
     if (o.optimizer == 1 && o.lm.precision == 32)
         return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs runs in f64 only");
-    if (o.optimizer == 1 && db->n_large)
-        return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs is implemented for Systems within the one-wavefront limits only "
-                                        "(%u System(s) of this batch exceed them)", db->n_large);
+
     if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
     fx::LmParams p;
     p.lm = o.lm;

@@ -30,6 +30,7 @@
 #include "fx_decompose.h"
 #include "fx_device.h"
 #include "fx_expr.h"
+#include "fx_lbfgs.h"
 #include "fx_sparse.h"
 
 namespace fx {
@@ -155,6 +156,8 @@ struct SpJac {                   // J of one component (device)
     const uint32_t* jrow_ptr;    // [m+1]
     const uint32_t* jslot;       // [m] 8 x 4-bit slot of each gradient entry (0xF = not a free column)
     uint32_t m;
+    int overwrite;               // entries sharing a column: 0 = summed (sparse J, sparse_col_mat.rs:710-711),
+                                 // 1 = the last one wins (dense J of L-BFGS, expressions.rs:993-1008) — quirk Q4
 };
 
 // K1/K2 for one component: thread per row (subsystem.rs:93-166).
@@ -182,7 +185,10 @@ __global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, co
         for (int q = 0; q < 8; ++q) {
             uint32_t sl = (slots >> (4 * q)) & 0xFu;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) out[t] += (sl == (uint32_t)t) ? g[q] : 0.0;
+            for (int t = 0; t < 8; ++t) {
+                if (jac.overwrite) out[t] = (sl == (uint32_t)t) ? g[q] : out[t];
+                else out[t] += (sl == (uint32_t)t) ? g[q] : 0.0;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -216,14 +222,106 @@ __global__ void sp_form_a_kernel(const uint32_t* __restrict__ pair_ptr, const ui
 }
 
 // K3b: b[c] = -sum_{rows of column c} J * r   (permuted column order)
+template <bool NEGATE>
 __global__ void sp_rhs_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx,
                               const uint32_t* __restrict__ crow, const double* __restrict__ jvals,
                               const double* __restrict__ r, uint32_t nv, double* __restrict__ b) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nv) return;
     double s = 0.0;
-    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * (-r[crow[p]]);
+    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * (NEGATE ? -r[crow[p]] : r[crow[p]]);
     b[c] = s;
+}
+
+// ---- Optimizer::LBfgs on one large block: vectors in (permuted) column space, one workgroup ----------
+__device__ __forceinline__ double block_sum_1024(double v, double* sh) {
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    double out = sh[0];
+    __syncthreads();
+    return out;
+}
+
+// out[0] = sum a_i b_i (fixed-shape tree: deterministic)
+__global__ __launch_bounds__(1024) void sp_dot_kernel(const double* __restrict__ a, const double* __restrict__ b, uint32_t n,
+                                                      double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
+    s = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ void sp_scaled_copy_kernel(const double* __restrict__ x, double alpha, uint32_t n, double* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = alpha * x[i];
+}
+
+// The two-loop recursion (lbfgs.rs:86-139) for iteration k: dir = -H_k grad, with the reference's ring
+// indexing (k + i) % 5 (unwritten slots are zero) and the gamma scaling from the previous pair.
+__global__ __launch_bounds__(1024) void sp_lbfgs_direction_kernel(uint32_t k, uint32_t n, const double* __restrict__ S,
+                                                                 const double* __restrict__ Y, const double* __restrict__ rho,
+                                                                 const double* __restrict__ grad, double* __restrict__ dir) {
+    __shared__ double sh[1024];
+    const uint32_t hl = k < 5u ? k : 5u;
+    double alpha[5] = {0., 0., 0., 0., 0.};
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) dir[i] = grad[i];
+    __syncthreads();
+    for (int i = 4; i >= 0; --i) {
+        if ((uint32_t)i >= hl) continue;
+        const uint32_t h = (k + (uint32_t)i) % 5u;
+        double part = 0.0;
+        for (uint32_t j = threadIdx.x; j < n; j += 1024) part += S[(size_t)h * n + j] * dir[j];
+        alpha[i] = rho[h] * block_sum_1024(part, sh);
+        for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] -= alpha[i] * Y[(size_t)h * n + j];
+        __syncthreads();
+    }
+    if (k > 0) {
+        const uint32_t h = (k - 1u) % 5u;
+        double p1 = 0.0, p2 = 0.0;
+        for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+            double yv = Y[(size_t)h * n + j];
+            p1 += S[(size_t)h * n + j] * yv;
+            p2 += yv * yv;
+        }
+        double s_dot_y = block_sum_1024(p1, sh), y_dot_y = block_sum_1024(p2, sh);
+        if (y_dot_y > 0.) {
+            double scale = s_dot_y / y_dot_y;
+            for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] *= scale;
+        }
+        __syncthreads();
+    }
+    for (int i = 0; i < 5; ++i) {
+        if ((uint32_t)i >= hl) continue;
+        const uint32_t h = (k + (uint32_t)i) % 5u;
+        double part = 0.0;
+        for (uint32_t j = threadIdx.x; j < n; j += 1024) part += Y[(size_t)h * n + j] * dir[j];
+        double beta = rho[h] * block_sum_1024(part, sh);
+        for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] += S[(size_t)h * n + j] * (alpha[i] - beta);
+        __syncthreads();
+    }
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] *= -1.;
+}
+
+// s_k = step * dir, y_k = grad - (old gradient parked in Y[h]), rho_k = 1 / s_k.y_k   (lbfgs.rs:168-180)
+__global__ __launch_bounds__(1024) void sp_lbfgs_update_kernel(uint32_t h, uint32_t n, double step, const double* __restrict__ dir,
+                                                              const double* __restrict__ grad, double* __restrict__ S,
+                                                              double* __restrict__ Y, double* __restrict__ rho) {
+    __shared__ double sh[1024];
+    double part = 0.0;
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+        double sk = step * dir[j];
+        double yk = grad[j] - Y[(size_t)h * n + j];
+        S[(size_t)h * n + j] = sk;
+        Y[(size_t)h * n + j] = yk;
+        part += sk * yk;
+    }
+    double s_dot_y = block_sum_1024(part, sh);
+    if (threadIdx.x == 0) rho[h] = 1.0 / s_dot_y;
 }
 
 __device__ __forceinline__ double ld_l2(const double* p) {  // L2-coherent load (bypasses the CU's L1)
@@ -912,6 +1010,7 @@ inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block 
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
                                double* d_vars_out /* device, n_vars of the System */, fx_result* result) {
     const bool single_pass = (prm.mode & MODE_UNITS) != 0;
+    const bool lbfgs = (prm.mode & MODE_LBFGS) != 0;
     const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;  // diagnostics on stderr
     const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
     const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
@@ -1028,6 +1127,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         jac.jrow_ptr = pool.up(P.jrow_ptr);
         jac.jslot = pool.up(P.jslot);
         jac.m = m;
+        jac.overwrite = lbfgs ? 1 : 0;
         uint32_t* d_apair_ptr = pool.up(P.apair_ptr);
         uint32_t* d_apairs = pool.up(P.apairs);
         uint32_t* d_cptr = pool.up(P.cptr);
@@ -1072,7 +1172,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         };
         auto form = [&](int buf) {
             if (P.nnz_a) hipLaunchKernelGGL(sp_form_a_kernel, grid_for(P.nnz_a), dim3(256), 0, stream, d_apair_ptr, d_apairs, d_j[buf], P.nnz_a, d_a);
-            if (nv) hipLaunchKernelGGL(sp_rhs_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf], d_r[buf], nv, d_rhs);
+            if (nv) hipLaunchKernelGGL(sp_rhs_kernel<true>, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf], d_r[buf], nv, d_rhs);
         };
 
         int cur = 0;
@@ -1080,9 +1180,85 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         e = eval(0, true, &sse);
         if (e != hipSuccess) return e;
         const double sse_start = sse;
+        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
+        if (lbfgs) {
+            // ---- Optimizer::LBfgs (lbfgs.rs:20-193): the host runs the line-search state machine on two
+            // scalars per evaluation, everything else is on the device
+            double* d_grad = pool.alloc<double>(nv);
+            double* d_dir = pool.alloc<double>(nv);
+            double* d_s = pool.alloc<double>(5 * (size_t)nv);
+            double* d_y = pool.alloc<double>(5 * (size_t)nv);
+            double* d_rho = pool.alloc<double>(8);
+            if (pool.err != hipSuccess) return pool.err;
+            e = hipMemsetAsync(d_s, 0, 5 * (size_t)nv * sizeof(double), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_y, 0, 5 * (size_t)nv * sizeof(double), stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_rho, 0, 8 * sizeof(double), stream);
+            if (e != hipSuccess) return e;
+            auto gradient = [&](int buf) {
+                if (nv) hipLaunchKernelGGL(sp_rhs_kernel<false>, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf],
+                                           d_r[buf], nv, d_grad);
+            };
+            trials = 1;
+            double prev = sse;
+            if (!(prev == prev)) {
+                exit_code = FX_EXIT_NAN;
+            } else if (prev < LbfgsConst::START_THRESHOLD) {
+                exit_code = FX_EXIT_SSE;
+            } else {
+                gradient(0);
+                for (uint32_t k = 0; k < LbfgsConst::MAX_ITERATIONS; ++k) {
+                    const uint32_t h = k % 5u;
+                    hipLaunchKernelGGL(sp_lbfgs_direction_kernel, dim3(1), dim3(1024), 0, stream, k, nv, d_s, d_y, d_rho, d_grad, d_dir);
+                    e = hipMemcpyAsync(d_y + (size_t)h * nv, d_grad, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(sp_dot_kernel, dim3(1), dim3(1024), 0, stream, d_grad, d_dir, nv, d_scal + 6);
+                    e = hipMemcpyAsync(host3, d_scal + 6, sizeof(double), hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    if (e != hipSuccess) return e;
+                    HzMachine hz;
+                    double step = hz.start(prev, host3[0]);
+                    HzParam acc_pt{0., 0., 0.};
+                    for (;;) {  // calculate_phi (lbfgs.rs:270-284): xs[1] = xs[0] + step * dir
+                        if (nv) {
+                            hipLaunchKernelGGL(sp_scaled_copy_kernel, grid_for(nv), dim3(256), 0, stream, d_dir, step, nv, d_delta);
+                            hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[0], d_xs[1]);
+                        }
+                        if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[1], d_r[1], d_j[1]);
+                        hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[1], m, d_scal + 5);
+                        gradient(1);
+                        hipLaunchKernelGGL(sp_dot_kernel, dim3(1), dim3(1024), 0, stream, d_grad, d_dir, nv, d_scal + 6);
+                        e = hipMemcpyAsync(host3, d_scal + 5, 2 * sizeof(double), hipMemcpyDeviceToHost, stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                        if (e != hipSuccess) return e;
+                        trials += 1;
+                        if (hz.feed(HzParam{step, host3[0], host3[1]}, step, acc_pt)) break;
+                    }
+                    if (nv) hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[1], d_xs[0]);
+                    hipLaunchKernelGGL(sp_lbfgs_update_kernel, dim3(1), dim3(1024), 0, stream, h, nv, acc_pt.p, d_dir, d_grad, d_s, d_y, d_rho);
+                    accepted += 1;
+                    sse = acc_pt.phi;
+                    if (hz.capped) {
+                        exit_code = FX_EXIT_TRIAL_CAP;
+                        break;
+                    }
+                    if (!(acc_pt.phi == acc_pt.phi)) {
+                        exit_code = FX_EXIT_NAN;
+                        break;
+                    }
+                    if (std::fabs(prev - acc_pt.phi) < LbfgsConst::CONVERGENCE_THRESHOLD) {
+                        exit_code = FX_EXIT_FTOL;
+                        break;
+                    }
+                    if (acc_pt.phi < LbfgsConst::RESIDUAL_THRESHOLD) {
+                        exit_code = FX_EXIT_SSE;
+                        break;
+                    }
+                    prev = acc_pt.phi;
+                }
+            }
+        } else {
         form(0);
         double lambda = o.lambda0;
-        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
         bool done = false;
         if (!(sse == sse) || !(sse < 1.0e300)) {
             exit_code = FX_EXIT_NAN;
@@ -1171,6 +1347,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 }
             }
         }
+        }  // optimizer
         if (nv) {
             hipLaunchKernelGGL(sp_writeback_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_scal, do_scale, d_vars_out);
             if (single_pass) {

@@ -133,7 +133,7 @@ typedef struct fx_lm_opts {
 } fx_lm_opts;
 
 /* SolvingOptions (fiksi/src/lib.rs:205-237). optimizer: 0 = LevenbergMarquardt, 1 = LBfgs
- * (solve/lbfgs.rs; f64, Systems within the one-wavefront limits; fx_result.accepted counts its
+ * (solve/lbfgs.rs; f64 only; fx_result.accepted counts its
  * iterations, .trials its residual+Jacobian evaluations); decomposer: 0 = None, 1 = SinglePass (assemble/mod.rs:169-210:
  * maximum matching + strongly connected blocks, solved one after the other); 2 =
  * RecursiveAssembly is reported as FX_ERR_UNSUPPORTED. */
