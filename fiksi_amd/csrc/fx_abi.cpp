@@ -43,8 +43,10 @@ struct HostPlan {
     uint64_t nnz = 0;
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
     std::vector<uint16_t> sys_ncomp;
-    std::vector<uint8_t> sys_large;  // components beyond the one-wavefront limits -> sparse path
-    uint32_t n_large = 0;
+    std::vector<uint8_t> sys_large;  // 0 fused kernel, 2 wide kernel (65..128 free variables), 1 sparse path
+    uint32_t n_large = 0;            // Systems with sys_large != 0
+    std::vector<uint32_t> wide_list;
+    uint32_t w_max_free = 0, w_max_vars = 0, w_max_rows = 0;
     std::vector<uint16_t> var_info;
     std::vector<uint16_t> expr_comp;
     std::vector<uint16_t> expr_idx16;
@@ -194,6 +196,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     struct Partial {
         uint64_t nnz = 0;
         uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0, n_large = 0;
+        uint32_t w_max_free = 0, w_max_rows = 0, w_max_vars = 0;
         int err = FX_OK;
         uint32_t err_system = 0;
         char msg[192] = {0};
@@ -307,11 +310,22 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 }
             }
             if (pt.err != FX_OK) break;
-            for (uint32_t c = 0; c < ncomp; ++c)
-                large = large || comp_free[c] > FX_MAX_FREE_VARS || comp_rows[c] > FX_MAX_ROWS;
+            bool wide = false;  // more than one wavefront's columns, but still an LDS-resident dense problem
+            uint32_t cf_max = 0, cr_max = 0;
+            for (uint32_t c = 0; c < ncomp; ++c) {
+                cf_max = std::max(cf_max, comp_free[c]);
+                cr_max = std::max(cr_max, comp_rows[c]);
+            }
+            if (!large && cr_max <= FX_MAX_ROWS && cf_max > FX_MAX_FREE_VARS && cf_max <= FX_MAX_WIDE_FREE_VARS) wide = true;
+            large = large || cf_max > FX_MAX_FREE_VARS || cr_max > FX_MAX_ROWS;
             if (large) {
-                p.sys_large[s] = 1;
+                p.sys_large[s] = wide ? 2 : 1;
                 pt.n_large += 1;
+                if (wide) {
+                    pt.w_max_free = std::max(pt.w_max_free, cf_max);
+                    pt.w_max_rows = std::max(pt.w_max_rows, cr_max);
+                    pt.w_max_vars = std::max(pt.w_max_vars, nvt);
+                }
             } else {  // LDS layout and kernel instantiation are sized by the one-wavefront systems only
                 pt.max_vars = std::max(pt.max_vars, nvt);
                 pt.max_exprs = std::max(pt.max_exprs, net);
@@ -333,7 +347,12 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         p.max_exprs = std::max(p.max_exprs, part[t].max_exprs);
         p.max_vars_all = std::max(p.max_vars_all, part[t].max_vars_all);
         p.max_exprs_all = std::max(p.max_exprs_all, part[t].max_exprs_all);
+        p.w_max_free = std::max(p.w_max_free, part[t].w_max_free);
+        p.w_max_rows = std::max(p.w_max_rows, part[t].w_max_rows);
+        p.w_max_vars = std::max(p.w_max_vars, part[t].w_max_vars);
     }
+    for (uint32_t s = 0; s < n; ++s)
+        if (p.sys_large[s] == 2) p.wide_list.push_back(s);
     // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
     const uint32_t nblk = (ne + 255u) / 256u;
     p.blk_info.assign(nblk, fx::BlockInfo{});
@@ -624,11 +643,21 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
 }
 
 // Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
+// the wide kernel covers f64 Levenberg-Marquardt without a decomposer
+bool wide_kernel_applies(const fx::LmParams& p) {
+    return !(p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS)) && p.lm.precision != 32;
+}
+
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (!db->n_large) return FX_OK;
+    if (wide_kernel_applies(p) && db->d.n_wide) {
+        hipError_t e = fx::launch_solve_wide(db->d, p, ctx->stream);
+        if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
+    }
     const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
     for (uint32_t s = 0; s < db->d.n_systems; ++s) {
         if (!db->h_sys_large[s]) continue;
+        if (db->h_sys_large[s] == 2 && wide_kernel_applies(p)) continue;  // done by the wide kernel
         if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
         fx_result res{};
         hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, ctx->stream, db->d.vars + db->h_var_off[s], &res);
@@ -809,6 +838,11 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(row_sysoff, p.row_sysoff.data(), p.n_exprs)
     FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
+    FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
+    d.n_wide = (uint32_t)p.wide_list.size();
+    d.w_max_free = p.w_max_free;
+    d.w_max_vars = p.w_max_vars;
+    d.w_max_rows = p.w_max_rows;
     // jrow_ptr / jcol / jslot / jvals (the CSR Jacobian) and resid are only needed by the standalone
     // evaluation entry points: they are built on first use (ensure_csr / ensure_resid), so a plain
     // solve neither computes nor uploads them.

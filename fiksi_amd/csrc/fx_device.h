@@ -47,7 +47,8 @@ struct DeviceBatch {
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]
     uint16_t* sys_ncomp;   // [n_systems] number of components
-    uint8_t* sys_large;    // [n_systems] 1 = exceeds the one-wavefront limits, solved by the sparse path
+    uint8_t* sys_large;    // [n_systems] 0 = fused one-wavefront kernel; 2 = medium (65..128 free variables per
+                           // component): the wide kernel (fx_wide.hip); 1 = beyond that: the sparse path
     double* vars0;         // [n_vars] start values (never written by solves)
     double* vars;          // [n_vars] last solved values
     uint16_t* var_info;    // [n_vars]
@@ -67,6 +68,9 @@ struct DeviceBatch {
     double* resid;         // [n_exprs]
     fx_result* results;    // [n_systems]
     double* sse_unscaled;  // [n_systems] sum r^2 on the solved, unscaled variables
+    // medium Systems (sys_large == 2)
+    uint32_t n_wide, w_max_free, w_max_vars, w_max_rows;
+    uint32_t* w_list;         // [n_wide] System ids
     // SinglePass blocks, built on first use (null until then)
     uint32_t max_unit_free;   // free variables per block
     uint32_t max_unit_rows;   // expressions per block (a block may hold a neighbouring component's rows)
@@ -93,6 +97,8 @@ struct LmParams {
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);
 hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream);
+hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+size_t wide_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes_units(const DeviceBatch& b);
 size_t analyze_lds_bytes(uint32_t max_vars, uint32_t max_exprs);

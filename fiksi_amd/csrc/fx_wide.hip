@@ -1,0 +1,462 @@
+// Fused per-System solve for MEDIUM components: 65 .. 128 free variables (still <= 256 expressions per
+// component and <= 512 variables per System, so everything stays in LDS).
+//
+// Same algorithm and control flow as lm_solve_kernel (fx_kernels.hip; reference
+// fiksi/src/assemble/mod.rs:46-167 and fiksi/src/solve/lm.rs:21-193), still one wavefront per System,
+// but a column no longer fits a lane's registers: the normal matrix JtJ + lambda I lives in LDS as a
+// packed lower triangle (66 KB for 128 columns) and is factored in place by a right-looking Cholesky
+// that sweeps it row by row — per row one broadcast read of L_ik and conflict-free read-modify-writes
+// of consecutive columns, each lane owning two column slots. The triangular solves walk rows the same
+// way (dot form forward, axpy form backward). JtJ is re-formed from the Jacobian rows of the current
+// point at every lambda trial (a few hundred LDS atomics) instead of being kept next to the factor:
+// two triangles would not fit.
+//
+// Without this kernel a System with 66 variables fell to the host-driven sparse path (~0.8 ms each, one
+// after the other); here Systems run concurrently, one per CU (LDS-bound occupancy).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fx_device.h"
+#include "fx_expr.h"
+#include "fx_wave.h"
+
+namespace fx {
+
+struct WideLayout {
+    uint32_t vt, mr, n;  // padded variables per System, rows per component, free variables per component
+    uint32_t off_xs, off_vout, off_l, off_rhs, off_delta, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx,
+        off_colof;
+    uint32_t total;
+};
+
+static WideLayout make_wide_layout(uint32_t max_free, uint32_t max_vars, uint32_t max_rows) {
+    WideLayout L;
+    L.vt = (max_vars + 7u) & ~7u;
+    L.mr = (max_rows + 7u) & ~7u;
+    L.n = (max_free + 7u) & ~7u;
+    if (L.vt == 0) L.vt = 8;
+    if (L.mr == 0) L.mr = 8;
+    if (L.n == 0) L.n = 8;
+    uint32_t o = 0;
+    auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
+    L.off_xs = take(2u * L.vt * 8u);
+    L.off_vout = take(L.vt * 8u);
+    L.off_l = take(L.n * (L.n + 1u) / 2u * 8u);
+    L.off_rhs = take(L.n * 8u);
+    L.off_delta = take(L.n * 8u);
+    L.off_g = take(2u * L.mr * 8u * 8u);
+    L.off_r = take(2u * L.mr * 8u);
+    L.off_p = take(L.mr * 8u);
+    L.off_gvar = take(L.mr * 8u * 2u);
+    L.off_gcol = take(L.mr * 8u * 2u);
+    L.off_rtag = take(L.mr);
+    L.off_fidx = take(L.n * 2u);
+    L.off_colof = take(L.vt * 2u);
+    L.total = o;
+    return L;
+}
+
+size_t wide_lds_bytes(const DeviceBatch& b) { return make_wide_layout(b.w_max_free, b.w_max_vars, b.w_max_rows).total; }
+
+__device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return i * (i + 1u) / 2u + j; }  // i >= j
+
+__global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const uint32_t s = b.w_list[blockIdx.x];
+    double* XS = reinterpret_cast<double*>(smem + L.off_xs);      // [2][vt]
+    double* VOUT = reinterpret_cast<double*>(smem + L.off_vout);  // [vt]
+    double* Lm = reinterpret_cast<double*>(smem + L.off_l);       // packed lower triangle
+    double* RHS = reinterpret_cast<double*>(smem + L.off_rhs);    // [n] -Jt r at the current point
+    double* DEL = reinterpret_cast<double*>(smem + L.off_delta);  // [n] right-hand side -> step
+    double* G = reinterpret_cast<double*>(smem + L.off_g);        // [2][mr][8]
+    double* R = reinterpret_cast<double*>(smem + L.off_r);        // [2][mr]
+    double* P = reinterpret_cast<double*>(smem + L.off_p);        // [mr]
+    uint16_t* gvar = reinterpret_cast<uint16_t*>(smem + L.off_gvar);
+    int16_t* gcol = reinterpret_cast<int16_t*>(smem + L.off_gcol);
+    uint8_t* rtag = reinterpret_cast<uint8_t*>(smem + L.off_rtag);
+    uint16_t* fidx = reinterpret_cast<uint16_t*>(smem + L.off_fidx);
+    int16_t* colof = reinterpret_cast<int16_t*>(smem + L.off_colof);
+    const uint32_t vt = L.vt, mr = L.mr;
+
+    const uint32_t v0 = b.var_off[s], nvt = b.var_off[s + 1] - v0;
+    const uint32_t e0 = b.expr_off[s], net = b.expr_off[s + 1] - e0;
+    const uint32_t ncomp = b.sys_ncomp[s];
+    const fx_lm_opts o = prm.lm;
+
+    // ---- K0a: system scale, summed strictly in reference order (assemble/mod.rs:32-44) ------------
+    double scale = 1.0, scale_recip = 1.0;
+    if (prm.mode & 1u) {
+        double sum = 0.0;
+        uint32_t count = nvt;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            if (i < nvt) {
+                double v = b.vars0[v0 + i];
+                t = v * v;
+            }
+            uint32_t cnt = min(64u, nvt - base);
+            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+        }
+        for (uint32_t base = 0; base < net; base += 64) {
+            uint32_t i = base + lane;
+            double t = 0.0;
+            bool isd = false;
+            if (i < net) {
+                int tag = b.expr_tag[e0 + i] & 0x7F;
+                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
+                if (isd) {
+                    double d = b.expr_param[e0 + i];
+                    t = d * d;
+                }
+            }
+            count += (uint32_t)__popcll(__ballot(isd));
+            uint32_t cnt = min(64u, net - base);
+            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+        }
+        scale = ::sqrt(sum / (double)count);
+        scale_recip = 1.0 / scale;
+    }
+    for (uint32_t i = lane; i < nvt; i += 64) {
+        double v = b.vars0[v0 + i];
+        double xsv = (prm.mode & 1u) ? v * scale_recip : v;
+        XS[i] = xsv;
+        XS[vt + i] = xsv;
+        VOUT[i] = v;
+        b.vars[v0 + i] = v;
+    }
+    __syncthreads();
+
+    uint32_t rng = 42u;
+    uint32_t tot_accept = 0, tot_trials = 0, last_exit = FX_EXIT_SSE, comps_done = 0;
+    double tot_sse0 = 0.0, tot_sse = 0.0;
+
+    for (uint32_t c = 0; c < ncomp; ++c) {
+        // ---- free variables of the component, ascending (:91-111); perturbation on the way (:113-124)
+        const uint32_t rng_start = rng;  // the component's draws start here
+        uint32_t nfree = 0;
+        bool any_var = false;
+        for (uint32_t base = 0; base < nvt; base += 64) {
+            uint32_t i = base + lane;
+            bool in = false, member = false;
+            if (i < nvt) {
+                uint16_t info = b.var_info[v0 + i];
+                member = (info & VAR_COMP_MASK) == c;
+                in = member && !(info & VAR_FIXED_BIT);
+            }
+            any_var = any_var || (__ballot(member) != 0ull);
+            uint64_t mk = __ballot(in);
+            uint32_t pos = nfree + (uint32_t)__popcll(mk & lanemask_lt(lane));
+            if (i < nvt) colof[i] = in ? (int16_t)pos : (int16_t)-1;
+            if (in) {
+                fidx[pos] = (uint16_t)i;
+                if (prm.mode & 2u) {
+                    uint32_t st = lcg_jump(rng, 2u * pos);
+                    st = st * 1664525u + 1013904223u;
+                    double f1 = (1.0 / 4294967295.0) * (double)st;
+                    st = st * 1664525u + 1013904223u;
+                    double f2 = (1.0 / 4294967295.0) * (double)st;
+                    double x = b.vars0[v0 + i];
+                    if (prm.mode & 1u) x = x * scale_recip;
+                    x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                    XS[i] = x;
+                    XS[vt + i] = x;
+                }
+            }
+            nfree += (uint32_t)__popcll(mk);
+        }
+        if (!uniform(any_var)) continue;
+        if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
+        __syncthreads();
+
+        // ---- rows of the component, ascending expression id (:139-145)
+        uint32_t m_rows = 0;
+        for (uint32_t base = 0; base < net; base += 64) {
+            uint32_t i = base + lane;
+            bool in = (i < net) && (b.expr_comp[e0 + i] == c);
+            uint64_t mk = __ballot(in);
+            uint32_t pos = m_rows + (uint32_t)__popcll(mk & lanemask_lt(lane));
+            if (in) {
+                int tag = b.expr_tag[e0 + i] & 0x7F;
+                const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
+                uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+                uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int k = expand_vars(tag, ff, vars8);
+                double prm_e = b.expr_param[e0 + i];
+                if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                rtag[pos] = (uint8_t)tag;
+                P[pos] = prm_e;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                    gcol[pos * 8 + e] = (e < k) ? colof[vars8[e]] : (int16_t)-1;
+                }
+            }
+            m_rows += (uint32_t)__popcll(mk);
+        }
+        __syncthreads();
+
+        auto eval_rows = [&](int buf) -> double {
+            const double* xs = XS + buf * vt;
+            double part = 0.0;
+            for (uint32_t row = lane; row < m_rows; row += 64) {
+                double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
+                double r = eval_expression<double, true>(rtag[row], v, P[row], g);
+                R[buf * mr + row] = r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
+                part += r * r;
+            }
+            return wave_sum(part);
+        };
+        // rhs = -Jt r at `buf`, one row per wave instruction (row order)
+        auto form_rhs = [&](int buf) {
+            for (uint32_t i = lane; i < nfree; i += 64) RHS[i] = 0.0;
+            __syncthreads();
+            for (uint32_t row = 0; row < m_rows; ++row) {
+                if (lane < 8) {
+                    int col = gcol[row * 8 + lane];
+                    if (col >= 0) lds_add(&RHS[col], G[(buf * mr + row) * 8 + lane] * -R[buf * mr + row]);
+                }
+            }
+            __syncthreads();
+        };
+        // packed lower triangle of Jt J + lambda I from the rows at `buf`
+        auto form_matrix = [&](int buf, double lambda) {
+            const uint32_t len = nfree * (nfree + 1u) / 2u;
+            for (uint32_t i = lane; i < len; i += 64) Lm[i] = 0.0;
+            __syncthreads();
+            const int e1 = lane >> 3, e2 = lane & 7;
+            constexpr int RB = 4;
+            for (uint32_t row0 = 0; row0 < m_rows; row0 += RB) {
+                int c1[RB], c2[RB];
+                double g1[RB], g2[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    uint32_t row = min(row0 + q, m_rows - 1);
+                    c1[q] = gcol[row * 8 + e1];
+                    c2[q] = gcol[row * 8 + e2];
+                    g1[q] = G[(buf * mr + row) * 8 + e1];
+                    g2[q] = G[(buf * mr + row) * 8 + e2];
+                    if (row0 + q >= m_rows) c1[q] = -1;
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    // lower triangle; a column that repeats inside the row meets itself on the diagonal
+                    // from both orders, as (g1 + g2)^2 requires
+                    if (c1[q] >= 0 && c2[q] >= 0 && c1[q] >= c2[q]) lds_add(&Lm[tri((uint32_t)c1[q], (uint32_t)c2[q])], g1[q] * g2[q]);
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = lane; i < nfree; i += 64) Lm[tri(i, i)] += lambda;
+            __syncthreads();
+        };
+        // in-place Cholesky of the packed triangle, right-looking, swept by rows; false on a bad pivot
+        auto factor = [&]() -> bool {
+            bool bad = false;
+            for (uint32_t k = 0; k < nfree; ++k) {
+                const double piv = Lm[tri(k, k)];
+                bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
+                const double d = ::sqrt(piv), inv = 1.0 / d;
+                __syncthreads();
+                for (uint32_t i = k + 1 + lane; i < nfree; i += 64) Lm[tri(i, k)] *= inv;
+                if (lane == 0) Lm[tri(k, k)] = d;
+                __syncthreads();
+                const uint32_t j0 = k + 1 + lane, j1 = j0 + 64;
+                const double l0 = (j0 < nfree) ? Lm[tri(j0, k)] : 0.0;
+                const double l1 = (j1 < nfree) ? Lm[tri(j1, k)] : 0.0;
+                for (uint32_t i = k + 1; i < nfree; ++i) {
+                    const double lik = Lm[tri(i, k)];  // one address for the whole wavefront
+                    const uint32_t rowbase = tri(i, 0);
+                    if (j0 <= i) Lm[rowbase + j0] = fma(-lik, l0, Lm[rowbase + j0]);
+                    if (j1 <= i) Lm[rowbase + j1] = fma(-lik, l1, Lm[rowbase + j1]);
+                }
+                __syncthreads();
+            }
+            return !uniform(bad);
+        };
+        // L L^T x = DEL in place: forward by row dots, backward by row axpys; returns |x|^2
+        auto solve = [&]() -> double {
+            for (uint32_t i = 0; i < nfree; ++i) {
+                const uint32_t rowbase = tri(i, 0);
+                double part = 0.0;
+                for (uint32_t j = lane; j < i; j += 64) part = fma(Lm[rowbase + j], DEL[j], part);
+                part = wave_sum(part);
+                if (lane == 0) DEL[i] = (DEL[i] - part) / Lm[rowbase + i];
+                __syncthreads();
+            }
+            for (uint32_t ii = nfree; ii-- > 0;) {
+                const uint32_t rowbase = tri(ii, 0);
+                const double xi = DEL[ii] / Lm[rowbase + ii];
+                __syncthreads();
+                for (uint32_t j = lane; j < ii; j += 64) DEL[j] = fma(-Lm[rowbase + j], xi, DEL[j]);
+                if (lane == 0) DEL[ii] = xi;
+                __syncthreads();
+            }
+            double part = 0.0;
+            for (uint32_t i = lane; i < nfree; i += 64) part += DEL[i] * DEL[i];
+            return wave_sum(part);
+        };
+
+        int cur = 0;
+        double sse = eval_rows(0);
+        const double sse_start = sse;
+        form_rhs(0);
+        double lambda = o.lambda0;
+        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
+        bool done = false;
+        if (!(sse == sse) || !(sse < 1.0e300)) {
+            exit_code = FX_EXIT_NAN;
+            done = true;
+        }
+        for (uint32_t outer = 0; outer < o.max_outer && !done; ++outer) {
+            if (sse < o.sse_tol) {  // lm.rs:110-112
+                exit_code = FX_EXIT_SSE;
+                break;
+            }
+            for (;;) {  // lambda trials, lm.rs:115-191
+                if (trials >= o.max_trials) {
+                    exit_code = FX_EXIT_TRIAL_CAP;
+                    done = true;
+                    break;
+                }
+                trials += 1;
+                form_matrix(cur, lambda);
+                if (!factor()) {  // lm.rs:134-137
+                    lambda *= o.singular_factor;
+                    if (!(lambda < 1.0e300)) {
+                        exit_code = FX_EXIT_NAN;
+                        done = true;
+                        break;
+                    }
+                    continue;
+                }
+                for (uint32_t i = lane; i < nfree; i += 64) DEL[i] = RHS[i];
+                __syncthreads();
+                const double dn2 = solve();
+                if (!(dn2 == dn2)) {
+                    exit_code = FX_EXIT_NAN;
+                    done = true;
+                    break;
+                }
+                if (dn2 < o.step_tol) {  // lm.rs:139-142
+                    exit_code = FX_EXIT_STEP;
+                    done = true;
+                    break;
+                }
+                const int trial = cur ^ 1;
+                for (uint32_t i = lane; i < nfree; i += 64) {
+                    uint32_t vi = fidx[i];
+                    XS[trial * vt + vi] = XS[cur * vt + vi] + DEL[i];
+                }
+                __syncthreads();
+                const double sse_t = eval_rows(trial);
+                if (sse_t < sse) {  // accept, lm.rs:151-186
+                    lambda *= o.accept_factor;
+                    if (lambda < o.lambda_min) lambda = o.lambda_min;
+                    cur = trial;
+                    accepted += 1;
+                    const double rel = (sse - sse_t) / sse;
+                    sse = sse_t;
+                    if (rel <= o.ftol) {
+                        exit_code = FX_EXIT_FTOL;
+                        done = true;
+                        break;
+                    }
+                    __syncthreads();
+                    form_rhs(cur);
+                    break;
+                } else {  // reject, lm.rs:187-190
+                    lambda *= o.reject_factor;
+                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
+                        exit_code = FX_EXIT_NAN;
+                        done = true;
+                        break;
+                    }
+                }
+            }
+        }
+
+        // ---- K6: write back scale * x (:161-166); later components see the pre-solve snapshot (quirk Q2)
+        __syncthreads();
+        for (uint32_t i = lane; i < nfree; i += 64) {
+            uint32_t vi = fidx[i];
+            double x = XS[cur * vt + vi];
+            double xo = (prm.mode & 1u) ? scale * x : x;
+            b.vars[v0 + vi] = xo;
+            VOUT[vi] = xo;
+        }
+        __syncthreads();
+        // restore the perturbed start values: recomputed exactly as above (same draws)
+        {
+            const uint32_t rng0 = rng_start;
+            for (uint32_t i = lane; i < nfree; i += 64) {
+                uint32_t vi = fidx[i];
+                double x = b.vars0[v0 + vi];
+                if (prm.mode & 1u) x = x * scale_recip;
+                if (prm.mode & 2u) {
+                    uint32_t st = lcg_jump(rng0, 2u * i);
+                    st = st * 1664525u + 1013904223u;
+                    double f1 = (1.0 / 4294967295.0) * (double)st;
+                    st = st * 1664525u + 1013904223u;
+                    double f2 = (1.0 / 4294967295.0) * (double)st;
+                    x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                }
+                XS[vi] = x;
+                XS[vt + vi] = x;
+            }
+        }
+        __syncthreads();
+        tot_accept += accepted;
+        tot_trials += trials;
+        last_exit = exit_code;
+        tot_sse0 += sse_start;
+        tot_sse += sse;
+        comps_done += 1;
+    }
+
+    // ---- post-solve check on unscaled variables (constraints/mod.rs:96-109)
+    __syncthreads();
+    double part = 0.0;
+    for (uint32_t i = lane; i < net; i += 64) {
+        int tag = b.expr_tag[e0 + i] & 0x7F;
+        const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
+        uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        expand_vars(tag, ff, vars8);
+        double v[8], g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
+        double r = eval_expression<double, false>(tag, v, b.expr_param[e0 + i], g);
+        part += r * r;
+    }
+    double sse_u = wave_sum(part);
+    if (lane == 0) {
+        fx_result res;
+        res.accepted = tot_accept;
+        res.trials = tot_trials;
+        res.exit = last_exit;
+        res.ncomp = comps_done;
+        res.scale = scale;
+        res.sse0 = tot_sse0;
+        res.sse = tot_sse;
+        res.sse_unscaled = sse_u;
+        b.results[s] = res;
+    }
+}
+
+hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (b.n_wide == 0) return hipSuccess;
+    WideLayout L = make_wide_layout(b.w_max_free, b.w_max_vars, b.w_max_rows);
+    if (L.total > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_wide_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lm_solve_wide_kernel, dim3(b.n_wide), dim3(64), L.total, stream, b, p, L);
+    return hipGetLastError();
+}
+
+}  // namespace fx

@@ -70,9 +70,12 @@ typedef enum fx_tag {
 } fx_tag;
 
 /* One-wavefront limits of the fused solve kernel (one wavefront per System). Systems within them
- * are solved thousands at a time; a System beyond them (more free variables or expressions in a
- * component, or more variables) is solved by the sparse large-sketch path, one at a time. */
+ * are solved thousands at a time; up to FX_MAX_WIDE_FREE_VARS free variables per component a second
+ * LDS-resident kernel takes over (f64 LM without a decomposer); a System beyond that (more free
+ * variables or expressions in a component, or more variables) is solved by the sparse large-sketch
+ * path, one at a time. */
 #define FX_MAX_FREE_VARS 64u          /* free variables (Jacobian columns) per component          */
+#define FX_MAX_WIDE_FREE_VARS 128u    /* ... per component, wide kernel                            */
 #define FX_MAX_ROWS 256u              /* expressions (Jacobian rows) per component                */
 #define FX_MAX_SYSTEM_VARS 512u       /* variables (free + fixed) per System, fused kernel        */
 #define FX_MAX_LARGE_SYSTEM_VARS 65535u /* variables per System, sparse path (16-bit local indices) */

@@ -1,0 +1,109 @@
+"""Medium components (65 .. 128 free variables): the LDS-resident wide kernel (fx_wide.hip) against the
+oracle, and its hand-over points to the fused kernel below and the sparse path above."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rms(x):
+    x = np.asarray(x, dtype=np.float64)
+    return float(np.sqrt(np.mean(x * x))) if len(x) else 0.0
+
+
+@pytest.mark.parametrize("n_tri", [16, 20, 25, 31])
+def test_hinged_chains_just_above_the_one_wavefront_limit(fiksi, oracle, ctx, n_tri):
+    """Chains of n hinged triangles: 4n + 2 variables (66 .. 126). Same LM path as the oracle: identical
+    accepted-step and trial counts, solved positions to 1e-8 (normal equations vs the reference's QR)."""
+    from fiksi_amd import workloads
+
+    b = workloads.hinged_triangles(24, n_tri)
+    assert 64 < int(b["var_off"][1]) <= 128
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    assert np.array_equal(res["scale"], res_o["scale"])
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.array_equal(res["trials"], res_o["trials"])
+    assert np.array_equal(res["exit"], res_o["exit"])
+    assert np.allclose(res["sse0"], res_o["sse0"], rtol=1e-12, atol=0)
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    assert np.all(res["sse_unscaled"] < 1e-4)
+
+
+def test_wide_and_narrow_and_large_systems_share_a_batch(fiksi, oracle, ctx):
+    from fiksi_amd import workloads
+
+    b = workloads.concat([workloads.ring16(6), workloads.hinged_triangles(3, 20), workloads.large_sketch(100),
+                          workloads.hinged_triangles(2, 5), workloads.hinged_triangles(2, 30), workloads.quadrilateral()])
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=4)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.array_equal(res["exit"], res_o["exit"])
+    assert np.allclose(res["sse"], res_o["sse"], rtol=1e-5, atol=1e-12)
+    db = ctx.upload(b)
+    db.system_solve()
+    assert np.array_equal(db.get_vars(), v)  # resident path: same answer, deterministic
+    db.system_solve()
+    assert np.array_equal(db.get_vars(), v)
+    db.free()
+
+
+def test_wide_multi_component_fixed_points_and_snapshot_quirk(fiksi, oracle, ctx):
+    """Two components in one System — a 70-variable chain and a small triangle — plus fixed points: the
+    shared LCG stream continues across components (assemble/mod.rs:47), fixed values stay bit-identical,
+    and the second component is solved against the pre-solve snapshot (quirk Q2)."""
+    F = fiksi
+    s = F.System()
+    pts = [F.elements.Point.create(s, 1.1 * i, 0.35 * ((i * 7) % 5)) for i in range(35)]
+    for i in range(34):
+        F.constraints.PointPointDistance.create(s, pts[i], pts[i + 1], 1.3)
+    for i in range(33):
+        F.constraints.PointPointDistance.create(s, pts[i], pts[i + 2], 2.2)
+    pts[0].fix(s)
+    q = [F.elements.Point.create(s, 50. + i, 3. * (i % 2)) for i in range(3)]
+    for a, c in ((0, 1), (0, 2), (1, 2)):
+        F.constraints.PointPointDistance.create(s, q[a], q[c], 1.5)
+    flat = s.flatten()
+    assert flat["var_comp"].max() == 1
+    v, res = ctx.system_solve_batch(flat)
+    v_o, res_o = oracle.solve_batch(flat, mode=3)
+    assert res["ncomp"][0] == res_o["ncomp"][0] == 2
+    assert res["accepted"][0] == res_o["accepted"][0] and res["trials"][0] == res_o["trials"][0]
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    assert np.array_equal(v[:2], flat["vars"][:2])
+
+
+def test_wide_kernel_other_modes_take_the_general_paths(fiksi, oracle, ctx):
+    """f32, L-BFGS and SinglePass on a medium System are served by the paths that implement them (sparse
+    path / block walker); results stay consistent with the oracle."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.hinged_triangles(4, 20)
+    v_sp, res_sp = ctx.system_solve_batch(b, abi.solving_opts(decomposer=1))
+    v_sp_o, res_sp_o = oracle.solve_single_pass_batch(b, trial_cap=4096)
+    assert np.array_equal(res_sp["accepted"], res_sp_o["accepted"]) and np.max(np.abs(v_sp - v_sp_o)) < 1e-8
+    v_l, res_l = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1))
+    v_l_o, res_l_o = oracle.solve_batch(b, mode=7)
+    assert np.all(res_l["sse"] <= np.maximum(2.0 * res_l_o["sse"], 1e-6))
+    v_f, res_f = ctx.system_solve_batch(b, abi.solving_opts(f32=True))
+    assert _rms(oracle.residuals_batch(b, v_f)) < 1e-4
+
+
+def test_wide_kernel_l2_entry_point_and_limits(fiksi, oracle, ctx):
+    """fx_lm_solve_batch (no scaling, no perturbation) on medium Systems; 129 free variables go to the
+    sparse path."""
+    F = fiksi
+    from fiksi_amd import workloads
+
+    b = workloads.hinged_triangles(8, 24)
+    v, res = ctx.lm_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=0, nthreads=4)
+    assert np.array_equal(res["accepted"], res_o["accepted"])
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    big = workloads.hinged_triangles(1, 32)  # 130 variables: one component of 130 free columns
+    assert int(big["var_off"][1]) == 130
+    v2, res2 = ctx.system_solve_batch(big)
+    v2_o, res2_o = oracle.solve_batch(big, mode=3)
+    assert res2["accepted"][0] == res2_o["accepted"][0]
+    assert np.max(np.abs(v2 - v2_o)) < 1e-7
