@@ -42,6 +42,7 @@ struct HostPlan {
     uint32_t n_systems = 0, n_vars = 0, n_exprs = 0;
     uint64_t nnz = 0;
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
+    uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0;
     std::vector<uint16_t> sys_ncomp;
     std::vector<uint8_t> sys_large;  // 0 fused kernel, 2 wide kernel (65..128 free variables), 1 sparse path
     uint32_t n_large = 0;            // Systems with sys_large != 0
@@ -197,6 +198,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         uint64_t nnz = 0;
         uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0, n_large = 0;
         uint32_t w_max_free = 0, w_max_rows = 0, w_max_vars = 0;
+        uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0;
         int err = FX_OK;
         uint32_t err_system = 0;
         char msg[192] = {0};
@@ -210,7 +212,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             snprintf(pt.msg, sizeof(pt.msg), fmt, a0, a1, a2, a3);
         };
         std::vector<int32_t> free_rank;  // per variable of the current system: system-wide free rank
-        std::vector<uint32_t> comp_free, comp_rows;
+        std::vector<uint32_t> comp_free, comp_rows, comp_pairs, comp_ents;
         for (uint32_t s = s_lo; s < s_hi && pt.err == FX_OK; ++s) {
             const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
             const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
@@ -261,6 +263,8 @@ int analyze(const fx_batch* b, HostPlan* plan) {
 
             comp_free.assign(ncomp, 0);
             comp_rows.assign(ncomp, 0);
+            comp_pairs.assign(ncomp, 0);
+            comp_ents.assign(ncomp, 0);
             for (uint32_t i = 0; i < nvt; ++i) {
                 uint16_t info = p.var_info[v0 + i];
                 uint16_t c = info & fx::VAR_COMP_MASK;
@@ -301,7 +305,13 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 p.row_simple[e] = (all_free && distinct) ? 1 : 0;
                 p.expr_sys[e] = s;
                 uint16_t c = p.expr_comp[e];
-                if (c != fx::VAR_COMP_NONE) comp_rows[c] += 1;
+                if (c != fx::VAR_COMP_NONE) {
+                    comp_rows[c] += 1;
+                    uint32_t kf = 0;  // entries with a free variable (an upper bound inside the kernel's component)
+                    for (int q = 0; q < k; ++q) kf += free_rank[vars8[q]] >= 0;
+                    comp_pairs[c] += kf * kf;
+                    comp_ents[c] += kf;
+                }
                 if (all_free && distinct) {
                     pt.nnz += (uint64_t)k;
                 } else {
@@ -310,6 +320,11 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 }
             }
             if (pt.err != FX_OK) break;
+            uint32_t cp_max = 0, ce_max = 0;
+            for (uint32_t c = 0; c < ncomp; ++c) {
+                cp_max = std::max(cp_max, comp_pairs[c]);
+                ce_max = std::max(ce_max, comp_ents[c]);
+            }
             bool wide = false;  // more than one wavefront's columns, but still an LDS-resident dense problem
             uint32_t cf_max = 0, cr_max = 0;
             for (uint32_t c = 0; c < ncomp; ++c) {
@@ -321,6 +336,8 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             if (large) {
                 p.sys_large[s] = wide ? 2 : 1;
                 pt.n_large += 1;
+                pt.max_pairs_large = std::max(pt.max_pairs_large, cp_max);
+                pt.max_ents_large = std::max(pt.max_ents_large, ce_max);
                 if (wide) {
                     pt.w_max_free = std::max(pt.w_max_free, cf_max);
                     pt.w_max_rows = std::max(pt.w_max_rows, cr_max);
@@ -329,6 +346,8 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             } else {  // LDS layout and kernel instantiation are sized by the one-wavefront systems only
                 pt.max_vars = std::max(pt.max_vars, nvt);
                 pt.max_exprs = std::max(pt.max_exprs, net);
+                pt.max_pairs = std::max(pt.max_pairs, cp_max);
+                pt.max_ents = std::max(pt.max_ents, ce_max);
                 for (uint32_t c = 0; c < ncomp; ++c) {
                     pt.max_free = std::max(pt.max_free, comp_free[c]);
                     pt.max_rows = std::max(pt.max_rows, comp_rows[c]);
@@ -347,6 +366,10 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         p.max_exprs = std::max(p.max_exprs, part[t].max_exprs);
         p.max_vars_all = std::max(p.max_vars_all, part[t].max_vars_all);
         p.max_exprs_all = std::max(p.max_exprs_all, part[t].max_exprs_all);
+        p.max_pairs = std::max(p.max_pairs, part[t].max_pairs);
+        p.max_ents = std::max(p.max_ents, part[t].max_ents);
+        p.max_pairs_large = std::max(p.max_pairs_large, part[t].max_pairs_large);
+        p.max_ents_large = std::max(p.max_ents_large, part[t].max_ents_large);
         p.w_max_free = std::max(p.w_max_free, part[t].w_max_free);
         p.w_max_rows = std::max(p.w_max_rows, part[t].w_max_rows);
         p.w_max_vars = std::max(p.w_max_vars, part[t].w_max_vars);
@@ -813,6 +836,10 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     d.max_exprs = p.max_exprs;
     d.max_vars_all = p.max_vars_all;
     d.max_exprs_all = p.max_exprs_all;
+    d.max_pairs = p.max_pairs;
+    d.max_ents = p.max_ents;
+    d.max_pairs_g = p.max_pairs_large;  // blocks of a large System hold at most its components' products
+    d.max_ents_g = p.max_ents_large;
     const uint32_t zero_off[1] = {0};
     const uint32_t* voff = p.n_systems ? batch->var_off : zero_off;
     const uint32_t* eoff = p.n_systems ? batch->expr_off : zero_off;

@@ -43,6 +43,8 @@ struct DeviceBatch {
     uint32_t max_vars;   // variables per System
     uint32_t max_exprs;  // expressions per System
     uint32_t max_vars_all, max_exprs_all;  // the same maxima over ALL Systems (large ones included)
+    uint32_t max_pairs, max_ents;          // per component: sum over rows of (free entries)^2 / of free entries
+    uint32_t max_pairs_g, max_ents_g;      // the same over the Systems of the GLOBAL block walker
 
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]

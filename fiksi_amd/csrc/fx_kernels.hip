@@ -28,11 +28,13 @@ struct SolveLayout {
     uint32_t vt;   // padded variables per System
     uint32_t mr;   // padded rows per component
     uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx, off_colof, off_vout;
+    uint32_t off_pw, off_pe;  // packed work lists of the normal-equation assembly
+    uint32_t pw_cap, pe_cap;  // their capacities in entries (0: the row-by-row assembly is used)
     uint32_t total;
 };
 
 static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows, uint32_t es /* sizeof(T) */,
-                               bool lbfgs = false) {
+                               bool lbfgs = false, uint32_t max_pairs = 0, uint32_t max_ents = 0) {
     SolveLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -54,6 +56,13 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     L.off_fidx = take(n_pad * 2u);
     L.off_colof = take(L.vt * 2u);
     L.off_vout = take(L.vt * 8u);  // unscaled output values (f64) for the post-solve check
+    // one u32 per product g_a * g_b of the assembly (and per g * r of the right-hand side); worth its
+    // LDS only while it stays small (ring16: 672 + 144 entries = 3.3 KB)
+    const bool packed = !lbfgs && max_pairs > 0 && max_pairs <= 4096u;
+    L.pw_cap = packed ? ((max_pairs + 63u) & ~63u) : 0u;
+    L.pe_cap = packed ? ((max_ents + 63u) & ~63u) : 0u;
+    L.off_pw = take(L.pw_cap * 4u);
+    L.off_pe = take(L.pe_cap * 4u);
     L.total = o;
     return L;
 }
@@ -63,9 +72,12 @@ static uint32_t pad_n(uint32_t max_free) {
     return n < 8u ? 8u : n;
 }
 
-size_t solve_lds_bytes(const DeviceBatch& b) { return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows, 8u).total; }
+size_t solve_lds_bytes(const DeviceBatch& b) {
+    return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents).total;
+}
 size_t solve_lds_bytes_units(const DeviceBatch& b) {
-    return make_layout(pad_n(b.max_unit_free), b.max_vars, b.max_rows > b.max_unit_rows ? b.max_rows : b.max_unit_rows, 8u).total;
+    return make_layout(pad_n(b.max_unit_free), b.max_vars, b.max_rows > b.max_unit_rows ? b.max_rows : b.max_unit_rows, 8u, false,
+                       b.max_pairs, b.max_ents).total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,8 +345,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
 
         // ---- K0b: perturbation of the free variables, 2 LCG draws each, ascending order -----
         if (prm.mode & 2u) {
-            uint32_t st = rng;
-            for (int k = 0; k < 2 * lane; ++k) st = st * 1664525u + 1013904223u;
+            uint32_t st = lcg_jump(rng, 2u * (uint32_t)lane);
             st = st * 1664525u + 1013904223u;
             double f1 = (1.0 / 4294967295.0) * (double)st;
             st = st * 1664525u + 1013904223u;
@@ -378,6 +389,57 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         __syncthreads();
         }  // !UNITS
 
+        // ---- packed work lists of the normal-equation assembly: one u32 per product g_a * g_b with both
+        // columns free (row << 19 | a << 16 | b << 13 | address in A) and one per g * r of the right-hand
+        // side (row << 9 | a << 6 | column). Built once per component / block; every later assembly then
+        // is a flat loop over them instead of 8 x 8 lanes per row with most of them idle.
+        uint32_t* PW = reinterpret_cast<uint32_t*>(smem + L.off_pw);
+        uint32_t* PE = reinterpret_cast<uint32_t*>(smem + L.off_pe);
+        uint32_t n_pw = 0, n_pe = 0;
+        bool use_packed = false;
+        if (OPT == 0 && L.pw_cap) {
+            for (uint32_t base = 0; base < m_rows; base += 64) {
+                const uint32_t row = base + lane;
+                uint32_t mask = 0;
+                uint64_t cols = 0;  // the row's eight columns, one byte each (registers only from here on)
+                if (row < m_rows) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int cc = gcol[row * 8 + e];
+                        mask |= (cc >= 0) ? (1u << e) : 0u;
+                        cols |= (uint64_t)(uint8_t)cc << (8 * e);
+                    }
+                }
+                const uint32_t kf = (uint32_t)__popc(mask);
+                uint32_t inc2 = kf * kf, inc1 = kf;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t t2 = __shfl_up(inc2, off, 64), t1 = __shfl_up(inc1, off, 64);
+                    if (lane >= off) {
+                        inc2 += t2;
+                        inc1 += t1;
+                    }
+                }
+                uint32_t at2 = n_pw + inc2 - kf * kf, at1 = n_pe + inc1 - kf;
+                if (at2 + kf * kf <= L.pw_cap && at1 + kf <= L.pe_cap) {
+                    for (uint32_t m1 = mask; m1; m1 &= m1 - 1u) {
+                        const uint32_t a = (uint32_t)__ffs(m1) - 1u;
+                        const uint32_t ca = (uint32_t)(cols >> (8u * a)) & 0xFFu;
+                        PE[at1++] = (row << 9) | (a << 6) | ca;
+                        for (uint32_t m2 = mask; m2; m2 &= m2 - 1u) {
+                            const uint32_t bb = (uint32_t)__ffs(m2) - 1u;
+                            const uint32_t cb = (uint32_t)(cols >> (8u * bb)) & 0xFFu;
+                            PW[at2++] = (row << 19) | (a << 16) | (bb << 13) | (ca * (uint32_t)LD + cb);
+                        }
+                    }
+                }
+                n_pw += (uint32_t)__builtin_amdgcn_readlane((int)inc2, 63);
+                n_pe += (uint32_t)__builtin_amdgcn_readlane((int)inc1, 63);
+            }
+            use_packed = n_pw <= L.pw_cap && n_pe <= L.pe_cap;
+            __syncthreads();
+        }
+
         // evaluates all rows at XS[buf] into G[buf], R[buf]; returns SSE (wave-uniform)
         auto eval_rows = [&](int buf) -> T {
             const T* xs = XS + buf * vt;
@@ -401,6 +463,22 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             for (uint32_t i = lane; i < (uint32_t)(N * LD); i += 64) Amat[i] = T(0);
             if (lane < N) rhsv[lane] = T(0);
             __syncthreads();
+            if (use_packed) {
+                const T* Gb = G + (size_t)buf * mr * 8;
+                for (uint32_t t = lane; t < n_pw; t += 64) {
+                    const uint32_t w = PW[t];
+                    const uint32_t gb = (w >> 19) * 8u;
+                    lds_add(&Amat[w & 0x1FFFu], Gb[gb + ((w >> 16) & 7u)] * Gb[gb + ((w >> 13) & 7u)]);
+                }
+                for (uint32_t t = lane; t < n_pe; t += 64) {
+                    const uint32_t w = PE[t];
+                    const uint32_t row = w >> 9;
+                    lds_add(&rhsv[w & 63u], Gb[row * 8u + ((w >> 6) & 7u)] * -R[buf * mr + row]);
+                }
+                if (lane < N && (uint32_t)lane >= nfree) Amat[lane * LD + lane] = T(1);  // identity padding
+                __syncthreads();
+                return;
+            }
             const int e1 = lane >> 3, e2 = lane & 7;
             constexpr int RB = 4;  // rows per batch: all loads of a batch are issued before its atomics
             for (uint32_t row0 = 0; row0 < m_rows; row0 += RB) {
@@ -1055,7 +1133,7 @@ static hipError_t launch_solve_global_n(const DeviceBatch& b, const LmParams& p,
 
 static hipError_t launch_solve_global(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     uint32_t n = pad_n(b.max_unit_free_g);
-    SolveLayout L = make_layout(n, 8u, b.max_unit_rows_g, 8u);  // System-wide vectors are not in LDS
+    SolveLayout L = make_layout(n, 8u, b.max_unit_rows_g, 8u, false, b.max_pairs_g, b.max_ents_g);  // System-wide vectors are not in LDS
     switch (n) {
         case 8: return launch_solve_global_n<8>(b, p, L, stream);
         case 16: return launch_solve_global_n<16>(b, p, L, stream);
@@ -1083,7 +1161,7 @@ template <typename T, bool UNITS, int OPT>
 static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     uint32_t n = pad_n(UNITS ? b.max_unit_free : b.max_free);
     const uint32_t rows = (UNITS && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
-    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1);
+    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, b.max_pairs, b.max_ents);
     switch (n) {
         case 8: return launch_solve_n<8, T, false, UNITS, OPT>(b, p, L, stream);
         case 16: return launch_solve_n<16, T, false, UNITS, OPT>(b, p, L, stream);
@@ -1102,7 +1180,7 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);
         if (n != 32 || p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS))) return hipErrorInvalidValue;
-        SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u);
+        SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents);
         return launch_solve_n<32, double, true, false, 0>(b, p, L, stream);
     }
     const bool units = (p.mode & MODE_UNITS) != 0;
