@@ -198,6 +198,25 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     const uint32_t ncomp = b.sys_ncomp[s];
     const fx_lm_opts o = prm.lm;
 
+    // ---- the first 64 variables / expressions of the System, fetched up front in one round trip (for
+    // the headline shape that is all of them). Element `lane` of every per-variable / per-expression
+    // array sits in a register; the accessors fall back to a load for any other index.
+    const bool pf_hv = (uint32_t)lane < nvt, pf_he = (uint32_t)lane < net;
+    const double pf_var = pf_hv ? b.vars0[v0 + lane] : 0.0;
+    const uint16_t pf_info = pf_hv ? b.var_info[v0 + lane] : (uint16_t)0;
+    const int pf_tag = pf_he ? (int)(b.expr_tag[e0 + lane] & 0x7F) : 0;
+    const double pf_param = pf_he ? b.expr_param[e0 + lane] : 0.0;
+    const uint16_t pf_comp = pf_he ? b.expr_comp[e0 + lane] : (uint16_t)0xFFFF;
+    const ushort4 pf_idx = pf_he ? reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + lane] : make_ushort4(0, 0, 0, 0);
+    auto ld_var = [&](uint32_t i) -> double { return i == (uint32_t)lane ? pf_var : b.vars0[v0 + i]; };
+    auto ld_info = [&](uint32_t i) -> uint16_t { return i == (uint32_t)lane ? pf_info : b.var_info[v0 + i]; };
+    auto ld_tag = [&](uint32_t i) -> int { return i == (uint32_t)lane ? pf_tag : (int)(b.expr_tag[e0 + i] & 0x7F); };
+    auto ld_param = [&](uint32_t i) -> double { return i == (uint32_t)lane ? pf_param : b.expr_param[e0 + i]; };
+    auto ld_comp = [&](uint32_t i) -> uint16_t { return i == (uint32_t)lane ? pf_comp : b.expr_comp[e0 + i]; };
+    auto ld_idx = [&](uint32_t i) -> ushort4 {
+        return i == (uint32_t)lane ? pf_idx : reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i];
+    };
+
     // ---- K0a: system scale = sqrt((sum v^2 + sum d^2) / count), summed strictly in reference
     // order (assemble/mod.rs:32-44, utils.rs:11-33) so the scale is bit-identical. ------------
     double scale = 1.0, scale_recip = 1.0;
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             uint32_t i = base + lane;
             double t = 0.0;
             if (i < nvt) {
-                double v = b.vars0[v0 + i];
+                double v = ld_var(i);
                 t = v * v;
             }
             uint32_t cnt = min(64u, nvt - base);
@@ -219,10 +238,10 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             double t = 0.0;
             bool isd = false;
             if (i < net) {
-                int tag = b.expr_tag[e0 + i] & 0x7F;
+                int tag = ld_tag(i);
                 isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
                 if (isd) {
-                    double d = b.expr_param[e0 + i];
+                    double d = ld_param(i);
                     t = d * d;
                 }
             }
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
 
     // ---- scaled snapshot of all variables (both halves of XS), output defaults to input ------
     for (uint32_t i = lane; i < nvt; i += 64) {
-        double v = b.vars0[v0 + i];
+        double v = ld_var(i);
         double xsv = (prm.mode & 1u) ? v * scale_recip : v;
         XS[i] = (T)xsv;
         XS[vt + i] = (T)xsv;
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     uint32_t i = base + lane;
                     bool in = false;
                     if (i < nvt) {
-                        uint16_t info = b.var_info[v0 + i];
+                        uint16_t info = ld_info(i);
                         in = ((info & VAR_COMP_MASK) == ud.comp) && !(info & VAR_FIXED_BIT);
                     }
                     uint64_t mk = __ballot(in);
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                         double f1 = (1.0 / 4294967295.0) * (double)st;
                         st = st * 1664525u + 1013904223u;
                         double f2 = (1.0 / 4294967295.0) * (double)st;
-                        double x = b.vars0[v0 + i];
+                        double x = ld_var(i);
                         if (prm.mode & 1u) x = x * scale_recip;
                         x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
                         XS[i] = (T)x;
@@ -302,12 +321,12 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         __syncthreads();
         for (uint32_t pos = lane; pos < m_rows; pos += 64) {  // rows in block order
             uint32_t i = b.unit_rows[ud.row_off + pos];
-            int tag = b.expr_tag[e0 + i] & 0x7F;
-            const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
-            uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+            int tag = ld_tag(i);
+            const ushort4 f4 = ld_idx(i);
+            uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
             uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int k = expand_vars(tag, ff, vars8);
-            double prm_e = b.expr_param[e0 + i];
+            double prm_e = ld_param(i);
             if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
             rtag[pos] = (uint8_t)tag;
             P[pos] = (T)prm_e;
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             uint32_t i = base + lane;
             bool in = false;
             if (i < nvt) {
-                uint16_t info = b.var_info[v0 + i];
+                uint16_t info = ld_info(i);
                 in = ((info & VAR_COMP_MASK) == c) && !(info & VAR_FIXED_BIT);
             }
             uint64_t m = __ballot(in);
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         bool any_var = false;
         for (uint32_t base = 0; base < nvt; base += 64) {
             uint32_t i = base + lane;
-            bool in = (i < nvt) && ((b.var_info[v0 + i] & VAR_COMP_MASK) == c);
+            bool in = (i < nvt) && ((ld_info(i) & VAR_COMP_MASK) == c);
             any_var = any_var || (__ballot(in) != 0ull);
         }
         if (!uniform(any_var)) continue;
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             if ((uint32_t)lane < nfree) {
                 uint32_t vi = fidx[lane];
                 // recomputed from the f64 input so the f64 start point is bit-identical to the reference
-                double x = b.vars0[v0 + vi];
+                double x = ld_var(vi);
                 if (prm.mode & 1u) x = x * scale_recip;
                 x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
                 XS[vi] = (T)x;
@@ -365,16 +384,16 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         // ---- rows of the component: ascending expression id (:139-145) ----------------------
         for (uint32_t base = 0; base < net; base += 64) {
             uint32_t i = base + lane;
-            bool in = (i < net) && (b.expr_comp[e0 + i] == c);
+            bool in = (i < net) && (ld_comp(i) == c);
             uint64_t mk = __ballot(in);
             uint32_t pos = m_rows + (uint32_t)__popcll(mk & lanemask_lt(lane));
             if (in) {
-                int tag = b.expr_tag[e0 + i] & 0x7F;
-                const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
-                uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+                int tag = ld_tag(i);
+                const ushort4 f4 = ld_idx(i);
+                uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
                 uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 int k = expand_vars(tag, ff, vars8);
-                double prm_e = b.expr_param[e0 + i];
+                double prm_e = ld_param(i);
                 if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
                 rtag[pos] = (uint8_t)tag;
                 P[pos] = (T)prm_e;
@@ -812,15 +831,15 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     const double* XD = VOUT;
     double part = 0.0;
     for (uint32_t i = lane; i < net; i += 64) {
-        int tag = b.expr_tag[e0 + i] & 0x7F;
-        const uint16_t* f = b.expr_idx + 4 * (size_t)(e0 + i);
-        uint16_t ff[4] = {f[0], f[1], f[2], f[3]};
+        int tag = ld_tag(i);
+        const ushort4 f4 = ld_idx(i);
+        uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
         uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         expand_vars(tag, ff, vars8);
         double v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = XD[vars8[e]];
-        double r = eval_expression<double, false>(tag, v, b.expr_param[e0 + i], g);
+        double r = eval_expression<double, false>(tag, v, ld_param(i), g);
         part += r * r;
     }
     double sse_u = wave_sum(part);
