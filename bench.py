@@ -218,7 +218,8 @@ def main() -> int:
 def other_workloads(ctx, abi, workloads, np, n_sys: int):
     """Reported beside the headline, never part of `value`: the reference's own bench generator
     (`add_hinged_triangles(n = 11)`, fiksi_bench.rs:15-40: 33 distance constraints, 46 variables) as a
-    batch of the same size, with Decomposer::None and Decomposer::SinglePass; N = 1 runs only."""
+    batch of the same size, with Decomposer::None and Decomposer::SinglePass, and cfg5's per-GPU share in
+    f32; N = 1 runs only."""
     out = {}
     b = workloads.hinged_triangles(n_sys, 11)
     db = ctx.upload(b)
@@ -236,6 +237,23 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
             "systems": n_sys, "ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3),
             "converged_fraction": conv / n_sys, "gn_iters_per_sec": int(res["accepted"].sum()) / (ms * 1e-3),
         }
+    db.free()
+    # cfg5's per-GPU share: 125 000 inconsistent (over-constrained least-squares) ring sketches, f32
+    b5 = workloads.ring16(125_000, inconsistent=True)
+    db = ctx.upload(b5)
+    o32 = abi.solving_opts(f32=True)
+    db.system_solve(o32)
+    ctx.synchronize()
+    ctx.timer_begin()
+    for _ in range(3):
+        db.system_solve(o32)
+    ms = ctx.timer_end() / 3
+    res = db.get_results()
+    settled = int(np.count_nonzero(res["exit"] <= 2))  # SSE / step / ftol exits (cfg5 "converged")
+    out["cfg5_share_f32"] = {
+        "systems": 125_000, "dtype": "f32", "ms_per_step": ms, "settled_systems_per_sec": settled / (ms * 1e-3),
+        "settled_fraction": settled / 125_000, "gn_iters_per_sec": int(res["accepted"].sum()) / (ms * 1e-3),
+    }
     db.free()
     return out
 

@@ -201,20 +201,23 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     // ---- the first 64 variables / expressions of the System, fetched up front in one round trip (for
     // the headline shape that is all of them). Element `lane` of every per-variable / per-expression
     // array sits in a register; the accessors fall back to a load for any other index.
-    const bool pf_hv = (uint32_t)lane < nvt, pf_he = (uint32_t)lane < net;
+    // (not in the block-walking instantiations: their rows come in block order, and the many small
+    // blocks run better with the registers left to occupancy)
+    constexpr bool PF = !UNITS;
+    const bool pf_hv = PF && (uint32_t)lane < nvt, pf_he = PF && (uint32_t)lane < net;
     const double pf_var = pf_hv ? b.vars0[v0 + lane] : 0.0;
     const uint16_t pf_info = pf_hv ? b.var_info[v0 + lane] : (uint16_t)0;
     const int pf_tag = pf_he ? (int)(b.expr_tag[e0 + lane] & 0x7F) : 0;
     const double pf_param = pf_he ? b.expr_param[e0 + lane] : 0.0;
     const uint16_t pf_comp = pf_he ? b.expr_comp[e0 + lane] : (uint16_t)0xFFFF;
     const ushort4 pf_idx = pf_he ? reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + lane] : make_ushort4(0, 0, 0, 0);
-    auto ld_var = [&](uint32_t i) -> double { return i == (uint32_t)lane ? pf_var : b.vars0[v0 + i]; };
-    auto ld_info = [&](uint32_t i) -> uint16_t { return i == (uint32_t)lane ? pf_info : b.var_info[v0 + i]; };
-    auto ld_tag = [&](uint32_t i) -> int { return i == (uint32_t)lane ? pf_tag : (int)(b.expr_tag[e0 + i] & 0x7F); };
-    auto ld_param = [&](uint32_t i) -> double { return i == (uint32_t)lane ? pf_param : b.expr_param[e0 + i]; };
-    auto ld_comp = [&](uint32_t i) -> uint16_t { return i == (uint32_t)lane ? pf_comp : b.expr_comp[e0 + i]; };
+    auto ld_var = [&](uint32_t i) -> double { return (PF && i == (uint32_t)lane) ? pf_var : b.vars0[v0 + i]; };
+    auto ld_info = [&](uint32_t i) -> uint16_t { return (PF && i == (uint32_t)lane) ? pf_info : b.var_info[v0 + i]; };
+    auto ld_tag = [&](uint32_t i) -> int { return (PF && i == (uint32_t)lane) ? pf_tag : (int)(b.expr_tag[e0 + i] & 0x7F); };
+    auto ld_param = [&](uint32_t i) -> double { return (PF && i == (uint32_t)lane) ? pf_param : b.expr_param[e0 + i]; };
+    auto ld_comp = [&](uint32_t i) -> uint16_t { return (PF && i == (uint32_t)lane) ? pf_comp : b.expr_comp[e0 + i]; };
     auto ld_idx = [&](uint32_t i) -> ushort4 {
-        return i == (uint32_t)lane ? pf_idx : reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i];
+        return (PF && i == (uint32_t)lane) ? pf_idx : reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i];
     };
 
     // ---- K0a: system scale = sqrt((sum v^2 + sum d^2) / count), summed strictly in reference
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         uint32_t* PE = reinterpret_cast<uint32_t*>(smem + L.off_pe);
         uint32_t n_pw = 0, n_pe = 0;
         bool use_packed = false;
-        if (OPT == 0 && L.pw_cap) {
+        if (OPT == 0 && L.pw_cap && m_rows > 8u) {  // a handful of rows is cheaper on the lane grid than listing them
             for (uint32_t base = 0; base < m_rows; base += 64) {
                 const uint32_t row = base + lane;
                 uint32_t mask = 0;
@@ -1180,7 +1183,9 @@ template <typename T, bool UNITS, int OPT>
 static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     uint32_t n = pad_n(UNITS ? b.max_unit_free : b.max_free);
     const uint32_t rows = (UNITS && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
-    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, b.max_pairs, b.max_ents);
+    // block walking: blocks of up to 8 rows never list their products (see the kernel), so no LDS for it
+    const bool lists = !UNITS || b.max_unit_rows > 8u;
+    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, lists ? b.max_pairs : 0u, lists ? b.max_ents : 0u);
     switch (n) {
         case 8: return launch_solve_n<8, T, false, UNITS, OPT>(b, p, L, stream);
         case 16: return launch_solve_n<16, T, false, UNITS, OPT>(b, p, L, stream);
