@@ -24,7 +24,7 @@ namespace fx {
 
 struct WideLayout {
     uint32_t vt, mr, n;  // padded variables per System, rows per component, free variables per component
-    uint32_t off_xs, off_vout, off_l, off_rhs, off_delta, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx,
+    uint32_t off_xs, off_vout, off_l, off_rhs, off_delta, off_aux, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx,
         off_colof;
     uint32_t total;
 };
@@ -44,6 +44,7 @@ static WideLayout make_wide_layout(uint32_t max_free, uint32_t max_vars, uint32_
     L.off_l = take(L.n * (L.n + 1u) / 2u * 8u);
     L.off_rhs = take(L.n * 8u);
     L.off_delta = take(L.n * 8u);
+    L.off_aux = take(L.n * 8u);
     L.off_g = take(2u * L.mr * 8u * 8u);
     L.off_r = take(2u * L.mr * 8u);
     L.off_p = take(L.mr * 8u);
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
     double* Lm = reinterpret_cast<double*>(smem + L.off_l);       // packed lower triangle
     double* RHS = reinterpret_cast<double*>(smem + L.off_rhs);    // [n] -Jt r at the current point
     double* DEL = reinterpret_cast<double*>(smem + L.off_delta);  // [n] right-hand side -> step
+    double* AUX = reinterpret_cast<double*>(smem + L.off_aux);    // [n] the unrefined step (FX_STEP_CHOLESKY_REFINED)
     double* G = reinterpret_cast<double*>(smem + L.off_g);        // [2][mr][8]
     double* R = reinterpret_cast<double*>(smem + L.off_r);        // [2][mr]
     double* P = reinterpret_cast<double*>(smem + L.off_p);        // [mr]
@@ -336,7 +338,43 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
                 }
                 for (uint32_t i = lane; i < nfree; i += 64) DEL[i] = RHS[i];
                 __syncthreads();
-                const double dn2 = solve();
+                double dn2 = solve();
+                if (o.solver == FX_STEP_CHOLESKY_REFINED) {
+                    // corrected semi-normal equations, as in lm_solve_kernel: t = -r - J delta from the rows,
+                    // (JtJ + lambda I) e = Jt t - lambda delta with the factor at hand, delta += e
+                    double* tr = R + (cur ^ 1) * mr;
+                    for (uint32_t i = lane; i < nfree; i += 64) AUX[i] = DEL[i];
+                    __syncthreads();
+                    for (uint32_t row = lane; row < m_rows; row += 64) {
+                        double acc = -R[cur * mr + row];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int cc = gcol[row * 8 + e];
+                            if (cc >= 0) acc -= G[(cur * mr + row) * 8 + e] * AUX[cc];
+                        }
+                        tr[row] = acc;
+                    }
+                    for (uint32_t i = lane; i < nfree; i += 64) DEL[i] = 0.0;
+                    __syncthreads();
+                    for (uint32_t row = 0; row < m_rows; ++row) {
+                        if (lane < 8) {
+                            const int cc = gcol[row * 8 + lane];
+                            if (cc >= 0) lds_add(&DEL[cc], G[(cur * mr + row) * 8 + lane] * tr[row]);
+                        }
+                    }
+                    __syncthreads();
+                    for (uint32_t i = lane; i < nfree; i += 64) DEL[i] -= lambda * AUX[i];
+                    __syncthreads();
+                    (void)solve();
+                    double part = 0.0;
+                    for (uint32_t i = lane; i < nfree; i += 64) {
+                        const double d2 = AUX[i] + DEL[i];
+                        DEL[i] = d2;
+                        part += d2 * d2;
+                    }
+                    dn2 = wave_sum(part);
+                    __syncthreads();
+                }
                 if (!(dn2 == dn2)) {
                     exit_code = FX_EXIT_NAN;
                     done = true;
