@@ -136,3 +136,39 @@ def test_one_million_systems_in_one_batch(fiksi, ctx):
     assert np.array_equal(r1, r2)
     assert np.isin(r1["exit"], (1, 2)).mean() > 0.99
     assert r1["accepted"].sum() > 4 * n
+
+
+def test_fully_fixed_and_unconstrained_parts(fiksi, oracle, ctx):
+    """A component whose variables are all fixed (zero free columns, constraints still present), a
+    constraint between two fixed points inside a free component, and free points no constraint touches:
+    nothing moves that must not move, counts and exits equal the oracle's."""
+    F = fiksi
+    s = F.System()
+    a = F.elements.Point.create(s, 0., 0.)
+    b = F.elements.Point.create(s, 3., 4.)
+    F.constraints.PointPointDistance.create(s, a, b, 7.)   # infeasible, both ends fixed
+    a.fix(s)
+    b.fix(s)
+    c = F.elements.Point.create(s, 1., 1.)
+    d = F.elements.Point.create(s, 2., 3.)
+    e = F.elements.Point.create(s, 5., 1.)
+    F.constraints.PointPointDistance.create(s, c, d, 2.)
+    F.constraints.PointPointDistance.create(s, d, e, 2.)
+    F.constraints.PointPointDistance.create(s, c, e, 3.)
+    c.fix(s)
+    e.fix(s)
+    F.constraints.PointPointDistance.create(s, c, e, 9.)   # fixed-fixed row inside a free component
+    lonely = F.elements.Point.create(s, -4., 2.5)          # no constraint: not part of any component's rows
+    flat = s.flatten()
+    v, res = ctx.system_solve_batch(flat)
+    v_o, res_o = oracle.solve_batch(flat, mode=3, trial_cap=4096)
+    assert res["ncomp"][0] == res_o["ncomp"][0]
+    assert res["accepted"][0] == res_o["accepted"][0] and res["exit"][0] == res_o["exit"][0]
+    fx = flat["var_fixed"] == 1
+    assert np.array_equal(v[fx], flat["vars"][fx])
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    # the lonely point is perturbed-and-written-back or left alone exactly as the oracle does
+    assert np.array_equal(v[-2:], v_o[-2:])
+    for opts in (F.abi.solving_opts(decomposer=1), F.abi.solving_opts(optimizer=1)):
+        v2, res2 = ctx.system_solve_batch(flat, opts)
+        assert np.array_equal(v2[fx], flat["vars"][fx]) and np.all(np.isfinite(v2))
