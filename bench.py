@@ -69,6 +69,9 @@ def main() -> int:
 
     import numpy as np
 
+    if world > 1 or os.environ.get("FIKSI_BENCH_FORCE_DIST") == "1":
+        import torch  # noqa: F401  (before fiksi_amd: one shared HIP runtime per process, see fiksi_amd/_lib.py)
+
     import __graft_entry__ as graft
 
     graft.build()
@@ -78,7 +81,10 @@ def main() -> int:
     dist = None
     torch = None
     reduce_device = None
-    if world > 1:
+    # FIKSI_BENCH_FORCE_DIST=1 (rehearsal): bring up the process group even for one rank, so that the RCCL
+    # code path (init, barrier, all-reduce on device tensors) can be exercised on a 1-GPU box
+    force_dist = os.environ.get("FIKSI_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
 

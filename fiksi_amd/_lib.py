@@ -17,6 +17,38 @@ if not os.path.exists(LIB_PATH):
         "(or `make -C fiksi_amd/csrc`). fiksi_amd has no pure-Python or CPU fallback."
     )
 
+
+
+def _share_hip_runtime_with_torch() -> str:
+    """One process can hold only one HIP/ROCr runtime. PyTorch-ROCm wheels bundle their own
+    (``torch/lib/libamdhip64.so``, SONAME ``libamdhip64.so.7`` like the system one), and this library is
+    linked against ``libamdhip64.so.7``: if torch is imported first the loader hands us torch's copy and
+    all is well, but if we come first the system copy is loaded, a later ``import torch`` brings its own
+    second runtime, and whichever initialises the GPU second finds no device. So when torch is installed
+    its runtime is loaded here, ahead of ours, and both sides share it in either import order.
+    ``FIKSI_AMD_HIP_RUNTIME=system`` opts out (processes that never import torch)."""
+    import sys
+
+    if os.environ.get("FIKSI_AMD_HIP_RUNTIME", "auto") == "system":
+        return "system"
+    if "torch" in sys.modules:
+        return "torch (already imported)"
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return "system"
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if not os.path.exists(path):
+            return "system"
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        return "torch (preloaded)"
+    except Exception:  # a broken torch install must not break this library
+        return "system"
+
+
+HIP_RUNTIME = _share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 
 u8p, u16p, u32p, u64p = (C.POINTER(t) for t in (C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64))

@@ -15,7 +15,7 @@ def rank_seed(base_seed: int, rank: int, systems_per_rank: int) -> int:
 def reduce_throughput(dist, elapsed_s: float, counters: Sequence[int], device=None) -> Tuple[float, list]:
     """MAX of the elapsed time and SUM of the integer counters over all ranks (identity without a
     process group)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(elapsed_s), [int(c) for c in counters]
     import torch
 
