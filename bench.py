@@ -94,6 +94,10 @@ def main() -> int:
         backend = os.environ.get("FIKSI_BENCH_BACKEND", "nccl")
         if "FIKSI_BENCH_DEVICE" in os.environ:
             local_rank = int(os.environ["FIKSI_BENCH_DEVICE"])
+        # a launcher that masks devices per rank (HIP_VISIBLE_DEVICES) leaves each rank one device, index 0
+        n_visible = torch.cuda.device_count()
+        if n_visible and local_rank >= n_visible:
+            local_rank = local_rank % n_visible
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
