@@ -213,7 +213,7 @@ def main() -> int:
         }
         if world == 1:
             out["other_workloads"] = other_workloads(ctx, abi, workloads, np, n_sys)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
         print(json.dumps(out), flush=True)
 
