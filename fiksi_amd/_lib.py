@@ -128,6 +128,7 @@ SIGNATURES = [
     ("fx_eval_residual_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp]),
     ("fx_constraint_residuals", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     ("fx_analyze_batch", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
+    ("fx_eval_residual_dense_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp, _vp, _vp]),
     ("fx_single_pass_blocks", C.c_int, [C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
     # builder
     ("fxs_system_new", C.c_int, [C.POINTER(_vp)]),

@@ -204,6 +204,26 @@ class Context:
         check(lib.fx_eval_residual_jacobian(self._h, C.byref(st), _ptr(r), _ptr(vals)), "fx_eval_residual_jacobian")
         return r, (row_ptr, col, vals)
 
+    def eval_residual_dense_jacobian(self, arrays):
+        """Problem::calculate_residuals_and_jacobian: (residuals, [dense row-major J of every System])."""
+        a = normalize_batch(arrays)
+        st = as_struct(a)
+        n = len(a["var_off"]) - 1
+        off = np.zeros(n + 1, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(lib.fx_eval_residual_dense_jacobian(self._h, C.byref(st), None, None, _ptr(off), C.byref(total)),
+              "fx_eval_residual_dense_jacobian")
+        r = np.zeros(int(a["expr_off"][-1]) if n else 0, dtype=np.float64)
+        jac = np.zeros(max(int(total.value), 1), dtype=np.float64)
+        check(lib.fx_eval_residual_dense_jacobian(self._h, C.byref(st), _ptr(r), _ptr(jac), _ptr(off), C.byref(total)),
+              "fx_eval_residual_dense_jacobian")
+        blocks = []
+        for s in range(n):
+            m = int(a["expr_off"][s + 1] - a["expr_off"][s])
+            blk = jac[int(off[s]):int(off[s + 1])]
+            blocks.append(blk.reshape(m, -1) if m and len(blk) else blk.reshape(m, 0))
+        return r, blocks
+
     def analyze_batch(self, arrays):
         """System::analyze per system: 1 per expression that over-constrains (does not increase the rank)."""
         a = normalize_batch(arrays)

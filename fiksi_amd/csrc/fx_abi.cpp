@@ -1164,6 +1164,55 @@ int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_bl
     return FX_OK;
 }
 
+int fx_eval_residual_dense_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jac, uint64_t* jac_off,
+                                    uint64_t* total) {
+    int rc = analyze(batch, nullptr);
+    if (rc) return rc;
+    const uint32_t n = batch->n_systems;
+    const uint32_t nv = n ? batch->var_off[n] : 0, ne = n ? batch->expr_off[n] : 0;
+    // free rank per variable (as in fx_jacobian_structure), sizes and offsets of the dense blocks
+    std::vector<uint16_t> var_rank(nv, 0xFFFFu), sys_nfree(n, 0);
+    std::vector<uint32_t> expr_sys(ne, 0);
+    std::vector<uint64_t> off((size_t)n + 1, 0);
+    for (uint32_t s = 0; s < n; ++s) {
+        uint32_t rank = 0;
+        for (uint32_t i = batch->var_off[s]; i < batch->var_off[s + 1]; ++i) {
+            const uint16_t c = batch->var_comp ? batch->var_comp[i] : 0;
+            if (c != FX_NO_COMPONENT && !batch->var_fixed[i]) var_rank[i] = (uint16_t)rank++;
+        }
+        sys_nfree[s] = (uint16_t)rank;
+        for (uint32_t e = batch->expr_off[s]; e < batch->expr_off[s + 1]; ++e) expr_sys[e] = s;
+        off[s + 1] = off[s] + (uint64_t)(batch->expr_off[s + 1] - batch->expr_off[s]) * rank;
+    }
+    if (total) *total = off[n];
+    if (jac_off) std::copy(off.begin(), off.end(), jac_off);
+    if (!jac && !r) return FX_OK;  // size query
+    if (!jac) return fail(FX_ERR_INVALID, "jac is NULL");
+    fx_dbatch* db = nullptr;
+    rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    uint16_t *d_rank = nullptr, *d_nfree = nullptr;
+    uint32_t* d_sys = nullptr;
+    uint64_t* d_off = nullptr;
+    double *d_jac = nullptr, *d_r = nullptr;
+    rc = dev_alloc_copy(ctx, db, &d_rank, var_rank.data(), var_rank.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d_nfree, sys_nfree.data(), sys_nfree.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d_sys, expr_sys.data(), expr_sys.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d_off, off.data(), off.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d_jac, (const double*)nullptr, (size_t)off[n]);
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d_r, (const double*)nullptr, ne);
+    if (!rc) {
+        hipError_t e = fx::launch_dense_jacobian(db->d, db->d.vars0, d_rank, d_sys, d_nfree, d_off, d_r, d_jac, ctx->stream);
+        if (e == hipSuccess && off[n])
+            e = hipMemcpyAsync(jac, d_jac, (size_t)off[n] * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && r && ne) e = hipMemcpyAsync(r, d_r, (size_t)ne * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(FX_ERR_HIP, "dense Jacobian evaluation failed: %s", hipGetErrorString(e));
+    }
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
 int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r) {
     if (!r) return fail(FX_ERR_INVALID, "r is NULL");
     fx_dbatch* db = nullptr;

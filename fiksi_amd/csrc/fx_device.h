@@ -99,6 +99,9 @@ struct LmParams {
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);
 hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream);
+hipError_t launch_dense_jacobian(const DeviceBatch& b, const double* x, const uint16_t* var_rank, const uint32_t* expr_sys,
+                                 const uint16_t* sys_nfree, const uint64_t* dense_off, double* resid, double* jac,
+                                 hipStream_t stream);
 hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t wide_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes(const DeviceBatch& b);

@@ -1276,6 +1276,50 @@ hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian
     return hipGetLastError();
 }
 
+// Problem::calculate_residuals_and_jacobian (subsystem.rs:106-124): the dense row-major Jacobian of
+// every System, [n_exprs_s x n_free_s] at dense_off[s]; one thread per row zeroes its row and then writes
+// the partials in gradient order, so a later entry of the same column overwrites an earlier one
+// (expressions.rs:993-1008, quirk Q4). var_rank: system-local free rank of every variable or 0xFFFF.
+__global__ __launch_bounds__(256) void dense_jacobian_kernel(DeviceBatch b, const double* __restrict__ x,
+                                                             const uint16_t* __restrict__ var_rank,
+                                                             const uint32_t* __restrict__ expr_sys,
+                                                             const uint16_t* __restrict__ sys_nfree,
+                                                             const uint64_t* __restrict__ dense_off,
+                                                             double* __restrict__ resid, double* __restrict__ jac) {
+    const uint32_t row = blockIdx.x * 256u + threadIdx.x;
+    if (row >= b.n_exprs) return;
+    const uint32_t s = expr_sys[row];
+    const uint32_t v0 = b.var_off[s], e0 = b.expr_off[s];
+    const uint32_t nfree = sys_nfree[s];
+    const int tag = b.expr_tag[row] & 0x7F;
+    ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int k = expand_vars(tag, ff, vars8);
+    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
+    resid[row] = eval_expression<double, true>(tag, v, b.expr_param[row], g);
+    double* out = jac + dense_off[s] + (uint64_t)(row - e0) * nfree;
+    for (uint32_t c = 0; c < nfree; ++c) out[c] = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (e < k) {
+            const uint16_t c = var_rank[v0 + vars8[e]];
+            if (c != 0xFFFFu) out[c] = g[e];
+        }
+    }
+}
+
+hipError_t launch_dense_jacobian(const DeviceBatch& b, const double* x, const uint16_t* var_rank, const uint32_t* expr_sys,
+                                 const uint16_t* sys_nfree, const uint64_t* dense_off, double* resid, double* jac,
+                                 hipStream_t stream) {
+    if (b.n_exprs == 0) return hipSuccess;
+    dim3 grid((b.n_exprs + 255u) / 256u), block(256);
+    hipLaunchKernelGGL(dense_jacobian_kernel, grid, block, 0, stream, b, x, var_rank, expr_sys, sys_nfree, dense_off, resid, jac);
+    return hipGetLastError();
+}
+
 hipError_t launch_identity_residuals(const DeviceBatch& b, const double* x, double* out, hipStream_t stream) {
     if (b.n_exprs == 0) return hipSuccess;
     dim3 grid((b.n_exprs + 255u) / 256u), block(256);

@@ -14,6 +14,7 @@
  *
  *   fx_eval_residual_jacobian*  == Problem::calculate_residuals_and_sparse_jacobian (subsystem.rs:126-166)
  *   fx_eval_residual*           == Problem::calculate_residuals                    (subsystem.rs:93-104)
+ *   fx_eval_residual_dense_jacobian == Problem::calculate_residuals_and_jacobian   (subsystem.rs:106-124)
  *   fx_lm_solve*                == levenberg_marquardt(Subsystem)                  (lm.rs:21-193)
  *   fx_system_solve*            == assemble::solve, Decomposer::None, LM           (assemble/mod.rs:46-167)
  *   fx_constraint_residuals*    == ConstraintHandle::calculate_residual            (constraints/mod.rs:88-110)
@@ -240,6 +241,14 @@ int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts
 /* == Problem::calculate_residuals_and_sparse_jacobian at batch->vars; jvals in
  * fx_jacobian_structure order (may be NULL for residuals only). */
 int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals);
+/* == Problem::calculate_residuals_and_jacobian (subsystem.rs:106-124), the dense variant L-BFGS and
+ * analyze use: per System a row-major [n_exprs_s x n_free_s] block at jac[jac_off[s]], columns = the
+ * free rank of fx_jacobian_structure; partials of fixed variables are dropped and — unlike the sparse
+ * variant, which sums — a later partial of the same column overwrites an earlier one
+ * (expressions.rs:993-1008). jac_off (n_systems + 1 entries) and total (doubles in jac) are outputs and
+ * may be NULL; with r == jac == NULL only they are filled in (size query, no device needed). */
+int fx_eval_residual_dense_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jac, uint64_t* jac_off,
+                                    uint64_t* total);
 /* == System::analyze -> analyze::numerical::find_overconstraints (analyze/numerical/mod.rs:123-163):
  * dependent[e] = 1 for every expression that does not increase the rank of the dense Jacobian at
  * batch->vars (all variables free, no scaling, no perturbation), n_exprs entries. */

@@ -411,6 +411,41 @@ int fo_maximum_matching(uint32_t nvars, uint32_t nexprs, const uint32_t* eptr, c
     return card;
 }
 
+// Problem::calculate_residuals_and_jacobian (subsystem.rs:106-124) with every non-fixed variable of a
+// component free (columns = ascending rank, as in the sparse structure) and every expression a row: the
+// dense row-major Jacobian of System s at jac[jac_off[s]]; jac_off has n_systems + 1 entries (filled
+// here); jac may be NULL to get the offsets only.
+int fo_eval_dense_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* expr_off, const double* vars,
+                        const uint8_t* var_fixed, const uint8_t* expr_tag, const uint32_t* expr_idx,
+                        const double* expr_param, const uint16_t* var_comp, double* residuals, double* jac,
+                        uint64_t* jac_off) {
+    jac_off[0] = 0;
+    for (uint32_t s = 0; s < n_systems; ++s) {
+        FlatSystem sys = make_system(s, var_off, expr_off, vars, var_fixed, expr_tag, expr_idx, expr_param, var_comp, nullptr);
+        Subsystem sub;
+        sub.system_variables = sys.variables.data();
+        sub.all_expressions = sys.expressions.data();
+        sub.free_index.assign(sys.variables.size(), -1);
+        for (uint32_t v = 0; v < sys.variables.size(); ++v) {
+            uint16_t c = var_comp ? var_comp[var_off[s] + v] : 0;
+            if (c != 0xFFFF && !sys.fixed[v]) {
+                sub.free_index[v] = static_cast<int32_t>(sub.free_variables.size());
+                sub.free_variables.push_back(v);
+            }
+        }
+        for (uint32_t e = 0; e < sys.expressions.size(); ++e) sub.expressions.push_back(e);
+        const size_t nv = sub.free_variables.size(), ne = sub.expressions.size();
+        jac_off[s + 1] = jac_off[s] + static_cast<uint64_t>(nv) * ne;
+        if (!jac) continue;
+        std::vector<double> x(nv), r(ne, 0.), j(nv * ne, 0.);
+        for (size_t k = 0; k < nv; ++k) x[k] = sys.variables[sub.free_variables[k]];
+        lbfgs_detail::residuals_and_dense_jacobian(sub, x.data(), r.data(), j.data());
+        std::copy(j.begin(), j.end(), jac + jac_off[s]);
+        if (residuals) std::copy(r.begin(), r.end(), residuals + expr_off[s]);
+    }
+    return 0;
+}
+
 // permutation.rs:41-80: applies the gather permutation to `values` in place through the swap
 // sequence; returns the number of swaps.
 int fo_permute(uint32_t n, const uint32_t* permutation, double* values) {

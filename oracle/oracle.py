@@ -276,3 +276,19 @@ def maximum_matching(nvars: int, expressions, free=None):
     card = lib().fo_maximum_matching(C.c_uint32(nvars), C.c_uint32(len(expressions)), _p(eptr), _p(evars),
                                      C.c_uint32(len(fr)), _p(fr), _p(out))
     return card, [int(x) if x != 0xFFFFFFFF else -1 for x in out[:nvars]]
+
+
+def eval_dense_batch(b):
+    """Problem::calculate_residuals_and_jacobian for every System: (residuals, [dense row-major J])."""
+    n, args = _batch_args(b)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    lib().fo_eval_dense_batch(*args, _p(b.get("var_comp")), None, None, _p(off))
+    r = np.zeros(int(b["expr_off"][-1]) if n else 0, dtype=np.float64)
+    jac = np.zeros(max(int(off[-1]), 1), dtype=np.float64)
+    lib().fo_eval_dense_batch(*args, _p(b.get("var_comp")), _p(r), _p(jac), _p(off))
+    out = []
+    for s in range(n):
+        m = int(b["expr_off"][s + 1] - b["expr_off"][s])
+        blk = jac[int(off[s]):int(off[s + 1])]
+        out.append(blk.reshape(m, -1) if m and len(blk) else blk.reshape(m, 0))
+    return r, out

@@ -398,3 +398,42 @@ def test_refined_step_follows_the_qr_oracle_more_closely(fiksi, oracle, ctx):
     v0, r0 = ctx.system_solve_batch(ring)
     v1, r1 = ctx.system_solve_batch(ring, abi.solving_opts(solver=1))
     assert np.array_equal(r0["accepted"], r1["accepted"]) and np.max(np.abs(v0 - v1)) < 1e-8
+
+
+def test_dense_jacobian_entry_point_bit_exact(fiksi, oracle, ctx):
+    """fx_eval_residual_dense_jacobian == Problem::calculate_residuals_and_jacobian (subsystem.rs:106-124):
+    every variant, fixed variables dropped, and the dense scatter's overwrite of a repeated column (the
+    sparse entry point sums it) — bit-identical to the oracle; consistent with the CSR entry point where
+    no column repeats."""
+    from fiksi_amd import workloads
+
+    b = workloads.concat([mixed_sketch(seed, fix_some=(seed % 2 == 1)).flatten() for seed in range(24)]
+                         + [workloads.ring16(5), workloads.quadrilateral()])
+    r, blocks = ctx.eval_residual_dense_jacobian(b)
+    r_o, blocks_o = oracle.eval_dense_batch(b)
+    ang = np.isin(b["expr_tag"], ANGLE_TAGS)
+    assert np.array_equal(r[~ang], r_o[~ang]) and np.max(np.abs(r[ang] - r_o[ang])) <= 4e-15
+    assert len(blocks) == len(blocks_o)
+    for s, (jb, jo) in enumerate(zip(blocks, blocks_o)):
+        assert jb.shape == jo.shape and np.array_equal(jb, jo), s
+    # against the sparse entry point: equal wherever a row does not read a variable twice
+    r2, (rp, ci, vals) = ctx.eval_residual_jacobian(b)
+    assert np.array_equal(r, r2)
+    n_dup = 0
+    for s in range(len(blocks)):
+        e0, e1 = int(b["expr_off"][s]), int(b["expr_off"][s + 1])
+        for row in range(e0, e1):
+            cols, v = ci[rp[row]:rp[row + 1]], vals[rp[row]:rp[row + 1]]
+            dense_row = blocks[s][row - e0]
+            same = np.array_equal(dense_row[cols], v)
+            n_dup += 0 if same else 1
+            assert np.count_nonzero(dense_row) <= len(cols)
+    assert 0 < n_dup <= 24  # the mixed sketches hold exactly one such row each
+    # size query without a device call
+    import ctypes as C
+    from fiksi_amd import abi
+    from fiksi_amd._lib import lib
+    st = abi.as_struct(abi.normalize_batch(b))
+    total = C.c_uint64(0)
+    assert lib.fx_eval_residual_dense_jacobian(None, C.byref(st), None, None, None, C.byref(total)) == 0
+    assert total.value == sum(x.size for x in blocks)
