@@ -1003,7 +1003,9 @@ int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opt
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u);
     p.prof = dev;
-    hipError_t e = fx::launch_solve(db->d, p, ctx->stream);
+    // a batch of medium Systems only: the wide kernel's stamps; otherwise the fused kernel's (N = 32 build)
+    hipError_t e = (db->d.n_wide && db->d.n_wide == db->d.n_systems) ? fx::launch_solve_wide(db->d, p, ctx->stream)
+                                                                     : fx::launch_solve(db->d, p, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(cycles, dev, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(dev);

@@ -3,13 +3,14 @@
 //
 // Same algorithm and control flow as lm_solve_kernel (fx_kernels.hip; reference
 // fiksi/src/assemble/mod.rs:46-167 and fiksi/src/solve/lm.rs:21-193), still one wavefront per System,
-// but a column no longer fits a lane's registers: the normal matrix JtJ + lambda I lives in LDS as a
-// packed lower triangle (66 KB for 128 columns) and is factored in place by a right-looking Cholesky
-// that sweeps it row by row — per row one broadcast read of L_ik and conflict-free read-modify-writes
-// of consecutive columns, each lane owning two column slots. The triangular solves walk rows the same
-// way (dot form forward, axpy form backward). JtJ is re-formed from the Jacobian rows of the current
-// point at every lambda trial (a few hundred LDS atomics) instead of being kept next to the factor:
-// two triangles would not fit.
+// but the matrix no longer fits one column per lane: JtJ + lambda I lives in LDS as a packed lower
+// triangle (66 KB for 128 columns) and is factored in place by a 2 x 2 blocked Cholesky whose diagonal
+// blocks (64 columns each) run through the same register-resident chol_factor<64> as the fused kernel;
+// the off-diagonal block is a register forward sweep per row, the Schur complement a row-in-registers
+// times broadcast-row product. (A first version swept the triangle in LDS row by row: with one
+// wavefront per CU every LDS round trip was exposed, ~1000 cycles per four rows.) JtJ is re-formed from
+// the Jacobian rows of the current point at every lambda trial (a few hundred LDS atomics) instead of
+// being kept next to the factor: two triangles would not fit.
 //
 // Without this kernel a System with 66 variables fell to the host-driven sparse path (~0.8 ms each, one
 // after the other); here Systems run concurrently, one per CU (LDS-bound occupancy).
@@ -17,6 +18,7 @@
 #include <stdint.h>
 
 #include "fx_device.h"
+#include "fx_chol.h"
 #include "fx_expr.h"
 #include "fx_wave.h"
 
@@ -61,10 +63,21 @@ size_t wide_lds_bytes(const DeviceBatch& b) { return make_wide_layout(b.w_max_fr
 
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return i * (i + 1u) / 2u + j; }  // i >= j
 
-__global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_wide_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = threadIdx.x;
     const uint32_t s = b.w_list[blockIdx.x];
+    // diagnostic phase stamps (prm.prof != nullptr only from fx_debug_phase_cycles):
+    // 0 setup, 1 eval, 2 form, 3 factor, 4 solve, 5 tail
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = prm.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto stamp = [&](int phase) {
+        if (prm.prof) {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[phase] += t - t_last;
+            t_last = t;
+        }
+    };
     double* XS = reinterpret_cast<double*>(smem + L.off_xs);      // [2][vt]
     double* VOUT = reinterpret_cast<double*>(smem + L.off_vout);  // [vt]
     double* Lm = reinterpret_cast<double*>(smem + L.off_l);       // packed lower triangle
@@ -256,57 +269,125 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
             for (uint32_t i = lane; i < nfree; i += 64) Lm[tri(i, i)] += lambda;
             __syncthreads();
         };
-        // in-place Cholesky of the packed triangle, right-looking, swept by rows; false on a bad pivot
+        // ---- blocked Cholesky of the packed triangle, in place: [A11 .; A21 A22] with a 64-column first
+        // block. Both diagonal blocks go through the register-resident chol_factor<64> of the fused kernel
+        // (one column per lane, v_readlane broadcasts); in between, L21 = A21 L11^-T row by row with the
+        // register forward sweep, and the Schur complement A22 - L21 L21^T with each lane holding its own
+        // row of L21 in registers against broadcast reads of the others. The factor is written back as
+        // the plain lower triangle L; the solves reload a block into registers when they need it.
+        const uint32_t n1 = min(nfree, 64u), n2 = nfree - n1;
+        // block `base`: lane j gets column base + j of the (symmetric) block, identity where padded
+        auto load_block = [&](double (&a)[64], uint32_t base, uint32_t nb) {
+            const uint32_t c = base + (uint32_t)lane;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t r = base + (uint32_t)i;
+                const bool real = (uint32_t)lane < nb && (uint32_t)i < nb;
+                const uint32_t hi = real ? max(r, c) : 0u, lo = real ? min(r, c) : 0u;
+                const double v = Lm[tri(hi, lo)];
+                a[i] = real ? v : ((i == lane) ? 1.0 : 0.0);
+            }
+        };
+        // the combined storage of a factored block back from the plain triangle (see chol_factor)
+        auto reload_factor = [&](double (&a)[64], double& invd, uint32_t base, uint32_t nb) {
+            const uint32_t c = base + (uint32_t)lane;
+            const bool lane_real = (uint32_t)lane < nb;
+            const double d = lane_real ? Lm[tri(c, c)] : 1.0;
+            invd = 1.0 / d;
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                const uint32_t r = base + (uint32_t)i;
+                const bool real = lane_real && (uint32_t)i < nb;
+                const uint32_t hi = real ? max(r, c) : 0u, lo = real ? min(r, c) : 0u;
+                const double v = Lm[tri(hi, lo)];
+                a[i] = real ? ((i > lane) ? v * d : v) : ((i == lane) ? 1.0 : 0.0);
+            }
+        };
         auto factor = [&]() -> bool {
-            bool bad = false;
-            for (uint32_t k = 0; k < nfree; ++k) {
-                const double piv = Lm[tri(k, k)];
-                bad = bad || !(piv > 0.0) || !(piv < 1.0e300);
-                const double d = ::sqrt(piv), inv = 1.0 / d;
+            bool ok = true;
+            double a[64], invd = 1.0;
+            for (uint32_t blk = 0; blk < 2u; ++blk) {  // one call site of chol_factor<64>
+                const uint32_t base = blk * 64u, nb = blk ? n2 : n1;
+                if (nb == 0u) break;
+                load_block(a, base, nb);
                 __syncthreads();
-                for (uint32_t i = k + 1 + lane; i < nfree; i += 64) Lm[tri(i, k)] *= inv;
-                if (lane == 0) Lm[tri(k, k)] = d;
-                __syncthreads();
-                const uint32_t j0 = k + 1 + lane, j1 = j0 + 64;
-                const double l0 = (j0 < nfree) ? Lm[tri(j0, k)] : 0.0;
-                const double l1 = (j1 < nfree) ? Lm[tri(j1, k)] : 0.0;
-                for (uint32_t i = k + 1; i < nfree; ++i) {
-                    const double lik = Lm[tri(i, k)];  // one address for the whole wavefront
-                    const uint32_t rowbase = tri(i, 0);
-                    if (j0 <= i) Lm[rowbase + j0] = fma(-lik, l0, Lm[rowbase + j0]);
-                    if (j1 <= i) Lm[rowbase + j1] = fma(-lik, l1, Lm[rowbase + j1]);
+                ok = chol_factor<64, double>(a, invd, lane) && ok;
+                // row `lane` of L and d back into the triangle
+                if ((uint32_t)lane < nb) {
+                    const uint32_t c = base + (uint32_t)lane;
+#pragma unroll
+                    for (int p = 0; p < 64; ++p)
+                        if (p <= lane) Lm[tri(c, base + (uint32_t)p)] = a[p];
                 }
                 __syncthreads();
+                if (blk == 0u && n2 > 0u) {
+                    // L21: row r of A21 against L11 (still in registers)
+                    for (uint32_t r = 64u; r < nfree; ++r) {
+                        const double v = Lm[tri(r, 0) + (uint32_t)lane];
+                        const double y = chol_forward<64, double>(a, invd, v, lane);
+                        Lm[tri(r, 0) + (uint32_t)lane] = y;
+                    }
+                    __syncthreads();
+                    // Schur complement, column 64 + lane: own row of L21 in registers
+                    const uint32_t c = 64u + (uint32_t)lane;
+                    const bool mine = (uint32_t)lane < n2;
+                    double rj[64];
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) rj[k] = mine ? Lm[tri(c, 0) + (uint32_t)k] : 0.0;
+                    for (uint32_t i = 64u; i < nfree; ++i) {
+                        const uint32_t rb = tri(i, 0);
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 64; ++k) acc = fma(Lm[rb + (uint32_t)k], rj[k], acc);  // broadcast reads
+                        if (mine && i >= c) Lm[rb + c] -= acc;
+                    }
+                    __syncthreads();
+                }
             }
-            return !uniform(bad);
+            return ok;
         };
-        // L L^T x = DEL in place: forward by row dots, backward by row axpys; returns |x|^2
+        // L L^T x = DEL in place through the blocks; returns |x|^2
         auto solve = [&]() -> double {
-            for (uint32_t i = 0; i < nfree; ++i) {
-                const uint32_t rowbase = tri(i, 0);
-                double part = 0.0;
-                for (uint32_t j = lane; j < i; j += 64) part = fma(Lm[rowbase + j], DEL[j], part);
-                part = wave_sum(part);
-                if (lane == 0) DEL[i] = (DEL[i] - part) / Lm[rowbase + i];
+            double a[64], invd = 1.0;
+            reload_factor(a, invd, 0u, n1);
+            const double y1 = chol_forward<64, double>(a, invd, ((uint32_t)lane < n1) ? DEL[lane] : 0.0, lane);
+            double u = y1;
+            if (n2 > 0u) {
                 __syncthreads();
+                if ((uint32_t)lane < n1) DEL[lane] = y1;
+                __syncthreads();
+                // b2 - L21 y1, row 64 + lane
+                double t = 0.0;
+                if ((uint32_t)lane < n2) {
+                    const uint32_t rb = tri(64u + (uint32_t)lane, 0);
+                    t = DEL[64 + lane];
+                    for (uint32_t k = 0; k < 64u; ++k) t = fma(-Lm[rb + k], DEL[k], t);
+                }
+                reload_factor(a, invd, 64u, n2);
+                const double x2 = chol_solve<64, double>(a, invd, t, lane);
+                __syncthreads();
+                if ((uint32_t)lane < n2) DEL[64 + lane] = x2;
+                __syncthreads();
+                // y1 - L21^T x2, column lane
+                for (uint32_t r = 0; r < n2; ++r) u = fma(-Lm[tri(64u + r, 0) + (uint32_t)lane], DEL[64u + r], u);
+                reload_factor(a, invd, 0u, n1);
             }
-            for (uint32_t ii = nfree; ii-- > 0;) {
-                const uint32_t rowbase = tri(ii, 0);
-                const double xi = DEL[ii] / Lm[rowbase + ii];
-                __syncthreads();
-                for (uint32_t j = lane; j < ii; j += 64) DEL[j] = fma(-Lm[rowbase + j], xi, DEL[j]);
-                if (lane == 0) DEL[ii] = xi;
-                __syncthreads();
-            }
+            const double x1 = chol_backward<64, double>(a, invd, u, lane);
+            __syncthreads();
+            if ((uint32_t)lane < n1) DEL[lane] = x1;
+            __syncthreads();
             double part = 0.0;
             for (uint32_t i = lane; i < nfree; i += 64) part += DEL[i] * DEL[i];
             return wave_sum(part);
         };
 
         int cur = 0;
+        stamp(0);
         double sse = eval_rows(0);
         const double sse_start = sse;
+        stamp(1);
         form_rhs(0);
+        stamp(2);
         double lambda = o.lambda0;
         uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
         bool done = false;
@@ -326,8 +407,12 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
                     break;
                 }
                 trials += 1;
+                stamp(5);
                 form_matrix(cur, lambda);
-                if (!factor()) {  // lm.rs:134-137
+                stamp(2);
+                const bool factored = factor();
+                stamp(3);
+                if (!factored) {  // lm.rs:134-137
                     lambda *= o.singular_factor;
                     if (!(lambda < 1.0e300)) {
                         exit_code = FX_EXIT_NAN;
@@ -339,6 +424,7 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
                 for (uint32_t i = lane; i < nfree; i += 64) DEL[i] = RHS[i];
                 __syncthreads();
                 double dn2 = solve();
+                stamp(4);
                 if (o.solver == FX_STEP_CHOLESKY_REFINED) {
                     // corrected semi-normal equations, as in lm_solve_kernel: t = -r - J delta from the rows,
                     // (JtJ + lambda I) e = Jt t - lambda delta with the factor at hand, delta += e
@@ -391,7 +477,9 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
                     XS[trial * vt + vi] = XS[cur * vt + vi] + DEL[i];
                 }
                 __syncthreads();
+                stamp(5);
                 const double sse_t = eval_rows(trial);
+                stamp(1);
                 if (sse_t < sse) {  // accept, lm.rs:151-186
                     lambda *= o.accept_factor;
                     if (lambda < o.lambda_min) lambda = o.lambda_min;
@@ -483,6 +571,11 @@ __global__ __launch_bounds__(64) void lm_solve_wide_kernel(DeviceBatch b, LmPara
         res.sse = tot_sse;
         res.sse_unscaled = sse_u;
         b.results[s] = res;
+    }
+    if (prm.prof) {
+        stamp(5);
+        if (lane == 0)
+            for (int i = 0; i < 6; ++i) atomicAdd(&prm.prof[i], ph[i]);
     }
 }
 
