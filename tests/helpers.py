@@ -105,3 +105,48 @@ def random_sketch(seed: int) -> System:
         elif k == 10 and C:
             constraints.LineCircleTangency.create(s, pick(L), pick(C))
     return s
+
+
+def random_big_sketch(seed: int, n_points: int) -> System:
+    """Like random_sketch, scaled up: n_points points (wide / sparse-path sizes), a locally connected
+    constraint graph (neighbours in index order, so components stay sparse), a few lines and circles,
+    a few fixed points, occasionally a second component."""
+    g = Lcg(seed)
+    s = System()
+    P = [elements.Point.create(s, 3.0 * i + g.u(-1, 1), g.u(-6, 6)) for i in range(n_points)]
+    near = lambda i, w=4: P[max(0, min(n_points - 1, i + int(g.u(-w, w + 0.99))))]
+    L = []
+    for _ in range(max(2, n_points // 8)):
+        i = int(g.u(0, n_points - 2))
+        L.append(elements.Line.create(s, P[i], P[i + 1]))
+    C = [elements.Circle.create(s, P[int(g.u(0, n_points - 0.01))], elements.Length.create(s, g.u(1, 4)))
+         for _ in range(max(1, n_points // 20))]
+    for p in P:
+        if g.u(0, 1) < 0.05:
+            p.fix(s)
+    split = int(g.u(0.3, 0.7) * n_points) if g.u(0, 1) < 0.4 else -1  # no constraint crosses the split
+    for i in range(n_points - 1):
+        if i + 1 == split:
+            continue
+        constraints.PointPointDistance.create(s, P[i], P[i + 1], g.u(2, 4))
+    for _ in range(int(0.8 * n_points)):
+        i = int(g.u(1, n_points - 2))
+        lo, hi = (0, split) if 0 < split and i < split else (max(split, 0), n_points)
+        pick = lambda: P[max(lo, min(hi - 1, i + int(g.u(-3, 3.99))))]
+        k = int(g.u(0, 6.99))
+        a, b, c = pick(), pick(), pick()
+        if k == 0 and a is not b:
+            constraints.PointPointDistance.create(s, a, b, g.u(2, 8))
+        elif k == 1 and len({id(a), id(b), id(c)}) == 3:
+            constraints.PointPointPointAngle.create(s, a, b, c, g.u(-2, 2))
+        elif k == 2:
+            constraints.PointLineDistance.create(s, a, L[int(g.u(0, len(L) - 0.01))], g.u(-3, 3))
+        elif k == 3:
+            constraints.PointCircleIncidence.create(s, a, C[int(g.u(0, len(C) - 0.01))])
+        elif k == 4 and len(L) > 1:
+            l1, l2 = L[int(g.u(0, len(L) - 0.01))], L[int(g.u(0, len(L) - 0.01))]
+            if l1 is not l2:
+                constraints.LineLineAngle.create(s, l1, l2, g.u(-1, 1))
+        elif k == 5 and a is not b:
+            constraints.PointPointCoincidence.create(s, a, b)
+    return s
