@@ -176,37 +176,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     // order (assemble/mod.rs:32-44, utils.rs:11-33) so the scale is bit-identical. ------------
     double scale = 1.0, scale_recip = 1.0;
     if (prm.mode & 1u) {
-        double sum = 0.0;
-        uint32_t count = nvt;
-        for (uint32_t base = 0; base < nvt; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            if (i < nvt) {
-                double v = ld_var(i);
-                t = v * v;
-            }
-            uint32_t cnt = min(64u, nvt - base);
-            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
-        }
-        for (uint32_t base = 0; base < net; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            bool isd = false;
-            if (i < net) {
-                int tag = ld_tag(i);
-                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
-                if (isd) {
-                    double d = ld_param(i);
-                    t = d * d;
-                }
-            }
-            uint64_t m = __ballot(isd);
-            count += (uint32_t)__popcll(m);
-            uint32_t cnt = min(64u, net - base);
-            // adding the +0.0 of non-distance rows is exact, so the order of real terms is kept
-            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
-        }
-        scale = ::sqrt(sum / (double)count);
+        scale = system_scale_wave(nvt, net, lane, ld_var, ld_tag, ld_param);
         scale_recip = 1.0 / scale;
     }
 

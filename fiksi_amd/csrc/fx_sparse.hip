@@ -32,6 +32,7 @@
 #include "fx_expr.h"
 #include "fx_lbfgs.h"
 #include "fx_sparse.h"
+#include "fx_wave.h"
 
 namespace fx {
 
@@ -54,45 +55,10 @@ __global__ __launch_bounds__(64) void sp_scale_kernel(const double* __restrict__
                                                       double* __restrict__ scal, int do_scale) {
     const int lane = threadIdx.x;
     double scale = 1.0;
-    if (do_scale) {
-        double sum = 0.0;
-        uint32_t count = nvt;
-        for (uint32_t base = 0; base < nvt; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            if (i < nvt) {
-                double v = vars0[i];
-                t = v * v;
-            }
-            uint32_t cnt = min(64u, nvt - base);
-            for (uint32_t k = 0; k < cnt; ++k) {
-                int lo = __builtin_amdgcn_readlane(__double2loint(t), (int)k);
-                int hi = __builtin_amdgcn_readlane(__double2hiint(t), (int)k);
-                sum += __hiloint2double(hi, lo);
-            }
-        }
-        for (uint32_t base = 0; base < rows.net; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            bool isd = false;
-            if (i < rows.net) {
-                int tag = rows.tag[i] & 0x7F;
-                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
-                if (isd) {
-                    double d = rows.param[i];
-                    t = d * d;
-                }
-            }
-            count += (uint32_t)__popcll(__ballot(isd));
-            uint32_t cnt = min(64u, rows.net - base);
-            for (uint32_t k = 0; k < cnt; ++k) {
-                int lo = __builtin_amdgcn_readlane(__double2loint(t), (int)k);
-                int hi = __builtin_amdgcn_readlane(__double2hiint(t), (int)k);
-                sum += __hiloint2double(hi, lo);
-            }
-        }
-        scale = ::sqrt(sum / (double)count);
-    }
+    if (do_scale)
+        scale = system_scale_wave(
+            nvt, rows.net, lane, [&](uint32_t i) { return vars0[i]; }, [&](uint32_t i) { return (int)(rows.tag[i] & 0x7F); },
+            [&](uint32_t i) { return rows.param[i]; });
     if (lane == 0) {
         scal[0] = scale;
         scal[1] = 1.0 / scale;

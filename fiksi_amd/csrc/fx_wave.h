@@ -79,4 +79,45 @@ __device__ __forceinline__ uint32_t lcg_jump(uint32_t st, uint32_t k) {
 }
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (lane == 0) ? 0ull : (~0ull >> (64 - lane)); }
 
+
+// calculate_system_scale (fiksi/src/assemble/mod.rs:32-44, utils.rs:11-33): sqrt of the mean square over all
+// variables and the distance parameters of PointPointDistance / PointLineDistance, summed strictly in the
+// reference's order (variables, then expressions, each ascending) so the result is bit-identical: a
+// wavefront squares 64 values at a time and adds them one by one through v_readlane. The accessors return
+// variable i / the tag and parameter of expression i of the System. Wave-uniform result.
+template <typename VarFn, typename TagFn, typename ParamFn>
+__device__ __forceinline__ double system_scale_wave(uint32_t nvt, uint32_t net, int lane, VarFn var_at, TagFn tag_at,
+                                                    ParamFn param_at) {
+    double sum = 0.0;
+    uint32_t count = nvt;
+    for (uint32_t base = 0; base < nvt; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        double t = 0.0;
+        if (i < nvt) {
+            const double v = var_at(i);
+            t = v * v;
+        }
+        const uint32_t cnt = min(64u, nvt - base);
+        for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+    }
+    for (uint32_t base = 0; base < net; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        double t = 0.0;
+        bool isd = false;
+        if (i < net) {
+            const int tag = tag_at(i);
+            isd = (tag == 1) || (tag == 4);  // FX_TAG_PPD, FX_TAG_PLD
+            if (isd) {
+                const double d = param_at(i);
+                t = d * d;
+            }
+        }
+        count += (uint32_t)__popcll(__ballot(isd));
+        const uint32_t cnt = min(64u, net - base);
+        // adding the +0.0 of non-distance rows is exact, so the order of the real terms is kept
+        for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
+    }
+    return ::sqrt(sum / (double)count);
+}
+
 }  // namespace fx

@@ -102,35 +102,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ---- K0a: system scale, summed strictly in reference order (assemble/mod.rs:32-44) ------------
     double scale = 1.0, scale_recip = 1.0;
     if (prm.mode & 1u) {
-        double sum = 0.0;
-        uint32_t count = nvt;
-        for (uint32_t base = 0; base < nvt; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            if (i < nvt) {
-                double v = b.vars0[v0 + i];
-                t = v * v;
-            }
-            uint32_t cnt = min(64u, nvt - base);
-            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
-        }
-        for (uint32_t base = 0; base < net; base += 64) {
-            uint32_t i = base + lane;
-            double t = 0.0;
-            bool isd = false;
-            if (i < net) {
-                int tag = b.expr_tag[e0 + i] & 0x7F;
-                isd = (tag == FX_TAG_PPD) || (tag == FX_TAG_PLD);
-                if (isd) {
-                    double d = b.expr_param[e0 + i];
-                    t = d * d;
-                }
-            }
-            count += (uint32_t)__popcll(__ballot(isd));
-            uint32_t cnt = min(64u, net - base);
-            for (uint32_t k = 0; k < cnt; ++k) sum += bcast(t, (int)k);
-        }
-        scale = ::sqrt(sum / (double)count);
+        scale = system_scale_wave(
+            nvt, net, lane, [&](uint32_t i) { return b.vars0[v0 + i]; }, [&](uint32_t i) { return (int)(b.expr_tag[e0 + i] & 0x7F); },
+            [&](uint32_t i) { return b.expr_param[e0 + i]; });
         scale_recip = 1.0 / scale;
     }
     for (uint32_t i = lane; i < nvt; i += 64) {
