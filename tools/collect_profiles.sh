@@ -13,6 +13,8 @@ cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kern
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_write.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json 100000 > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_sq.log 2>&1
+python3 tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/${TAG}_pmc_sq.json 100000 > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg2 -- python3 tools/cfg2.py 5000 > $OUT/cfg2.log 2>&1
 cp $(find $OUT/cfg2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg2_kernel_stats.csv
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
