@@ -284,6 +284,12 @@ class DeviceBatch:
     def eval_residual(self, which: int = 0):
         check(lib.fx_eval_residual_device(self.ctx.handle, self._h, which), "fx_eval_residual_device")
 
+    def set_params(self, expr_param):
+        """New constraint targets (distances / angles) for the resident batch; structure unchanged."""
+        v = np.ascontiguousarray(expr_param, dtype=np.float64)
+        assert v.size == self.n_exprs
+        check(lib.fx_batch_set_params(self.ctx.handle, self._h, _ptr(v)), "fx_batch_set_params")
+
     def set_vars(self, vars_):
         v = np.ascontiguousarray(vars_, dtype=np.float64)
         assert v.size == self.n_vars

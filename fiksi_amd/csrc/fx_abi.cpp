@@ -934,6 +934,16 @@ int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars) {
     return FX_OK;
 }
 
+int fx_batch_set_params(fx_ctx* ctx, fx_dbatch* db, const double* expr_param) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !expr_param) return fail(FX_ERR_INVALID, "bad argument");
+    if (db->n_large) std::copy(expr_param, expr_param + db->d.n_exprs, db->h_expr_param.begin());
+    FX_HIP(hipMemcpyAsync(db->d.expr_param, expr_param, (size_t)db->d.n_exprs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
 int fx_batch_get_vars(fx_ctx* ctx, fx_dbatch* db, double* vars) {
     int rc = bind(ctx);
     if (rc) return rc;

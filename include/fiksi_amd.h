@@ -209,6 +209,10 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out);
 void fx_batch_free(fx_ctx* ctx, fx_dbatch* db);
 /* Replace the start values of an uploaded batch (n_vars doubles). */
 int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars);
+/* Replace the expression parameters (distances / angles; n_exprs doubles) of an uploaded batch — the
+ * resident counterpart of ConstraintHandle::update_parameter (constraints/mod.rs:992-1046): the
+ * structure stays, only the targets change (dragging a dimension). */
+int fx_batch_set_params(fx_ctx* ctx, fx_dbatch* db, const double* expr_param);
 /* Copy the current (last solved) values / results back. */
 int fx_batch_get_vars(fx_ctx* ctx, fx_dbatch* db, double* vars);
 int fx_batch_get_results(fx_ctx* ctx, fx_dbatch* db, fx_result* results);

@@ -172,3 +172,26 @@ def test_fully_fixed_and_unconstrained_parts(fiksi, oracle, ctx):
     for opts in (F.abi.solving_opts(decomposer=1), F.abi.solving_opts(optimizer=1)):
         v2, res2 = ctx.system_solve_batch(flat, opts)
         assert np.array_equal(v2[fx], flat["vars"][fx]) and np.all(np.isfinite(v2))
+
+
+def test_resident_batch_with_new_parameters_and_start_values(fiksi, oracle, ctx):
+    """fx_batch_set_params / fx_batch_set_vars on a resident batch == uploading the changed batch anew
+    (the dragging-a-dimension workflow: same structure, new targets, warm start from the last solution)."""
+    from fiksi_amd import workloads
+
+    b = workloads.concat([workloads.ring16(200), workloads.hinged_triangles(3, 20), workloads.large_sketch(80)])
+    db = ctx.upload(b)
+    db.system_solve()
+    v1 = db.get_vars()
+    b2 = dict(b)
+    b2["expr_param"] = b["expr_param"] * np.where(np.isin(b["expr_tag"], (1, 4)), 1.03, 1.0)  # distances +3 %
+    b2["vars"] = v1.copy()
+    db.set_params(b2["expr_param"])
+    db.set_vars(v1)
+    db.system_solve()
+    v2, r2 = db.get_vars(), db.get_results()
+    v_ref, r_ref = ctx.system_solve_batch(b2)
+    assert np.array_equal(v2, v_ref) and np.array_equal(r2, r_ref)
+    v_o, r_o = oracle.solve_batch(b2, mode=3, nthreads=4)
+    assert np.mean(r2["accepted"] == r_o["accepted"]) > 0.95
+    db.free()
