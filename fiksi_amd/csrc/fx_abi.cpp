@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -678,17 +679,54 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
     }
     const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
+    std::vector<uint32_t> todo;
     for (uint32_t s = 0; s < db->d.n_systems; ++s) {
         if (!db->h_sys_large[s]) continue;
         if (db->h_sys_large[s] == 2 && wide_kernel_applies(p)) continue;  // done by the wide kernel
         if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
-        fx_result res{};
-        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, ctx->stream, db->d.vars + db->h_var_off[s], &res);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(db->d.results + s, &res, sizeof(fx_result), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", s, hipGetErrorString(e));
+        todo.push_back(s);
     }
+    auto solve_one = [&](uint32_t s, hipStream_t stream) -> hipError_t {
+        fx_result res{};
+        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, stream, db->d.vars + db->h_var_off[s], &res);
+        if (e == hipSuccess) e = hipMemcpyAsync(db->d.results + s, &res, sizeof(fx_result), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        return e;
+    };
+    if (todo.size() <= 1) {
+        for (uint32_t s : todo) {
+            hipError_t e = solve_one(s, ctx->stream);
+            if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", s, hipGetErrorString(e));
+        }
+        return FX_OK;
+    }
+    // Several large Systems: each one is a host-driven loop of small launches that leaves the GPU mostly
+    // idle, so a few host threads, each with its own stream, run them side by side (Systems are
+    // independent; every result depends only on its own System, so the schedule does not show).
+    const uint32_t nt = (uint32_t)std::min<size_t>(todo.size(), 8);
+    std::atomic<uint32_t> next{0};
+    std::vector<hipError_t> err(nt, hipSuccess);
+    std::vector<uint32_t> err_sys(nt, 0);
+    std::vector<std::thread> workers;
+    for (uint32_t t = 0; t < nt; ++t) {
+        workers.emplace_back([&, t] {
+            hipError_t e = hipSetDevice(ctx->device);
+            hipStream_t stream = nullptr;
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+            while (e == hipSuccess) {
+                const uint32_t k = next.fetch_add(1);
+                if (k >= todo.size()) break;
+                e = solve_one(todo[k], stream);
+                if (e != hipSuccess) err_sys[t] = todo[k];
+            }
+            if (stream) (void)hipStreamDestroy(stream);
+            err[t] = e;
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (uint32_t t = 0; t < nt; ++t)
+        if (err[t] != hipSuccess)
+            return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", err_sys[t], hipGetErrorString(err[t]));
     return FX_OK;
 }
 }  // namespace
