@@ -472,10 +472,47 @@ struct DevArr {
     size_t n = 0;
 };
 
-struct Pool {  // device allocations of one solve
-    std::vector<void*> ptrs;
-    hipStream_t stream;
+// Device memory of one System's solve: a few large hipMalloc chunks handed out by bumping a pointer.
+// hipMalloc / hipFree synchronise the whole device, and a SinglePass solve creates dozens of small arrays
+// for each of thousands of blocks — and several Systems may be solved at once from different host
+// threads — so the per-array calls are what must go.
+struct Arena {
+    struct Chunk { char* base; size_t size; };
+    struct Mark { size_t cur, used; };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, used = 0;
+    void* take(size_t bytes, hipError_t& err) {
+        bytes = (std::max<size_t>(bytes, 1) + 255u) & ~size_t(255);
+        for (; cur < chunks.size(); ++cur, used = 0)
+            if (used + bytes <= chunks[cur].size) {
+                void* p = chunks[cur].base + used;
+                used += bytes;
+                return p;
+            }
+        void* d = nullptr;
+        const size_t size = std::max<size_t>(bytes, size_t(4) << 20);
+        err = hipMalloc(&d, size);
+        if (err != hipSuccess) return nullptr;
+        chunks.push_back({static_cast<char*>(d), size});
+        cur = chunks.size() - 1;
+        used = bytes;
+        return d;
+    }
+    Mark mark() const { return {cur, used}; }
+    void reset(Mark m) { cur = m.cur; used = m.used; }
+    ~Arena() {
+        for (auto& c : chunks) (void)hipFree(c.base);
+    }
+};
+
+struct Pool {  // the arrays of one scope (System or block); released together when it ends (stream synced by then)
+    Arena* arena;
+    Arena::Mark start;
+    hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
+    explicit Pool(Arena* a) : arena(a), start(a->mark()) {}
+    Pool(const Pool&) = delete;
+    Pool& operator=(const Pool&) = delete;
     template <typename T>
     T* up(const std::vector<T>& h) {
         T* d = alloc<T>(h.size());
@@ -485,16 +522,10 @@ struct Pool {  // device allocations of one solve
     }
     template <typename T>
     T* alloc(size_t n) {
-        void* d = nullptr;
         if (err != hipSuccess) return nullptr;
-        err = hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T));
-        if (err != hipSuccess) return nullptr;
-        ptrs.push_back(d);
-        return static_cast<T*>(d);
+        return static_cast<T*>(arena->take(n * sizeof(T), err));
     }
-    ~Pool() {
-        for (void* p : ptrs) (void)hipFree(p);
-    }
+    ~Pool() { arena->reset(start); }
 };
 
 // reverse Cuthill-McKee order of the column graph of A (adjacency given as sorted lists)
@@ -982,7 +1013,8 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
     const fx_lm_opts o = prm.lm;
     const int do_scale = (prm.mode & 1u) ? 1 : 0;
-    Pool pool;
+    Arena arena;
+    Pool pool(&arena);
     pool.stream = stream;
 
     // ---- System-wide device data
@@ -1046,7 +1078,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         if (prm.mode & 2u) {
             const uint32_t nfv = (uint32_t)fvar.size();
             if (nfv) {
-                Pool tmp;
+                Pool tmp(&arena);
                 tmp.stream = stream;
                 uint32_t* d_all = tmp.up(fvar);
                 if (tmp.err != hipSuccess) return tmp.err;
@@ -1077,7 +1109,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         res.exit = FX_EXIT_SSE;
 
         for (uint32_t u = 0; u < units.count(); ++u) {
-        Pool pool;  // device memory of this block only
+        Pool pool(&arena);  // device memory of this block only
         pool.stream = stream;
         ComponentPlan P;
         const auto t_plan0 = std::chrono::steady_clock::now();
