@@ -409,11 +409,53 @@ struct fx_ctx {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     char name[128] = {0};
     char arch[64] = {0};
+    // Device blocks released by freed batches, kept for the next upload: hipMalloc / hipFree synchronise
+    // the device and cost more than a small solve (one System::solve = one upload + one free).
+    struct Block { void* p; size_t size; };
+    std::vector<Block> free_blocks;
+    size_t free_bytes = 0;
+    static constexpr size_t MAX_CACHED_BYTES = size_t(4) << 30;  // beyond this, released blocks go back to the driver
+
+    void* take(size_t bytes, hipError_t& err) {
+        err = hipSuccess;
+        size_t best = free_blocks.size();
+        for (size_t i = 0; i < free_blocks.size(); ++i)
+            if (free_blocks[i].size >= bytes && free_blocks[i].size <= 2 * bytes + 4096 &&
+                (best == free_blocks.size() || free_blocks[i].size < free_blocks[best].size))
+                best = i;
+        if (best != free_blocks.size()) {
+            void* p = free_blocks[best].p;
+            free_bytes -= free_blocks[best].size;
+            free_blocks[best] = free_blocks.back();
+            free_blocks.pop_back();
+            return p;
+        }
+        void* p = nullptr;
+        err = hipMalloc(&p, bytes);
+        if (err == hipErrorOutOfMemory && !free_blocks.empty()) {  // give the cache back and retry once
+            drop_cache();
+            err = hipMalloc(&p, bytes);
+        }
+        return err == hipSuccess ? p : nullptr;
+    }
+    void give_back(void* p, size_t bytes) {
+        if (free_bytes + bytes > MAX_CACHED_BYTES || free_blocks.size() >= 256) {
+            (void)hipFree(p);
+            return;
+        }
+        free_blocks.push_back({p, bytes});
+        free_bytes += bytes;
+    }
+    void drop_cache() {
+        for (auto& b : free_blocks) (void)hipFree(b.p);
+        free_blocks.clear();
+        free_bytes = 0;
+    }
 };
 
 struct fx_dbatch {
     fx::DeviceBatch d{};
-    std::vector<void*> allocations;
+    std::vector<fx_ctx::Block> allocations;
     // host copy of the batch, kept only when some System needs the sparse path
     std::vector<uint32_t> h_var_off, h_expr_off, h_expr_idx;
     std::vector<double> h_vars, h_expr_param;
@@ -429,11 +471,11 @@ namespace {
 template <typename T>
 int dev_alloc_copy(fx_ctx* ctx, fx_dbatch* db, T** out, const T* host, size_t count) {
     *out = nullptr;
-    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-    db->allocations.push_back(p);
+    size_t bytes = ((std::max<size_t>(count, 1) * sizeof(T)) + 255u) & ~size_t(255);
+    hipError_t e = hipSuccess;
+    void* p = ctx->take(bytes, e);
+    if (!p) return fail(e == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    db->allocations.push_back({p, bytes});
     if (host && count) {
         FX_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     } else {
@@ -789,6 +831,7 @@ void fx_ctx_destroy(fx_ctx* ctx) {
     }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    ctx->drop_cache();
     delete ctx;
 }
 
@@ -957,7 +1000,10 @@ void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    for (void* p : db->allocations) (void)hipFree(p);
+    for (auto& blk : db->allocations) {
+        if (ctx) ctx->give_back(blk.p, blk.size);  // the stream is idle: the blocks can be handed out again
+        else (void)hipFree(blk.p);
+    }
     delete db;
 }
 
