@@ -924,12 +924,14 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     const uint32_t zero_off[1] = {0};
     const uint32_t* voff = p.n_systems ? batch->var_off : zero_off;
     const uint32_t* eoff = p.n_systems ? batch->expr_off : zero_off;
-#define FX_UP(field, host, count)                                       \
-    rc = dev_alloc_copy(ctx, db, &d.field, host, (size_t)(count));      \
-    if (rc) {                                                           \
-        fx_batch_free(ctx, db);                                         \
-        return rc;                                                      \
-    }
+    // Every array of the batch: (device pointer to set, host source or NULL for zeros, bytes). A small
+    // batch (one System::solve) goes up as ONE block with ONE copy from a packed staging buffer — a
+    // dozen-and-a-half separate hipMemcpy calls cost more than its solve; a big batch keeps one block and
+    // one copy per array (no extra pass over 100 MB on the host).
+    struct Req { void** dst; const void* src; size_t bytes; };
+    std::vector<Req> reqs;
+#define FX_UP(field, host, count) \
+    reqs.push_back({reinterpret_cast<void**>(&d.field), static_cast<const void*>(host), (size_t)(count) * sizeof(*d.field)});
     FX_UP(var_off, voff, (size_t)p.n_systems + 1)
     FX_UP(expr_off, eoff, (size_t)p.n_systems + 1)
     FX_UP(sys_ncomp, p.sys_ncomp.data(), p.n_systems)
@@ -947,6 +949,41 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
     FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
+#undef FX_UP
+    size_t packed = 0;
+    for (const Req& r : reqs) packed += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
+    std::vector<unsigned char> stage;
+    if (packed <= (size_t(256) << 10)) {
+        hipError_t e1 = hipSuccess;
+        unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
+        if (!base) {
+            fx_batch_free(ctx, db);
+            return fail(e1 == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", packed, hipGetErrorString(e1));
+        }
+        db->allocations.push_back({base, packed});
+        stage.assign(packed, 0);
+        size_t at = 0;
+        for (const Req& r : reqs) {
+            if (r.src && r.bytes) memcpy(stage.data() + at, r.src, r.bytes);
+            *r.dst = base + at;
+            at += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
+        }
+        e1 = hipMemcpyAsync(base, stage.data(), packed, hipMemcpyHostToDevice, ctx->stream);
+        if (e1 != hipSuccess) {
+            fx_batch_free(ctx, db);
+            return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e1));
+        }
+    } else {
+        for (const Req& r : reqs) {
+            unsigned char* dptr = nullptr;
+            rc = dev_alloc_copy(ctx, db, &dptr, static_cast<const unsigned char*>(r.src), r.bytes);
+            if (rc) {
+                fx_batch_free(ctx, db);
+                return rc;
+            }
+            *r.dst = dptr;
+        }
+    }
     d.n_wide = (uint32_t)p.wide_list.size();
     d.w_max_free = p.w_max_free;
     d.w_max_vars = p.w_max_vars;
