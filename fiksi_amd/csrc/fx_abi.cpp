@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <thread>
@@ -461,6 +462,9 @@ struct fx_dbatch {
     std::vector<double> h_vars, h_expr_param;
     std::vector<uint8_t> h_var_fixed, h_expr_tag, h_sys_large;
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
+    // sparse-path plans of large Systems, key = 2 * system + (SinglePass ? 1 : 0)
+    std::map<uint64_t, fx::SparsePlanCache*> sparse_plans;
+    bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
     uint32_t n_large = 0;
@@ -728,17 +732,26 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
         todo.push_back(s);
     }
-    auto solve_one = [&](uint32_t s, hipStream_t stream) -> hipError_t {
+    // plan caches are created here, on the calling thread (the map is not touched by the workers)
+    std::vector<fx::SparsePlanCache*> plans(todo.size(), nullptr);
+    if (db->resident)
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const uint64_t key = 2ull * todo[k] + ((p.mode & fx::MODE_UNITS) ? 1u : 0u);
+            auto it = db->sparse_plans.find(key);
+            if (it == db->sparse_plans.end()) it = db->sparse_plans.emplace(key, fx::sparse_cache_new()).first;
+            plans[k] = it->second;
+        }
+    auto solve_one = [&](uint32_t s, hipStream_t stream, fx::SparsePlanCache* plan) -> hipError_t {
         fx_result res{};
-        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, stream, db->d.vars + db->h_var_off[s], &res);
+        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, stream, db->d.vars + db->h_var_off[s], &res, plan);
         if (e == hipSuccess) e = hipMemcpyAsync(db->d.results + s, &res, sizeof(fx_result), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         return e;
     };
     if (todo.size() <= 1) {
-        for (uint32_t s : todo) {
-            hipError_t e = solve_one(s, ctx->stream);
-            if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", s, hipGetErrorString(e));
+        for (size_t k = 0; k < todo.size(); ++k) {
+            hipError_t e = solve_one(todo[k], ctx->stream, plans[k]);
+            if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", todo[k], hipGetErrorString(e));
         }
         return FX_OK;
     }
@@ -758,7 +771,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
             while (e == hipSuccess) {
                 const uint32_t k = next.fetch_add(1);
                 if (k >= todo.size()) break;
-                e = solve_one(todo[k], stream);
+                e = solve_one(todo[k], stream, plans[k]);
                 if (e != hipSuccess) err_sys[t] = todo[k];
             }
             if (stream) (void)hipStreamDestroy(stream);
@@ -906,6 +919,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     if (rc) return rc;
     fx_dbatch* db = new (std::nothrow) fx_dbatch();
     if (!db) return fail(FX_ERR_NOMEM, "out of host memory");
+    db->resident = true;
     fx::DeviceBatch& d = db->d;
     d.n_systems = p.n_systems;
     d.n_vars = p.n_vars;
@@ -1037,6 +1051,7 @@ void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
+    for (auto& kv : db->sparse_plans) fx::sparse_cache_free(kv.second);
     for (auto& blk : db->allocations) {
         if (ctx) ctx->give_back(blk.p, blk.size);  // the stream is idle: the blocks can be handed out again
         else (void)hipFree(blk.p);
@@ -1208,6 +1223,7 @@ static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts*
     fx_dbatch* db = nullptr;
     int rc = fx_batch_upload(ctx, batch, &db);
     if (rc) return rc;
+    db->resident = false;  // solved once and freed: no point in keeping plans
     rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
     if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
     if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);

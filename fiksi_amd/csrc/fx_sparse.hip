@@ -693,6 +693,36 @@ struct ComponentPlan {
     std::vector<uint32_t> level_ptr;                   // lists of level v: [level_ptr[v], level_ptr[v+1])
 };
 
+// Structure of one block on the device (index arrays only; what plan_component produced, uploaded).
+struct BlockOnDevice {
+    ComponentPlan P;
+    uint32_t* d_fvar = nullptr;
+    uint32_t* d_perm = nullptr;
+    SpJac jac{};
+    uint32_t *d_apair_ptr = nullptr, *d_apairs = nullptr, *d_cptr = nullptr, *d_cidx = nullptr, *d_crow = nullptr;
+    SpChol chol{};
+    SpRowsOfL lrows{};
+    ColLists lists{};
+    double plan_ms = 0.0;
+};
+
+}  // namespace
+
+// Plans of a resident System (one per decomposer mode), kept between solves: the structure never changes
+// on a resident batch — only start values and parameters do — so ordering, symbolic factorisation,
+// gather lists and their upload (12 ms for cfg2) are paid once.
+struct SparsePlanCache {
+    Arena arena;                                     // holds the blocks' index arrays
+    std::unique_ptr<Pool> pool;
+    std::vector<UnitList> units;                     // per visited component
+    std::vector<std::unique_ptr<BlockOnDevice>> blocks;  // in visiting order
+    bool ready = false;
+};
+SparsePlanCache* sparse_cache_new() { return new SparsePlanCache(); }
+void sparse_cache_free(SparsePlanCache* c) { delete c; }
+
+namespace {
+
 // Builds every index structure of one component. `colof[v]` = free column of system variable v
 // (ascending rank among the component's free variables) or -1.
 void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& rows,
@@ -1005,7 +1035,18 @@ inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block 
 // host: LM driver for one System (all of its components), numerics on the device
 // ------------------------------------------------------------------------------------------------
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
-                               double* d_vars_out /* device, n_vars of the System */, fx_result* result) {
+                               double* d_vars_out /* device, n_vars of the System */, fx_result* result,
+                               SparsePlanCache* cache) {
+    const bool reuse = cache && cache->ready;  // structure from an earlier solve of this resident System
+    if (cache && !cache->ready) {  // first solve (or an earlier attempt failed half-way): start clean
+        cache->units.clear();
+        cache->blocks.clear();
+    }
+    if (cache && !cache->pool) {
+        cache->pool.reset(new Pool(&cache->arena));
+        cache->pool->stream = stream;
+    }
+    size_t comp_at = 0, block_at = 0;
     const bool single_pass = (prm.mode & MODE_UNITS) != 0;
     const bool lbfgs = (prm.mode & MODE_LBFGS) != 0;
     const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;  // diagnostics on stderr
@@ -1092,61 +1133,90 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         if (e != hipSuccess) return e;
 
         // ---- the blocks to solve: the whole component, or its SinglePass decomposition
-        UnitList units;
-        if (single_pass) {
+        UnitList units_local;
+        if (reuse) {
+            // decided on the first solve
+        } else if (single_pass) {
             if (!decomposer) {
                 inc.build(nvt, net, b->expr_tag + e0, b->expr_idx + 4 * (size_t)e0);
                 decomposer.reset(new SinglePassDecomposer(inc));
             }
-            decomposer->run(fvar, units);
+            decomposer->run(fvar, units_local);
         } else {
-            units.rows = crow_ids;
-            units.vars = fvar;
-            units.row_off.push_back((uint32_t)crow_ids.size());
-            units.var_off.push_back((uint32_t)fvar.size());
+            units_local.rows = crow_ids;
+            units_local.vars = fvar;
+            units_local.row_off.push_back((uint32_t)crow_ids.size());
+            units_local.var_off.push_back((uint32_t)fvar.size());
         }
+        if (cache && !reuse) cache->units.push_back(units_local);
+        const UnitList& units = cache ? cache->units[comp_at] : units_local;
+        comp_at += 1;
         res.ncomp += 1;
         res.exit = FX_EXIT_SSE;
 
         for (uint32_t u = 0; u < units.count(); ++u) {
         Pool pool(&arena);  // device memory of this block only
         pool.stream = stream;
-        ComponentPlan P;
-        const auto t_plan0 = std::chrono::steady_clock::now();
-        plan_component(b, s, std::vector<uint32_t>(units.rows.begin() + units.row_off[u], units.rows.begin() + units.row_off[u + 1]),
-                       std::vector<uint32_t>(units.vars.begin() + units.var_off[u], units.vars.begin() + units.var_off[u + 1]), P);
-        const auto t_plan1 = std::chrono::steady_clock::now();
+        // the block's structure: planned and uploaded now, or kept from the first solve
+        BlockOnDevice local_block;
+        BlockOnDevice* blk = &local_block;
+        if (reuse) {
+            blk = cache->blocks[block_at].get();
+        } else {
+            if (cache) {
+                cache->blocks.emplace_back(new BlockOnDevice());
+                blk = cache->blocks.back().get();
+            }
+            Pool& sp = cache ? *cache->pool : pool;  // index arrays outlive the solve only when cached
+            const auto t_plan0 = std::chrono::steady_clock::now();
+            plan_component(b, s,
+                           std::vector<uint32_t>(units.rows.begin() + units.row_off[u], units.rows.begin() + units.row_off[u + 1]),
+                           std::vector<uint32_t>(units.vars.begin() + units.var_off[u], units.vars.begin() + units.var_off[u + 1]),
+                           blk->P);
+            blk->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
+            const ComponentPlan& Q = blk->P;
+            blk->d_fvar = sp.up(Q.fvar);
+            blk->d_perm = sp.up(Q.perm);
+            blk->jac.rows = sp.up(Q.rows);
+            blk->jac.jrow_ptr = sp.up(Q.jrow_ptr);
+            blk->jac.jslot = sp.up(Q.jslot);
+            blk->jac.m = Q.m;
+            blk->d_apair_ptr = sp.up(Q.apair_ptr);
+            blk->d_apairs = sp.up(Q.apairs);
+            blk->d_cptr = sp.up(Q.cptr);
+            blk->d_cidx = sp.up(Q.cidx);
+            blk->d_crow = sp.up(Q.crow);
+            blk->chol.lcolptr = sp.up(Q.lcolptr);
+            blk->chol.lrow = sp.up(Q.lrow);
+            blk->chol.l2a = sp.up(Q.l2a);
+            blk->chol.lpair_ptr = sp.up(Q.lpair_ptr);
+            blk->chol.lpairs = sp.up(Q.lpairs);
+            blk->chol.coop = sp.up(Q.coop);
+            blk->chol.nv = Q.nv;
+            blk->lrows.rptr = sp.up(Q.rptr);
+            blk->lrows.ridx = sp.up(Q.ridx);
+            blk->lrows.rcol = sp.up(Q.rcol);
+            blk->lists.ptr = sp.up(Q.list_ptr);
+            blk->lists.cols = sp.up(Q.list_cols);
+            blk->lists.first = 0;
+            if (sp.err != hipSuccess) return sp.err;
+        }
+        block_at += 1;
+        const ComponentPlan& P = blk->P;
         const uint32_t m = P.m, nv = P.nv;
-
-        uint32_t* d_fvar = pool.up(P.fvar);
-        uint32_t* d_perm = pool.up(P.perm);
-        SpJac jac;
-        jac.rows = pool.up(P.rows);
-        jac.jrow_ptr = pool.up(P.jrow_ptr);
-        jac.jslot = pool.up(P.jslot);
-        jac.m = m;
+        uint32_t* d_fvar = blk->d_fvar;
+        uint32_t* d_perm = blk->d_perm;
+        SpJac jac = blk->jac;
         jac.overwrite = lbfgs ? 1 : 0;
-        uint32_t* d_apair_ptr = pool.up(P.apair_ptr);
-        uint32_t* d_apairs = pool.up(P.apairs);
-        uint32_t* d_cptr = pool.up(P.cptr);
-        uint32_t* d_cidx = pool.up(P.cidx);
-        uint32_t* d_crow = pool.up(P.crow);
-        SpChol chol;
-        chol.lcolptr = pool.up(P.lcolptr);
-        chol.lrow = pool.up(P.lrow);
-        chol.l2a = pool.up(P.l2a);
-        chol.lpair_ptr = pool.up(P.lpair_ptr);
-        chol.lpairs = pool.up(P.lpairs);
-        chol.coop = pool.up(P.coop);
-        chol.nv = nv;
-        SpRowsOfL lrows;
-        lrows.rptr = pool.up(P.rptr);
-        lrows.ridx = pool.up(P.ridx);
-        lrows.rcol = pool.up(P.rcol);
-        ColLists lists;
-        lists.ptr = pool.up(P.list_ptr);
-        lists.cols = pool.up(P.list_cols);
-        lists.first = 0;
+        uint32_t* d_apair_ptr = blk->d_apair_ptr;
+        uint32_t* d_apairs = blk->d_apairs;
+        uint32_t* d_cptr = blk->d_cptr;
+        uint32_t* d_cidx = blk->d_cidx;
+        uint32_t* d_crow = blk->d_crow;
+        const SpChol chol = blk->chol;
+        const SpRowsOfL lrows = blk->lrows;
+        const ColLists lists = blk->lists;
+        const auto t_plan1 = std::chrono::steady_clock::now();
         const uint32_t nlevels = (uint32_t)P.level_ptr.size() - 1;
         double* d_r[2] = {pool.alloc<double>(m), pool.alloc<double>(m)};
         double* d_j[2] = {pool.alloc<double>(P.nnz_j), pool.alloc<double>(P.nnz_j)};
@@ -1366,7 +1436,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                             "%zu lists in %zu levels; plan %.2f ms, upload+LM %.2f ms (%u trials)\n",
                     m, nv, P.nnz_j, P.nnz_a, P.nnz_l, P.lpairs.size() / 2,
                     (unsigned)std::count(P.coop.begin(), P.coop.end(), (uint8_t)1), P.list_ptr.size() - 1,
-                    P.level_ptr.size() - 1, ms(t_plan0, t_plan1),
+                    P.level_ptr.size() - 1, reuse ? 0.0 : blk->plan_ms,
                     ms(t_plan1, t_end), trials);
         }
         res.accepted += accepted;
@@ -1387,6 +1457,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     res.scale = host3[0];
     res.sse_unscaled = host3[1];
     if (result) *result = res;
+    if (cache) cache->ready = true;
     e = hipGetLastError();
     return e;
 }
