@@ -464,6 +464,11 @@ struct fx_dbatch {
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
     // sparse-path plans of large Systems, key = 2 * system + (SinglePass ? 1 : 0)
     std::map<uint64_t, fx::SparsePlanCache*> sparse_plans;
+    // Decomposer::None on large Systems made of small components: the component walk (a DeviceBatch
+    // whose unit arrays list whole components), built on first use
+    fx::DeviceBatch comp_walk{};
+    bool comp_walk_built = false;
+    std::vector<uint8_t> h_comp_walk;  // per System: 1 = walked on the device
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -712,6 +717,97 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     return FX_OK;
 }
 
+// Decomposer::None on a System too large for LDS but made of components that each fit one wavefront (a
+// sketch of many separate features): the GLOBAL block walker takes the components as its blocks — rows
+// and free variables ascending, snapshot restore after each (quirk Q2) — instead of the host-driven
+// sparse path going through them one by one.
+int ensure_component_walk(fx_ctx* ctx, fx_dbatch* db) {
+    if (db->comp_walk_built) return FX_OK;
+    const fx_batch& hb = db->h_batch;
+    const uint32_t n = db->d.n_systems;
+    std::vector<uint32_t> unit_off((size_t)n + 1, 0), unit_rows, g_list, g_off;
+    std::vector<uint16_t> unit_vars;
+    std::vector<fx::UnitDesc> desc;
+    db->h_comp_walk.assign(n, 0);
+    uint32_t g_total = 0, mf = 0, mr = 0, mp = 0, me = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        unit_off[s] = (uint32_t)desc.size();
+        if (db->h_sys_large.empty() || db->h_sys_large[s] != 1) continue;
+        const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0;
+        const uint32_t e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
+        uint32_t ncomp = 0;
+        for (uint32_t i = 0; i < nvt; ++i) {
+            uint16_t c = hb.var_comp ? hb.var_comp[v0 + i] : 0;
+            if (c != FX_NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, c + 1u);
+        }
+        std::vector<std::vector<uint32_t>> rows(ncomp), fvars(ncomp);
+        std::vector<uint8_t> has_var(ncomp, 0);
+        std::vector<uint32_t> pairs(ncomp, 0), ents(ncomp, 0);
+        for (uint32_t i = 0; i < nvt; ++i) {
+            uint16_t c = hb.var_comp ? hb.var_comp[v0 + i] : 0;
+            if (c == FX_NO_COMPONENT) continue;
+            has_var[c] = 1;
+            if (!hb.var_fixed[v0 + i]) fvars[c].push_back(i);
+        }
+        for (uint32_t i = 0; i < net; ++i) {
+            uint16_t c = hb.expr_comp ? hb.expr_comp[e0 + i] : 0;
+            if (c == FX_NO_COMPONENT || c >= ncomp) continue;
+            rows[c].push_back(i);
+            uint32_t k = (uint32_t)fx::tag_nvars((int)hb.expr_tag[e0 + i]);
+            pairs[c] += k * k;
+            ents[c] += k;
+        }
+        bool fits = nvt <= 0xFFFFu;
+        for (uint32_t c = 0; c < ncomp && fits; ++c) fits = fvars[c].size() <= FX_MAX_FREE_VARS && rows[c].size() <= FX_MAX_ROWS;
+        if (!fits) continue;
+        for (uint32_t c = 0; c < ncomp; ++c) {
+            if (!has_var[c]) continue;  // skipped by the reference
+            fx::UnitDesc ud{};
+            ud.row_off = (uint32_t)unit_rows.size();
+            ud.var_off = (uint32_t)unit_vars.size();
+            ud.nrows = (uint16_t)rows[c].size();
+            ud.nvars = (uint16_t)fvars[c].size();
+            ud.comp = (uint16_t)c;
+            ud.flags = (uint16_t)(fx::UNIT_FIRST | fx::UNIT_RESTORE);
+            unit_rows.insert(unit_rows.end(), rows[c].begin(), rows[c].end());
+            for (uint32_t v : fvars[c]) unit_vars.push_back((uint16_t)v);
+            desc.push_back(ud);
+            mf = std::max<uint32_t>(mf, ud.nvars);
+            mr = std::max<uint32_t>(mr, ud.nrows);
+            mp = std::max(mp, pairs[c]);
+            me = std::max(me, ents[c]);
+        }
+        db->h_comp_walk[s] = 1;
+        g_list.push_back(s);
+        g_off.push_back(g_total);
+        g_total += nvt;
+    }
+    unit_off[n] = (uint32_t)desc.size();
+    fx::DeviceBatch w = db->d;
+    w.n_g = 0;
+    if (!g_list.empty()) {
+        int rc = dev_alloc_copy(ctx, db, &w.unit_desc, desc.data(), desc.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.unit_rows, unit_rows.data(), unit_rows.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.unit_vars, unit_vars.data(), unit_vars.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.sys_unit_off, unit_off.data(), unit_off.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.g_list, g_list.data(), g_list.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.g_off, g_off.data(), g_off.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.g_xs, (const double*)nullptr, 2 * (size_t)g_total);
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.g_vout, (const double*)nullptr, g_total);
+        if (!rc) rc = dev_alloc_copy(ctx, db, &w.g_colof, (const int16_t*)nullptr, g_total);
+        if (rc) return rc;
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        w.n_g = (uint32_t)g_list.size();
+        w.max_unit_free_g = mf;
+        w.max_unit_rows_g = mr;
+        w.max_pairs_g = mp;
+        w.max_ents_g = me;
+    }
+    db->comp_walk = w;
+    db->comp_walk_built = true;
+    return FX_OK;
+}
+
 // Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
 // the wide kernel covers f64 Levenberg-Marquardt without a decomposer
 bool wide_kernel_applies(const fx::LmParams& p) {
@@ -725,11 +821,24 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
     }
     const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
+    // Decomposer::None, f64 LM: large Systems made of small components are walked on the device
+    const bool comp_walk = wide_kernel_applies(p);
+    if (comp_walk) {
+        int rc = ensure_component_walk(ctx, db);
+        if (rc) return rc;
+        if (db->comp_walk.n_g) {
+            fx::LmParams pw = p;
+            pw.mode |= fx::MODE_UNITS;  // the walker's block loop; the RESTORE flag keeps None semantics
+            hipError_t e = fx::launch_solve_walk(db->comp_walk, pw, ctx->stream);
+            if (e != hipSuccess) return fail(FX_ERR_HIP, "component walk launch failed: %s", hipGetErrorString(e));
+        }
+    }
     std::vector<uint32_t> todo;
     for (uint32_t s = 0; s < db->d.n_systems; ++s) {
         if (!db->h_sys_large[s]) continue;
         if (db->h_sys_large[s] == 2 && wide_kernel_applies(p)) continue;  // done by the wide kernel
         if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
+        if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
         todo.push_back(s);
     }
     // plan caches are created here, on the calling thread (the map is not touched by the workers)

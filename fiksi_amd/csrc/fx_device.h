@@ -30,6 +30,8 @@ struct UnitDesc {
 };
 constexpr uint16_t UNIT_FIRST = 1;  // first block of its component: the component is perturbed before it
 constexpr uint16_t UNIT_EMPTY = 2;  // placeholder of a component without any block
+constexpr uint16_t UNIT_RESTORE = 4;  // the block is a whole component of Decomposer::None: afterwards the working vector goes
+                                      // back to the pre-solve snapshot (quirk Q2) instead of taking the solved values
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
@@ -103,6 +105,8 @@ hipError_t launch_dense_jacobian(const DeviceBatch& b, const double* x, const ui
                                  const uint16_t* sys_nfree, const uint64_t* dense_off, double* resid, double* jac,
                                  hipStream_t stream);
 hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+// the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
+hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t wide_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes_units(const DeviceBatch& b);

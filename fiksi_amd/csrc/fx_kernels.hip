@@ -203,8 +203,10 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     const uint32_t n_iter = UNITS ? b.sys_unit_off[s + 1] - unit0 : ncomp;
     for (uint32_t c = 0; c < n_iter; ++c) {
         uint32_t nfree = 0, m_rows = 0;
+        uint32_t unit_flags = 0;
         if constexpr (UNITS) {
         const UnitDesc ud = b.unit_desc[unit0 + c];
+        unit_flags = ud.flags;
         if (ud.flags & UNIT_FIRST) {  // the component's perturbation comes before its first block (:91-111)
             comps_done += 1;
             last_exit = FX_EXIT_SSE;
@@ -773,11 +775,11 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             double xo = (prm.mode & 1u) ? scale * x : x;
             b.vars[v0 + vi] = xo;
             VOUT[vi] = xo;
-            if (UNITS) {  // SinglePass also updates the working vector (:201-207)
+            if (UNITS) colof[vi] = (int16_t)-1;
+            if (UNITS && !(unit_flags & UNIT_RESTORE)) {  // SinglePass also updates the working vector (:201-207)
                 T xv = XS[cur * vt + vi];
                 XS[vi] = xv;
                 XS[vt + vi] = xv;
-                colof[vi] = (int16_t)-1;
             } else {
                 // later components are solved against the PRE-solve snapshot (only `system.variables` is
                 // written back, quirk Q2): restore the perturbed start value in both halves
@@ -1132,6 +1134,11 @@ static hipError_t launch_solve_global(const DeviceBatch& b, const LmParams& p, h
         case 64: return launch_solve_global_n<64>(b, p, L, stream);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (b.n_g == 0) return hipSuccess;
+    return launch_solve_global(b, p, stream);
 }
 
 template <int N, typename T, bool PROF, bool UNITS, int OPT>

@@ -195,3 +195,46 @@ def test_resident_batch_with_new_parameters_and_start_values(fiksi, oracle, ctx)
     v_o, r_o = oracle.solve_batch(b2, mode=3, nthreads=4)
     assert np.mean(r2["accepted"] == r_o["accepted"]) > 0.95
     db.free()
+
+
+def test_large_system_of_many_small_components_is_walked_on_the_device(fiksi, oracle, ctx):
+    """One System of 150 separate features (600 points in triangles and quadrilaterals: 1 200 variables, far
+    beyond LDS) under Decomposer::None: every component fits a wavefront, so one wavefront walks them in
+    order — shared LCG stream across components, snapshot semantics of quirk Q2 — instead of 150 trips
+    through the host-driven sparse path. Same answer as the oracle."""
+    F = fiksi
+    import time
+
+    s = F.System()
+    g = 0.0
+    for k in range(150):
+        n = 3 + (k % 2)
+        pts = [F.elements.Point.create(s, 10.0 * k + 1.3 * i + 0.01 * ((7 * k + i) % 5), 0.9 * ((i * i + k) % 3)) for i in range(n)]
+        for i in range(n):
+            F.constraints.PointPointDistance.create(s, pts[i], pts[(i + 1) % n], 1.5 + 0.1 * (k % 4))
+        if n == 4:
+            F.constraints.PointPointDistance.create(s, pts[0], pts[2], 2.2)
+        if k % 9 == 0:
+            pts[0].fix(s)
+    flat = s.flatten()
+    assert len(flat["vars"]) > 1000 and int(flat["var_comp"].max()) == 149
+    t = time.time()
+    v, res = ctx.system_solve_batch(flat)
+    dt = time.time() - t
+    v_o, res_o = oracle.solve_batch(flat, mode=3, trial_cap=4096)
+    assert res["ncomp"][0] == res_o["ncomp"][0] == 150
+    assert res["accepted"][0] == res_o["accepted"][0] and res["trials"][0] == res_o["trials"][0]
+    assert np.max(np.abs(v - v_o)) < 1e-8
+    fx = flat["var_fixed"] == 1
+    assert np.array_equal(v[fx], flat["vars"][fx])
+    assert dt < 0.05  # one launch, not 150 host-driven solves
+    # mixed with other size classes in one batch, and repeatable on a resident batch
+    from fiksi_amd import workloads
+    b = workloads.concat([workloads.ring16(3), flat, workloads.hinged_triangles(1, 20), workloads.large_sketch(60)])
+    v2, res2 = ctx.system_solve_batch(b)
+    assert np.array_equal(v2[96:96 + len(v)], v)
+    db = ctx.upload(b)
+    db.system_solve()
+    db.system_solve()
+    assert np.array_equal(db.get_vars(), v2)
+    db.free()
