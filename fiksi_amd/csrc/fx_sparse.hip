@@ -300,6 +300,7 @@ struct SpChol {                  // symbolic factor (device)
     const int32_t* l2a;          // [nnzL] index into A or -1 (fill-in)
     const uint32_t* lpair_ptr;   // [nnzL+1]
     const uint32_t* lpairs;      // [2*npairs] indices into L
+    const uint32_t* lpair_k;     // [npairs] the entry of L a product belongs to (the inverse of lpair_ptr)
     const uint8_t* coop;         // [nv] 1 = the column's gather lists are long: the whole wavefront sums each one
     uint32_t nv;
 };
@@ -314,6 +315,9 @@ struct ColLists {
     uint32_t first;
 };
 
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+}
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -336,6 +340,7 @@ __global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsO
                                                                const double* __restrict__ a, double lambda,
                                                                double* __restrict__ l, double* __restrict__ b,
                                                                uint32_t* __restrict__ flag) {
+    __shared__ double acc[64];
     const int lane = threadIdx.x;
     const uint32_t list = cl.first + blockIdx.x;
     bool bad = false;
@@ -355,20 +360,18 @@ __global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsO
                 s = ai >= 0 ? a[ai] : 0.0;
                 if (k == beg) s += lambda;
             }
-            if (c.coop[j]) {
-                // separator columns: few entries, each the sum of hundreds of products (every column of
-                // the neighbouring subtrees contributes) — lanes stride over one list at a time
-                for (uint32_t t = beg; t < end; ++t) {
-                    double part = 0.0;
-                    for (uint32_t p = c.lpair_ptr[t] + lane; p < c.lpair_ptr[t + 1]; p += 64)
-                        part = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), part);
-                    part = wave_sum64(part);
-                    if (k == t) s += part;
-                }
-            } else if (k < end) {
-                for (uint32_t p = c.lpair_ptr[k]; p < c.lpair_ptr[k + 1]; ++p)
-                    s = fma(-ld_l2(l + c.lpairs[2 * p]), ld_l2(l + c.lpairs[2 * p + 1]), s);
+            // All products of the column in one flat, lane-strided sweep (they are contiguous: lpair_ptr
+            // is a prefix over the entries), summed per entry with LDS atomics. A lane walking its own
+            // list one product at a time pays an L2 round trip per product — 85 in a row for the top
+            // separators; flat, the whole column is a handful of passes.
+            if (lane < 64) acc[lane] = 0.0;
+            __syncthreads();
+            for (uint32_t p = c.lpair_ptr[beg] + lane; p < c.lpair_ptr[end]; p += 64) {
+                const double v = -ld_l2(l + c.lpairs[2 * p]) * ld_l2(l + c.lpairs[2 * p + 1]);
+                lds_add_f64(&acc[c.lpair_k[p] - beg], v);
             }
+            __syncthreads();
+            if (k < end) s += acc[lane];
             int lo = __builtin_amdgcn_readfirstlane(__double2loint(s));
             int hi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
             double piv = __hiloint2double(hi, lo);
@@ -685,7 +688,7 @@ struct ComponentPlan {
     std::vector<uint32_t> perm;                        // new column -> old column
     std::vector<uint32_t> apair_ptr, apairs;           // gather lists of A
     std::vector<uint32_t> cptr, cidx, crow;            // columns of J (permuted order) for the rhs
-    std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs;
+    std::vector<uint32_t> lcolptr, lrow, lpair_ptr, lpairs, lpair_k;
     std::vector<int32_t> l2a;
     std::vector<uint8_t> coop;                         // per column: sum its gather lists cooperatively
     std::vector<uint32_t> rptr, ridx, rcol;            // strictly lower part of L by rows
@@ -882,6 +885,10 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
                     P.lpairs[2 * (size_t)dst + 1] = P.lcolptr[k] + (uint32_t)p;  // L[j][k]
                 }
     }
+
+    P.lpair_k.assign(P.lpairs.size() / 2, 0);
+    for (uint32_t t = 0; t < P.nnz_l; ++t)
+        for (uint32_t pp = P.lpair_ptr[t]; pp < P.lpair_ptr[t + 1]; ++pp) P.lpair_k[pp] = t;
 
     // --- how a column sums its gather lists: one lane per entry (cost ~ the longest list), or the whole
     // wavefront on one list after the other (cost ~ sum over entries of ceil(len / 64) + a reduction)
@@ -1191,6 +1198,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
             blk->chol.l2a = sp.up(Q.l2a);
             blk->chol.lpair_ptr = sp.up(Q.lpair_ptr);
             blk->chol.lpairs = sp.up(Q.lpairs);
+            blk->chol.lpair_k = sp.up(Q.lpair_k);
             blk->chol.coop = sp.up(Q.coop);
             blk->chol.nv = Q.nv;
             blk->lrows.rptr = sp.up(Q.rptr);
@@ -1430,6 +1438,21 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         e = hipStreamSynchronize(stream);  // the block's device memory is released when `pool` goes out of scope
         if (e != hipSuccess) return e;
         if (trace) {
+            for (size_t v = 0; v + 1 < P.level_ptr.size(); ++v) {
+                uint32_t maxc = 0, totc = 0, maxl = 0, maxr = 0;
+                for (uint32_t q = P.level_ptr[v]; q < P.level_ptr[v + 1]; ++q) {
+                    uint32_t nc = P.list_ptr[q + 1] - P.list_ptr[q];
+                    maxc = std::max(maxc, nc);
+                    totc += nc;
+                    for (uint32_t t = P.list_ptr[q]; t < P.list_ptr[q + 1]; ++t) {
+                        uint32_t j = P.list_cols[t];
+                        maxr = std::max(maxr, P.rptr[j + 1] - P.rptr[j]);
+                        for (uint32_t k = P.lcolptr[j]; k < P.lcolptr[j + 1]; ++k) maxl = std::max(maxl, P.lpair_ptr[k + 1] - P.lpair_ptr[k]);
+                    }
+                }
+                fprintf(stderr, "[fiksi_amd]   level %zu: %u lists, %u columns (longest list %u), longest product list %u, longest L row %u\n",
+                        v, P.level_ptr[v + 1] - P.level_ptr[v], totc, maxc, maxl, maxr);
+            }
             const auto t_end = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
             fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u (%zu products, %u cooperative columns), "
