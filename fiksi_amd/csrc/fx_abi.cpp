@@ -44,7 +44,8 @@ struct HostPlan {
     uint32_t n_systems = 0, n_vars = 0, n_exprs = 0;
     uint64_t nnz = 0;
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
-    uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0;
+    uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0, max_pairs_tri = 0;
+    uint32_t uniform = 0;  // every System has the same structure (one sketch, many parameter sets)
     std::vector<uint16_t> sys_ncomp;
     std::vector<uint8_t> sys_large;  // 0 fused kernel, 2 wide kernel (65..128 free variables), 1 sparse path
     uint32_t n_large = 0;            // Systems with sys_large != 0
@@ -200,7 +201,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         uint64_t nnz = 0;
         uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0, n_large = 0;
         uint32_t w_max_free = 0, w_max_rows = 0, w_max_vars = 0;
-        uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0;
+        uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0, max_pairs_tri = 0;
         int err = FX_OK;
         uint32_t err_system = 0;
         char msg[192] = {0};
@@ -214,7 +215,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             snprintf(pt.msg, sizeof(pt.msg), fmt, a0, a1, a2, a3);
         };
         std::vector<int32_t> free_rank;  // per variable of the current system: system-wide free rank
-        std::vector<uint32_t> comp_free, comp_rows, comp_pairs, comp_ents;
+        std::vector<uint32_t> comp_free, comp_rows, comp_pairs, comp_ents, comp_tri;
         for (uint32_t s = s_lo; s < s_hi && pt.err == FX_OK; ++s) {
             const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
             const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
@@ -267,6 +268,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             comp_rows.assign(ncomp, 0);
             comp_pairs.assign(ncomp, 0);
             comp_ents.assign(ncomp, 0);
+            comp_tri.assign(ncomp, 0);
             for (uint32_t i = 0; i < nvt; ++i) {
                 uint16_t info = p.var_info[v0 + i];
                 uint16_t c = info & fx::VAR_COMP_MASK;
@@ -313,6 +315,11 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                     for (int q = 0; q < k; ++q) kf += free_rank[vars8[q]] >= 0;
                     comp_pairs[c] += kf * kf;
                     comp_ents[c] += kf;
+                    // the lower triangle only: unordered pairs, plus once more for two entries on one column
+                    uint32_t twice = 0;
+                    for (int q = 0; q < k; ++q)
+                        for (int u = q + 1; u < k; ++u) twice += vars8[q] == vars8[u] && free_rank[vars8[q]] >= 0;
+                    comp_tri[c] += kf * (kf + 1u) / 2u + twice;
                 }
                 if (all_free && distinct) {
                     pt.nnz += (uint64_t)k;
@@ -322,10 +329,11 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 }
             }
             if (pt.err != FX_OK) break;
-            uint32_t cp_max = 0, ce_max = 0;
+            uint32_t cp_max = 0, ce_max = 0, ct_max = 0;
             for (uint32_t c = 0; c < ncomp; ++c) {
                 cp_max = std::max(cp_max, comp_pairs[c]);
                 ce_max = std::max(ce_max, comp_ents[c]);
+                ct_max = std::max(ct_max, comp_tri[c]);
             }
             bool wide = false;  // more than one wavefront's columns, but still an LDS-resident dense problem
             uint32_t cf_max = 0, cr_max = 0;
@@ -350,6 +358,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 pt.max_exprs = std::max(pt.max_exprs, net);
                 pt.max_pairs = std::max(pt.max_pairs, cp_max);
                 pt.max_ents = std::max(pt.max_ents, ce_max);
+                pt.max_pairs_tri = std::max(pt.max_pairs_tri, ct_max);
                 for (uint32_t c = 0; c < ncomp; ++c) {
                     pt.max_free = std::max(pt.max_free, comp_free[c]);
                     pt.max_rows = std::max(pt.max_rows, comp_rows[c]);
@@ -370,6 +379,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         p.max_exprs_all = std::max(p.max_exprs_all, part[t].max_exprs_all);
         p.max_pairs = std::max(p.max_pairs, part[t].max_pairs);
         p.max_ents = std::max(p.max_ents, part[t].max_ents);
+        p.max_pairs_tri = std::max(p.max_pairs_tri, part[t].max_pairs_tri);
         p.max_pairs_large = std::max(p.max_pairs_large, part[t].max_pairs_large);
         p.max_ents_large = std::max(p.max_ents_large, part[t].max_ents_large);
         p.w_max_free = std::max(p.w_max_free, part[t].w_max_free);
@@ -378,6 +388,20 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     }
     for (uint32_t s = 0; s < n; ++s)
         if (p.sys_large[s] == 2) p.wide_list.push_back(s);
+    // Same structure everywhere? (sizes, components, fixed flags, kinds and element fields of System 0.) The
+    // grouped kernel then builds its per-System lists once per lane row instead of once per System.
+    if (n >= 2) {
+        const uint32_t nv0 = b->var_off[1] - b->var_off[0], ne0 = b->expr_off[1] - b->expr_off[0];
+        bool same = (uint64_t)nv0 * n == nv && (uint64_t)ne0 * n == ne;
+        for (uint32_t s = 1; same && s < n; ++s) {
+            same = b->var_off[s] == s * nv0 && b->expr_off[s] == s * ne0 &&
+                   memcmp(&p.var_info[(size_t)s * nv0], &p.var_info[0], nv0 * sizeof(uint16_t)) == 0 &&
+                   memcmp(&p.expr_tagx[(size_t)s * ne0], &p.expr_tagx[0], ne0) == 0 &&
+                   memcmp(&p.expr_comp[(size_t)s * ne0], &p.expr_comp[0], ne0 * sizeof(uint16_t)) == 0 &&
+                   memcmp(&p.expr_idx16[4 * (size_t)s * ne0], &p.expr_idx16[0], 4 * (size_t)ne0 * sizeof(uint16_t)) == 0;
+        }
+        p.uniform = same ? 1u : 0u;
+    }
     // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
     const uint32_t nblk = (ne + 255u) / 256u;
     p.blk_info.assign(nblk, fx::BlockInfo{});
@@ -1042,6 +1066,8 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     d.max_exprs_all = p.max_exprs_all;
     d.max_pairs = p.max_pairs;
     d.max_ents = p.max_ents;
+    d.max_pairs_tri = p.max_pairs_tri;
+    d.uniform = p.uniform;
     d.max_pairs_g = p.max_pairs_large;  // blocks of a large System hold at most its components' products
     d.max_ents_g = p.max_ents_large;
     const uint32_t zero_off[1] = {0};
@@ -1071,6 +1097,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(row_sysoff, p.row_sysoff.data(), p.n_exprs)
     FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
+    FX_UP(work_counter, (const uint32_t*)nullptr, 1)
     FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
 #undef FX_UP
     size_t packed = 0;

@@ -47,6 +47,8 @@ struct DeviceBatch {
     uint32_t max_vars_all, max_exprs_all;  // the same maxima over ALL Systems (large ones included)
     uint32_t max_pairs, max_ents;          // per component: sum over rows of (free entries)^2 / of free entries
     uint32_t max_pairs_g, max_ents_g;      // the same over the Systems of the GLOBAL block walker
+    uint32_t max_pairs_tri;                // per component: products of the lower triangle only (grouped kernel)
+    uint32_t uniform;                      // 1: every System has the same structure (variables, fixed flags, expressions)
 
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]
@@ -72,6 +74,7 @@ struct DeviceBatch {
     double* resid;         // [n_exprs]
     fx_result* results;    // [n_systems]
     double* sse_unscaled;  // [n_systems] sum r^2 on the solved, unscaled variables
+    uint32_t* work_counter;  // [1] next System of the grouped kernel's device-side queue (reset before each launch)
     // medium Systems (sys_large == 2)
     uint32_t n_wide, w_max_free, w_max_vars, w_max_rows;
     uint32_t* w_list;         // [n_wide] System ids
@@ -105,6 +108,10 @@ hipError_t launch_dense_jacobian(const DeviceBatch& b, const double* x, const ui
                                  const uint16_t* sys_nfree, const uint64_t* dense_off, double* resid, double* jac,
                                  hipStream_t stream);
 hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+// several Systems per wavefront (fx_grouped.hip): batches of components with at most 32 free variables
+bool grouped_applies(const DeviceBatch& b, const LmParams& p);
+hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t wide_lds_bytes(const DeviceBatch& b);

@@ -1,0 +1,909 @@
+// Grouped fused solve (gfx950, wave64): FOUR Systems per wavefront, one per row of 16 lanes, for batches
+// whose components have at most 32 free variables — the headline shape (BASELINE cfg3: 32 variables /
+// 32 expressions per System) and everything smaller.
+//
+// Same algorithm and the same arithmetic as lm_solve_kernel (fx_kernels.hip; reference:
+// fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193), reorganised around what that kernel's
+// profile shows: with N <= 32 columns only half of a wavefront's lanes hold a column of the
+// register-resident Cholesky, and every multiply-add of it pays two v_readlane for its broadcast. Here
+//   * a System lives in one DPP row: lane r of the row holds columns r and r + 16 of the matrix (NC = 2;
+//     NC = 1 for components of at most 16 free variables), and every broadcast is a
+//     `v_mov_b32_dpp row_newbcast:k` — a full-rate VALU move that serves the four Systems of the
+//     wavefront at once and feeds NC multiply-adds, with no SGPR and no LDS round trip;
+//   * what was wave-uniform (lambda, SSE, trial counts, exit code) is row-uniform and kept per lane; the LM
+//     control flow is a per-row state machine (NEXT System -> COMPonent set-up -> RUN trials -> FINISH
+//     component), so rows only wait for each other inside one wave instruction;
+//   * rows take Systems from a device-side counter: a row that finishes early starts its next System
+//     while its neighbours are still iterating;
+//   * LDS per System is cut to 10 KB for the headline shape (JtJ as a packed lower triangle, one
+//     Jacobian-row buffer — the trial point's rows are only read after it was accepted —, the current point
+//     in registers, set-up scratch aliased with the triangle), so a CU still holds 16 Systems.
+// Sums (SSE, |delta|^2, the system scale) are taken in the order lm_solve_kernel takes them, and the
+// factorization does the same operations on the same operands: results are bit-identical to that kernel's
+// (tests/test_gpu_grouped.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <utility>
+
+#include "fx_device.h"
+#include "fx_expr.h"
+#include "fx_wave.h"
+
+namespace fx {
+
+constexpr int RS = 16;  // lanes per System: one DPP row
+
+struct GroupLayout {
+    uint32_t vt, mr;  // padded variables per System / rows per component
+    uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_rtag, off_vout, off_pw, off_pe;
+    uint32_t off_colof, off_gcol, off_fidx;  // set-up scratch inside the triangle's bytes
+    uint32_t pw_cap, pe_cap;
+    uint32_t stride;  // bytes per System
+};
+
+static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max_rows, uint32_t es, uint32_t max_pairs_tri,
+                                     uint32_t max_ents) {
+    GroupLayout L;
+    L.vt = (max_vars + 7u) & ~7u;
+    L.mr = (max_rows + 7u) & ~7u;
+    if (L.vt == 0) L.vt = 8;
+    if (L.mr == 0) L.mr = 8;
+    uint32_t o = 0;
+    auto al = [](uint32_t bytes) { return (bytes + 15u) & ~15u; };
+    auto take = [&](uint32_t bytes) { uint32_t at = o; o += al(bytes); return at; };
+    L.off_xs = take(L.vt * es);
+    const uint32_t tri = n * (n + 1u) / 2u * es;
+    const uint32_t scratch = al(L.vt * 2u) + al(L.mr * 8u) + al(n * 2u);
+    L.off_a = take(tri > scratch ? tri : scratch);
+    L.off_colof = L.off_a;
+    L.off_gcol = L.off_colof + al(L.vt * 2u);
+    L.off_fidx = L.off_gcol + al(L.mr * 8u);
+    L.off_rhs = take(n * es);
+    L.off_g = take(L.mr * 8u * es);
+    L.off_r = take(L.mr * es);
+    L.off_p = take(L.mr * es);
+    L.off_gvar = take(L.mr * 16u);
+    L.off_rtag = take(L.mr);
+    L.off_vout = take(L.vt * 8u);
+    L.pw_cap = (max_pairs_tri + 3u) & ~3u;
+    L.pe_cap = (max_ents + 7u) & ~7u;
+    L.off_pw = take(L.pw_cap * 4u);
+    L.off_pe = take(L.pe_cap * 2u);
+    L.stride = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------
+// row-wide cross-lane helpers
+// ------------------------------------------------------------------------------------------
+// lane K of the caller's row of 16 (DPP row_newbcast; the lane is an instruction immediate)
+template <int K>
+__device__ __forceinline__ double rbcast(double v) {
+    // (mov_dpp: every source lane of a row broadcast is valid, so no `old` value has to be set up first)
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float rbcast(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x150 + K, 0xF, 0xF, false));
+}
+// acc = fma(-(m's lane K of the row), w, acc) in one VOP2-DPP instruction (gfx90a+: 64-bit DPP takes row_newbcast)
+template <int K>
+__device__ __forceinline__ void fnma_rbcast(double& acc, double m, double w) {
+    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fnma_rbcast(float& acc, float m, float w) {
+    asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
+}
+// the same with m == acc (the register is read through DPP before it is written)
+template <int K>
+__device__ __forceinline__ void fnma_rbcast_self(double& acc, double w) {
+    asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
+}
+template <int K>
+__device__ __forceinline__ void fnma_rbcast_self(float& acc, float w) {
+    asm("v_fmac_f32_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
+}
+// sum over the 16 lanes of a row, identical bits in every lane: the DPP butterfly of wave_sum
+template <typename T>
+__device__ __forceinline__ T row_sum(T v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    return v;
+}
+// wave_sum over a vector laid out 16 entries per accumulator (acc[q] of lane r = entry 16 q + r, entries
+// 64 apart added up first): (b0 + b1) + (b2 + b3), the order wave_sum adds its four rows in
+template <typename T>
+__device__ __forceinline__ T block_sum4(const T (&acc)[4]) {
+    return (row_sum(acc[0]) + row_sum(acc[1])) + (row_sum(acc[2]) + row_sum(acc[3]));
+}
+// sum += t(lane 0) + t(lane 1) + ... + t(lane 15) of the row, strictly in that order
+template <int... K>
+__device__ __forceinline__ void seq_add_impl(double& sum, double t, std::integer_sequence<int, K...>) {
+    ((sum += rbcast<K>(t)), ...);
+}
+__device__ __forceinline__ void seq_add(double& sum, double t) { seq_add_impl(sum, t, std::make_integer_sequence<int, RS>{}); }
+
+// ------------------------------------------------------------------------------------------
+// Cholesky of fx_chol.h with the columns of one matrix spread over a row: lane r holds column r + 16 q in
+// a[q][.] (same operations on the same operands as chol_factor / chol_solve: bit-identical results)
+// ------------------------------------------------------------------------------------------
+template <int NC, typename T, int K>
+struct RStep {
+    static constexpr int N = RS * NC;
+    static constexpr int KA = K / RS, KL = K % RS;  // array and lane of column K
+    static __device__ __forceinline__ void factor(T (&a)[NC][N], T (&invd)[NC], bool& bad, int hl) {
+        const T piv = rbcast<KL>(a[KA][K]);
+        bad = bad || !(piv > T(0)) || !(piv < Lim<T>::huge());
+        const T rs = rsqrt_refined(piv);
+        const T ip = rs * rs;  // 1/pivot
+        T mul[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            mul[q] = T(0);
+            if (q < KA) continue;  // columns below K: untouched
+            const T ljk = a[q][K] * rs;
+            const bool above = (q > KA) || (hl > KL);  // column > K
+            mul[q] = above ? a[q][K] * ip : T(0);
+            if (above || hl == KL) a[q][K] = ljk;
+            if (q == KA && hl == KL) invd[q] = rs;
+        }
+        // a[q][i] -= A_iK (from the lane of column K, which still holds A_iK = L_iK * d_K) * mul[q]: ONE instruction
+        // each, v_fmac_f64_dpp with the broadcast as its DPP operand. Array KA last: its update leaves the lane of
+        // column K untouched (mul = 0 there), and so no DPP read follows a write of the same register.
+#pragma unroll
+        for (int i = K + 1; i < N; ++i) {
+#pragma unroll
+            for (int q = NC - 1; q >= KA; --q) {
+                if (q == KA && KL == RS - 1) continue;  // no column of this array lies above K
+                if (q == KA) fnma_rbcast_self<KL>(a[q][i], mul[q]);
+                else fnma_rbcast<KL>(a[q][i], a[KA][i], mul[q]);
+            }
+        }
+        // (inline asm is opaque to the hazard recogniser: a DPP read needs two wait states after a VALU write of its
+        // source, and the next pivot broadcast may read what the last instruction above wrote)
+        asm volatile("s_nop 1");
+        if constexpr (K + 1 < N) RStep<NC, T, K + 1>::factor(a, invd, bad, hl);
+    }
+    static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl) {
+        const T yk = rbcast<KL>(acc[KA] * invd[KA]);
+#pragma unroll
+        for (int q = KA; q < NC; ++q) {
+            if (q == KA && KL == RS - 1) continue;
+            if (q > KA || hl > KL) acc[q] = fma(-a[q][K], yk, acc[q]);
+        }
+        if constexpr (K + 1 < N) RStep<NC, T, K + 1>::forward(a, invd, acc, hl);
+    }
+    static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl) {
+        const T xi = rbcast<KL>(acc[KA] * invd2[KA]);
+#pragma unroll
+        for (int q = 0; q <= KA; ++q) {
+            if (q == KA && KL == 0) continue;  // no column of this array lies below K
+            if (q < KA || hl < KL) acc[q] = fma(-a[q][K], xi, acc[q]);
+        }
+        if constexpr (K > 0) RStep<NC, T, K - 1>::backward(a, invd2, acc, hl);
+    }
+};
+
+// LDS accesses of one wavefront execute in order; between phases that exchange data through LDS inside a
+// row only the compiler has to be kept from reordering them (no s_barrier: rows diverge).
+// (wavefront scope: a workgroup-scope fence would also drain the global loads in flight, vmcnt(0))
+__device__ __forceinline__ void group_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+enum GroupPhase : int { GP_NEXT = 0, GP_COMP = 1, GP_RUN = 2, GP_FINISH = 3, GP_EXIT = 4 };
+
+// PROF = true is the diagnostic build (fx_debug_phase_cycles): s_memtime stamps at the phase boundaries, summed
+// per phase over the wavefront (all four rows) into prm.prof — same six phases as lm_solve_kernel's.
+enum GPhase { GH_SETUP = 0, GH_EVAL = 1, GH_FORM = 2, GH_FACTOR = 3, GH_SOLVE = 4, GH_TAIL = 5, GH_COUNT = 6 };
+
+template <int NC, typename T, bool PROF>
+__device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParams& prm, const GroupLayout& L,
+                                             uint32_t* __restrict__ next_system, unsigned char* smem) {
+    unsigned long long ph[GH_COUNT] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = 0;
+    // (the stamps sit in divergent control flow, so the compiler keeps these sums per lane: a lane only sees the
+    // stamps of the blocks its row takes part in, and the time its row sits out lands on its next stamp. Lane 0's
+    // sums are reported: row 0's view of the wavefront's time.)
+    auto stamp = [&](int phase_id) {
+        if (PROF) {
+            unsigned long long t = __builtin_amdgcn_s_memtime();
+            ph[phase_id] += t - t_last;
+            t_last = t;
+        }
+    };
+    if (PROF) t_last = __builtin_amdgcn_s_memtime();
+    constexpr int N = RS * NC;
+    constexpr int CB = (NC == 2) ? 5 : 4;  // column bits of a packed entry
+    const int lane = threadIdx.x;
+    const int hl = lane & (RS - 1);
+    const int gbase = lane & ~(RS - 1);
+    const uint32_t below = (1u << hl) - 1u;
+    unsigned char* base = smem + (uint32_t)(lane / RS) * L.stride;
+
+    T* XS = reinterpret_cast<T*>(base + L.off_xs);       // [vt] working variables: snapshot, trial point on the free ones
+    T* At = reinterpret_cast<T*>(base + L.off_a);        // packed lower triangle of JtJ (+ lambda on the diagonal per trial)
+    T* rhsv = reinterpret_cast<T*>(base + L.off_rhs);    // [N] -Jt r
+    T* G = reinterpret_cast<T*>(base + L.off_g);         // [mr][8] Jacobian rows of the last evaluated point
+    T* R = reinterpret_cast<T*>(base + L.off_r);         // [mr]
+    T* P = reinterpret_cast<T*>(base + L.off_p);         // [mr] scaled parameters
+    uint16_t* gvar = reinterpret_cast<uint16_t*>(base + L.off_gvar);  // [mr][8]
+    uint8_t* rtag = reinterpret_cast<uint8_t*>(base + L.off_rtag);    // [mr]
+    double* VOUT = reinterpret_cast<double*>(base + L.off_vout);       // [vt] unscaled values as written back
+    uint32_t* PW = reinterpret_cast<uint32_t*>(base + L.off_pw);       // products of the triangle: row<<19 | a<<16 | b<<13 | address
+    uint16_t* PE = reinterpret_cast<uint16_t*>(base + L.off_pe);       // entries of the right-hand side: row<<(3+CB) | a<<CB | column
+    // set-up scratch, dead before the first assembly zeroes the triangle
+    int16_t* colof = reinterpret_cast<int16_t*>(base + L.off_colof);   // [vt] variable -> free column
+    int8_t* gcol = reinterpret_cast<int8_t*>(base + L.off_gcol);       // [mr][8] free column or -1
+    uint16_t* fidx = reinterpret_cast<uint16_t*>(base + L.off_fidx);   // [N] free column -> variable
+
+    const fx_lm_opts o = prm.lm;
+    auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & 0xFFFFu; };
+    auto tri_at = [](uint32_t r, uint32_t cc) -> uint32_t { return r * (r + 1u) / 2u + cc; };  // r >= cc
+
+    // per-row state (identical in every lane of the row unless noted)
+    int phase = GP_NEXT;
+    uint32_t s = 0, v0 = 0, nvt = 0, e0 = 0, net = 0, ncomp = 0, c = 0;
+    double scale = 1.0, scale_recip = 1.0;
+    uint32_t rng = 42u;
+    uint32_t tot_accept = 0, tot_trials = 0, last_exit = FX_EXIT_SSE, comps_done = 0;
+    double tot_sse0 = 0.0, tot_sse = 0.0;
+    uint32_t nfree = 0, m_rows = 0, n_pw = 0, n_pe = 0;
+    // per lane and column q (column hl + 16 q): its variable, current point, perturbed start, diagonal, right-hand side
+    uint32_t my_vi[NC];
+    T xc[NC], xstart[NC], diag[NC], rhs_l[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        my_vi[q] = 0;
+        xc[q] = xstart[q] = rhs_l[q] = T(0);
+        diag[q] = T(1);
+    }
+    T sse = T(0), sse_start = T(0);
+    double lambda = 0.0;
+    uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
+    bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
+    // Batches whose Systems all have the same structure (one sketch, many parameter sets): the row lists, the
+    // product lists and the free-variable map of a single-component System are built for the first System a row
+    // takes and kept for the following ones — only values change. Per lane: the column of variable hl + 16 k and
+    // the row of expression hl + 16 k (or -1).
+    bool built = false;
+    int c_col[2] = {-1, -1}, c_row[2] = {-1, -1};
+
+    // The System's own arrays, fetched in one round trip when the row takes the System: lane r keeps
+    // elements r and r + 16 of every per-variable / per-expression array (all of them for the headline
+    // shape); elements past 32 are loaded where they are used.
+    constexpr int PF = 2;  // (the selects in for_vars / for_exprs are written for two chunks)
+    double c_var[PF], c_param[PF];
+    uint32_t c_info[PF], c_tag[PF], c_comp[PF];
+    ushort4 c_idx[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        c_var[k] = c_param[k] = 0.0;
+        c_info[k] = c_tag[k] = c_comp[k] = 0;
+        c_idx[k] = make_ushort4(0, 0, 0, 0);
+    }
+    // f(i, value, info) over all variables / f(i, tag, param, comp, idx) over all expressions of the System,
+    // 16 at a time in ascending order; i may lie past the end (then the other arguments are zero / 0xFFFF)
+    // (one dynamic loop each, the cached chunks picked by selects: one copy of every loop body in the code)
+    auto for_vars = [&](auto&& f) {
+#pragma unroll 1
+        for (uint32_t at = 0; at < nvt; at += RS) {
+            const uint32_t i = at + (uint32_t)hl;
+            double v = (at == 0) ? c_var[0] : c_var[1];
+            uint32_t info = (at == 0) ? c_info[0] : c_info[1];
+            if (at >= (uint32_t)(RS * PF)) {
+                const bool have = i < nvt;
+                v = have ? b.vars0[v0 + i] : 0.0;
+                info = have ? (uint32_t)b.var_info[v0 + i] : 0xFFFFu;
+            }
+            f(i, v, info);
+        }
+    };
+    auto for_exprs = [&](auto&& f) {
+#pragma unroll 1
+        for (uint32_t at = 0; at < net; at += RS) {
+            const uint32_t i = at + (uint32_t)hl;
+            int tag = (int)((at == 0) ? c_tag[0] : c_tag[1]);
+            double param = (at == 0) ? c_param[0] : c_param[1];
+            uint32_t comp = (at == 0) ? c_comp[0] : c_comp[1];
+            ushort4 idx = (at == 0) ? c_idx[0] : c_idx[1];
+            if (at >= (uint32_t)(RS * PF)) {
+                const bool have = i < net;
+                tag = have ? (int)(b.expr_tag[e0 + i] & 0x7F) : 0;
+                param = have ? b.expr_param[e0 + i] : 0.0;
+                comp = have ? (uint32_t)b.expr_comp[e0 + i] : 0xFFFFu;
+                idx = have ? reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i] : make_ushort4(0, 0, 0, 0);
+            }
+            f(i, tag, param, comp, idx);
+        }
+    };
+
+    auto eval_rows = [&]() -> T {
+        T part[4] = {T(0), T(0), T(0), T(0)};
+        for (uint32_t row = hl; row < m_rows; row += RS) {
+            T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = XS[gvar[row * 8 + e]];
+            T r = eval_expression<T, true>(rtag[row], v, P[row], g);
+            R[row] = r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) G[row * 8 + e] = g[e];
+            const T r2 = r * r;
+            const uint32_t blk = (row >> 4) & 3u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : T(0);
+        }
+        group_sync();
+        return block_sum4(part);
+    };
+    // K3: the lower triangle of Jt J and -Jt r from the packed lists (ds_add_f64 / ds_add_f32)
+    auto form_normal = [&]() {
+        for (uint32_t i = hl; i < (uint32_t)(N * (N + 1) / 2); i += RS) At[i] = T(0);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) rhsv[hl + RS * q] = T(0);
+        group_sync();
+        for (uint32_t t = hl; t < n_pw; t += RS) {
+            const uint32_t w = PW[t];
+            const uint32_t gb = (w >> 19) * 8u;
+            lds_add(&At[w & 0x1FFFu], G[gb + ((w >> 16) & 7u)] * G[gb + ((w >> 13) & 7u)]);
+        }
+        for (uint32_t t = hl; t < n_pe; t += RS) {
+            const uint32_t w = PE[t];
+            const uint32_t row = w >> (3 + CB);
+            lds_add(&rhsv[w & (uint32_t)(N - 1)], G[row * 8u + ((w >> CB) & 7u)] * -R[row]);
+        }
+        group_sync();
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const uint32_t j = (uint32_t)(hl + RS * q);
+            if (j >= nfree) At[tri_at(j, j)] = T(1);  // identity padding
+        }
+        group_sync();
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const uint32_t j = (uint32_t)(hl + RS * q);
+            diag[q] = At[tri_at(j, j)];
+            rhs_l[q] = rhsv[j];
+        }
+    };
+
+    for (;;) {
+        // ================= NEXT: take a System, scale it, snapshot its variables =================
+        if (phase == GP_NEXT) {
+            uint32_t nxt;
+            for (;;) {
+                uint32_t tk = 0;
+                if (hl == 0) tk = atomicAdd(next_system, 1u);
+                nxt = (uint32_t)__shfl((int)tk, 0, RS);
+                if (nxt >= b.n_systems || !b.sys_large[nxt]) break;  // large Systems belong to the other paths
+            }
+            if (nxt >= b.n_systems) {
+                phase = GP_EXIT;
+            } else {
+                s = nxt;
+                v0 = b.var_off[s];
+                nvt = b.var_off[s + 1] - v0;
+                e0 = b.expr_off[s];
+                net = b.expr_off[s + 1] - e0;
+                ncomp = b.sys_ncomp[s];
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const uint32_t i = (uint32_t)(RS * k + hl);
+                    const bool hv_ = i < nvt, he_ = i < net;
+                    c_var[k] = hv_ ? b.vars0[v0 + i] : 0.0;
+                    c_info[k] = hv_ ? (uint32_t)b.var_info[v0 + i] : 0xFFFFu;
+                    c_tag[k] = he_ ? (uint32_t)(b.expr_tag[e0 + i] & 0x7F) : 0u;
+                    c_param[k] = he_ ? b.expr_param[e0 + i] : 0.0;
+                    c_comp[k] = he_ ? (uint32_t)b.expr_comp[e0 + i] : 0xFFFFu;
+                    c_idx[k] = he_ ? reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i] : make_ushort4(0, 0, 0, 0);
+                }
+                // All of these are needed right away, so wait for them here, explicitly: otherwise the loads only
+                // used by the COMP block stay "possibly in flight" for the compiler on the path that skips it, and
+                // the trial code gets vmcnt(0) waits that in fact wait for this block's global STORES to land.
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                // K0a: system scale, summed strictly in reference order (assemble/mod.rs:32-44, utils.rs:11-33)
+                scale = 1.0;
+                scale_recip = 1.0;
+                if (prm.mode & 1u) {
+                    double sum = 0.0;
+                    uint32_t count = nvt;
+                    for_vars([&](uint32_t i, double v, uint32_t) {
+                        seq_add(sum, i < nvt ? v * v : 0.0);  // lanes past the end add +0.0: exact
+                    });
+                    for_exprs([&](uint32_t i, int tag, double d, uint32_t, ushort4) {
+                        const bool isd = i < net && ((tag == FX_TAG_PPD) || (tag == FX_TAG_PLD));
+                        count += (uint32_t)__popc(gballot(isd));
+                        seq_add(sum, isd ? d * d : 0.0);
+                    });
+                    scale = ::sqrt(sum / (double)count);
+                    scale_recip = 1.0 / scale;
+                }
+                for_vars([&](uint32_t i, double v, uint32_t) {
+                    if (i < nvt) {
+                        XS[i] = (T)((prm.mode & 1u) ? v * scale_recip : v);
+                        VOUT[i] = v;
+                        b.vars[v0 + i] = v;  // fixed / unconstrained variables stay bit-identical
+                    }
+                });
+                group_sync();
+                rng = 42u;  // one Rng::from_seed(42) per solve, shared by the components (assemble/mod.rs:47)
+                tot_accept = 0;
+                tot_trials = 0;
+                last_exit = FX_EXIT_SSE;
+                comps_done = 0;
+                tot_sse0 = 0.0;
+                tot_sse = 0.0;
+                c = 0;
+                phase = GP_COMP;
+            }
+            stamp(GH_SETUP);
+        }
+
+        // ================= COMP: set up component c, or close the System =================
+        if (phase == GP_COMP) {
+            if (c >= ncomp) {
+                // post-solve check on unscaled variables (constraints/mod.rs:96-109)
+                double part[4] = {0.0, 0.0, 0.0, 0.0};
+                for_exprs([&](uint32_t i, int tag, double param, uint32_t, ushort4 f4) {
+                    if (i < net) {
+                        uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+                        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        expand_vars(tag, ff, vars8);
+                        double v[8], g[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
+                        const double r = eval_expression<double, false>(tag, v, param, g);
+                        const double r2 = r * r;
+                        const uint32_t blk = (i >> 4) & 3u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : 0.0;
+                    }
+                });
+                const double sse_u = block_sum4(part);
+                if (hl == 0) {
+                    fx_result res;
+                    res.accepted = tot_accept;
+                    res.trials = tot_trials;
+                    res.exit = last_exit;
+                    res.ncomp = comps_done;
+                    res.scale = scale;
+                    res.sse0 = tot_sse0;
+                    res.sse = tot_sse;
+                    res.sse_unscaled = sse_u;
+                    b.results[s] = res;
+                }
+                group_sync();
+                phase = GP_NEXT;
+                stamp(GH_SETUP);
+            } else {
+                const bool reuse = b.uniform != 0u && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
+                if (reuse) {
+                    // same structure as the System before: perturb and re-scale the parameters, nothing else
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) {
+                        const uint32_t i = (uint32_t)(RS * k + hl);
+                        if (c_col[k] >= 0 && (prm.mode & 2u)) {
+                            uint32_t st = lcg_jump(rng, 2u * (uint32_t)c_col[k]);
+                            st = st * 1664525u + 1013904223u;
+                            const double f1 = (1.0 / 4294967295.0) * (double)st;
+                            st = st * 1664525u + 1013904223u;
+                            const double f2 = (1.0 / 4294967295.0) * (double)st;
+                            double x = (prm.mode & 1u) ? c_var[k] * scale_recip : c_var[k];
+                            x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                            XS[i] = (T)x;
+                        }
+                        if (c_row[k] >= 0) {
+                            const int tag = (int)c_tag[k];
+                            double prm_e = c_param[k];
+                            if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                            P[c_row[k]] = (T)prm_e;
+                        }
+                    }
+                    if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
+                    group_sync();
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        xstart[q] = ((uint32_t)(hl + RS * q) < nfree) ? XS[my_vi[q]] : T(0);
+                        xc[q] = xstart[q];
+                    }
+                }
+                bool have_comp = reuse;
+                if (!reuse) {
+                // free variables of the component, ascending (BTreeSet order, assemble/mod.rs:91-111)
+                // (perturbed where they are found — K0b: 2 LCG draws each, in that order)
+                nfree = 0;
+                bool any_var = false;
+                for_vars([&](uint32_t i, double v, uint32_t info) {
+                    const bool member = i < nvt && (info & VAR_COMP_MASK) == c;
+                    const bool in = member && !(info & VAR_FIXED_BIT);
+                    const uint32_t m = gballot(in);
+                    const uint32_t pos = nfree + (uint32_t)__popc(m & below);
+                    if (i < nvt) colof[i] = in ? (int16_t)pos : (int16_t)-1;
+                    if (in && pos < (uint32_t)N) fidx[pos] = (uint16_t)i;
+                    if (i < (uint32_t)(RS * PF)) {
+                        const int cc = in ? (int)pos : -1;
+                        if (i < (uint32_t)RS) c_col[0] = cc; else c_col[1] = cc;
+                    }
+                    if (in && (prm.mode & 2u)) {
+                        uint32_t st = lcg_jump(rng, 2u * pos);
+                        st = st * 1664525u + 1013904223u;
+                        const double f1 = (1.0 / 4294967295.0) * (double)st;
+                        st = st * 1664525u + 1013904223u;
+                        const double f2 = (1.0 / 4294967295.0) * (double)st;
+                        // from the f64 input, so the f64 start point is bit-identical to the reference
+                        double x = (prm.mode & 1u) ? v * scale_recip : v;
+                        x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                        XS[i] = (T)x;
+                    }
+                    nfree += (uint32_t)__popc(m);
+                    any_var = any_var || gballot(member) != 0u;
+                });
+                if (!any_var) {
+                    c += 1;  // a component without variables is skipped by the reference (`elements.is_empty()`)
+                } else {
+                    have_comp = true;
+                    built = true;
+                    if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
+                    group_sync();
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const uint32_t j = (uint32_t)(hl + RS * q);
+                        my_vi[q] = (j < nfree) ? (uint32_t)fidx[j] : 0u;
+                    }
+                    // rows of the component: ascending expression id (assemble/mod.rs:139-145)
+                    m_rows = 0;
+                    for_exprs([&](uint32_t i, int tag, double prm_e, uint32_t comp, ushort4 f4) {
+                        const bool in = (i < net) && (comp == c);
+                        const uint32_t mk = gballot(in);
+                        const uint32_t pos = m_rows + (uint32_t)__popc(mk & below);
+                        if (i < (uint32_t)(RS * PF)) {
+                            const int rr = in ? (int)pos : -1;
+                            if (i < (uint32_t)RS) c_row[0] = rr; else c_row[1] = rr;
+                        }
+                        if (in) {
+                            uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+                            uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            const int k = expand_vars(tag, ff, vars8);
+                            if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                            rtag[pos] = (uint8_t)tag;
+                            P[pos] = (T)prm_e;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                                gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
+                            }
+                        }
+                        m_rows += (uint32_t)__popc(mk);
+                    });
+                    group_sync();
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        xstart[q] = ((uint32_t)(hl + RS * q) < nfree) ? XS[my_vi[q]] : T(0);
+                        xc[q] = xstart[q];
+                    }
+                    // packed work lists: one u32 per product g_a g_b (a <= b, both columns free) of the lower
+                    // triangle, one u16 per g r of the right-hand side. Two entries of a row on one column
+                    // (an expression reading a variable twice) add their cross product twice, as the full
+                    // symmetric assembly does.
+                    n_pw = 0;
+                    n_pe = 0;
+                    for (uint32_t at = 0; at < m_rows; at += RS) {
+                        const uint32_t row = at + (uint32_t)hl;
+                        uint32_t mask = 0;
+                        uint64_t cols = 0;
+                        if (row < m_rows) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int cc = gcol[row * 8 + e];
+                                mask |= (cc >= 0) ? (1u << e) : 0u;
+                                cols |= (uint64_t)(uint8_t)cc << (8 * e);
+                            }
+                        }
+                        const uint32_t kf = (uint32_t)__popc(mask);
+                        uint32_t np = kf * (kf + 1u) / 2u;
+                        for (uint32_t m1 = mask; m1; m1 &= m1 - 1u) {
+                            const uint32_t a = (uint32_t)__ffs(m1) - 1u;
+                            for (uint32_t m2 = m1 & (m1 - 1u); m2; m2 &= m2 - 1u) {
+                                const uint32_t bb = (uint32_t)__ffs(m2) - 1u;
+                                np += (((cols >> (8u * a)) ^ (cols >> (8u * bb))) & 0xFFu) == 0u;
+                            }
+                        }
+                        uint32_t inc2 = np, inc1 = kf;
+#pragma unroll
+                        for (int off = 1; off < RS; off <<= 1) {
+                            const uint32_t t2 = (uint32_t)__shfl_up((int)inc2, off, RS), t1 = (uint32_t)__shfl_up((int)inc1, off, RS);
+                            if (hl >= off) {
+                                inc2 += t2;
+                                inc1 += t1;
+                            }
+                        }
+                        uint32_t at2 = n_pw + inc2 - np, at1 = n_pe + inc1 - kf;
+                        if (at2 + np <= L.pw_cap && at1 + kf <= L.pe_cap) {
+                            for (uint32_t m1 = mask; m1; m1 &= m1 - 1u) {
+                                const uint32_t a = (uint32_t)__ffs(m1) - 1u;
+                                const uint32_t ca = (uint32_t)(cols >> (8u * a)) & 0xFFu;
+                                PE[at1++] = (uint16_t)((row << (3 + CB)) | (a << CB) | ca);
+                                for (uint32_t m2 = m1; m2; m2 &= m2 - 1u) {
+                                    const uint32_t bb = (uint32_t)__ffs(m2) - 1u;
+                                    const uint32_t cb = (uint32_t)(cols >> (8u * bb)) & 0xFFu;
+                                    const uint32_t hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca;
+                                    const uint32_t w = (row << 19) | (a << 16) | (bb << 13) | tri_at(hi, lo);
+                                    PW[at2++] = w;
+                                    if (a != bb && ca == cb) PW[at2++] = w;
+                                }
+                            }
+                        }
+                        n_pw += (uint32_t)__shfl((int)inc2, RS - 1, RS);
+                        n_pe += (uint32_t)__shfl((int)inc1, RS - 1, RS);
+                    }
+                    group_sync();
+                }
+                }  // !reuse
+                if (have_comp) {
+                    stamp(GH_SETUP);
+                    // the start point is evaluated and assembled by the RUN block (one copy of that code)
+                    lambda = o.lambda0;
+                    accepted = 0;
+                    trials = 0;
+                    outer = 0;
+                    exit_code = FX_EXIT_MAX_OUTER;
+                    fresh = true;
+                    phase = GP_RUN;
+                    if (n_pw > L.pw_cap || n_pe > L.pe_cap) {  // the host sizes the lists; never expected
+                        sse = sse_start = T(0);
+                        exit_code = FX_EXIT_NAN;
+                        phase = GP_FINISH;
+                    }
+                }
+            }
+        }
+
+        // ================= RUN: one lambda trial (lm.rs:115-191) =================
+        if (phase == GP_RUN) {
+            stamp(GH_TAIL);
+            bool go = true;
+            T delta[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) delta[q] = T(0);
+            if (!fresh) {
+                if (trials >= o.max_trials) {
+                    exit_code = FX_EXIT_TRIAL_CAP;
+                    phase = GP_FINISH;
+                    go = false;
+                }
+                if (go) {
+                    trials += 1;
+                    // K4: factor (JtJ + lambda I) and solve for delta; columns hl and hl + 16 of the symmetric
+                    // matrix from the triangle (the lane id goes through an opaque move so that the addresses are
+                    // recomputed per trial instead of being hoisted out of the loop into dozens of long-lived
+                    // registers)
+                    int hv = hl;
+                    asm volatile("" : "+v"(hv));
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) At[tri_at((uint32_t)(hv + RS * q), (uint32_t)(hv + RS * q))] = diag[q] + (T)lambda;
+                    group_sync();
+                    T a[NC][N];
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        const int j = hv + RS * q;
+                        const uint32_t tj = (uint32_t)(j * (j + 1) / 2);
+#pragma unroll
+                        for (int i = 0; i < N; ++i) a[q][i] = At[(i <= j) ? tj + (uint32_t)i : (uint32_t)(i * (i + 1) / 2 + j)];
+                    }
+                    T invd[NC];
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) invd[q] = T(1);
+                    bool bad = false;
+                    RStep<NC, T, 0>::factor(a, invd, bad, hl);
+                    stamp(GH_FACTOR);
+                    if (bad) {  // lm.rs:134-137
+                        lambda *= o.singular_factor;
+                        go = false;
+                    } else {
+                        T acc[NC], invd2[NC];
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            acc[q] = rhs_l[q];
+                            invd2[q] = invd[q] * invd[q];
+                        }
+                        RStep<NC, T, 0>::forward(a, invd, acc, hl);
+                        RStep<NC, T, N - 1>::backward(a, invd2, acc, hl);
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) delta[q] = ((uint32_t)(hl + RS * q) < nfree) ? acc[q] * invd2[q] : T(0);
+                    }
+                }
+                if (go) {
+                    // |delta|^2 block by block of 16 columns, as wave_sum adds it
+                    T dn2 = row_sum(delta[0] * delta[0]);
+                    if constexpr (NC == 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
+                    if (!(dn2 == dn2)) {
+                        exit_code = FX_EXIT_NAN;
+                        phase = GP_FINISH;
+                        go = false;
+                    } else if (dn2 < (T)o.step_tol) {  // lm.rs:139-142
+                        exit_code = FX_EXIT_STEP;
+                        phase = GP_FINISH;
+                        go = false;
+                    }
+                    stamp(GH_SOLVE);
+                }
+                if (go) {
+                    // K2/K1 at the trial point (its rows become J on acceptance)
+#pragma unroll
+                    for (int q = 0; q < NC; ++q)
+                        if ((uint32_t)(hl + RS * q) < nfree) XS[my_vi[q]] = xc[q] + delta[q];
+                    group_sync();
+                }
+            }
+            if (go) {
+                const T sse_t = eval_rows();
+                stamp(GH_EVAL);
+                bool assemble = false;
+                if (fresh) {  // the component's start point
+                    sse = sse_t;
+                    sse_start = sse_t;
+                    assemble = true;
+                } else if (sse_t < sse) {  // accept, lm.rs:151-186
+                    lambda *= o.accept_factor;
+                    if (lambda < o.lambda_min) lambda = o.lambda_min;
+#pragma unroll
+                    for (int q = 0; q < NC; ++q)
+                        if ((uint32_t)(hl + RS * q) < nfree) xc[q] = xc[q] + delta[q];
+                    accepted += 1;
+                    const T rel = (sse - sse_t) / sse;
+                    sse = sse_t;  // the returned point's SSE (the reference leaves it stale, quirk Q9)
+                    if (rel <= (T)o.ftol) {
+                        exit_code = FX_EXIT_FTOL;
+                        phase = GP_FINISH;
+                    } else {
+                        assemble = true;
+                        outer += 1;
+                    }
+                } else {  // reject, lm.rs:187-190
+                    lambda *= o.reject_factor;
+                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
+                        exit_code = FX_EXIT_NAN;  // NaN trial point: the reference would double lambda forever
+                        phase = GP_FINISH;
+                    }
+                }
+                if (assemble) {
+                    form_normal();
+                    stamp(GH_FORM);
+                    // top of the next outer iteration (lm.rs:108-112)
+                    if (fresh && (!(sse == sse) || !(sse < Lim<T>::huge()))) {
+                        exit_code = FX_EXIT_NAN;
+                        phase = GP_FINISH;
+                    } else if (outer >= o.max_outer) {
+                        phase = GP_FINISH;  // exit_code is still FX_EXIT_MAX_OUTER
+                    } else if (sse < (T)o.sse_tol) {
+                        exit_code = FX_EXIT_SSE;
+                        phase = GP_FINISH;
+                    }
+                }
+                fresh = false;
+            }
+        }
+
+        // ================= FINISH: K6 write back scale * x for the free variables (assemble/mod.rs:161-166) ===
+        if (phase == GP_FINISH) {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                if ((uint32_t)(hl + RS * q) < nfree) {
+                    const double x = (double)xc[q];
+                    const double xo = (prm.mode & 1u) ? scale * x : x;
+                    b.vars[v0 + my_vi[q]] = xo;
+                    VOUT[my_vi[q]] = xo;
+                    // later components are solved against the PRE-solve snapshot (only `system.variables` is
+                    // written back, quirk Q2): the working vector goes back to the perturbed start value
+                    XS[my_vi[q]] = xstart[q];
+                }
+            }
+            group_sync();
+            tot_accept += accepted;
+            tot_trials += trials;
+            last_exit = exit_code;
+            tot_sse0 += (double)sse_start;
+            tot_sse += (double)sse;
+            comps_done += 1;
+            c += 1;
+            phase = GP_COMP;
+            stamp(GH_TAIL);
+        }
+
+        if (__ballot(phase != GP_EXIT) == 0ull) break;
+    }
+    if (PROF) {
+        stamp(GH_TAIL);
+        if (lane == 0 && prm.prof) {
+            for (int i = 0; i < GH_COUNT; ++i) atomicAdd(&prm.prof[i], ph[i]);
+        }
+    }
+}
+
+// The occupancy hint is part of the kernel's signature: the 32-column f64 build is LDS-bound to one wavefront
+// per SIMD anyway (4 x 10 KB per wavefront) and may use the registers that frees; the others run two.
+template <int NC, typename T, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_kernel_w1(
+    DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_body<NC, T, PROF>(b, prm, L, next_system, smem);
+}
+template <int NC, typename T, bool PROF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void lm_solve_grouped_kernel_w2(
+    DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_body<NC, T, PROF>(b, prm, L, next_system, smem);
+}
+
+// ------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------
+template <int NC, typename T, bool PROF = false>
+static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint32_t* counter, hipStream_t stream) {
+    const GroupLayout L = make_group_layout((uint32_t)(RS * NC), b.max_vars, b.max_rows, (uint32_t)sizeof(T), b.max_pairs_tri, b.max_ents);
+    constexpr uint32_t groups = 64u / (uint32_t)RS;
+    const uint32_t per_wave = groups * L.stride;
+    constexpr bool one_wave = (NC == 2 && sizeof(T) == 8);
+    const void* fn;
+    if constexpr (one_wave) fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w1<NC, T, PROF>);
+    else fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w2<NC, T, PROF>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    // enough wavefronts to fill the chip a few times over; every row keeps taking Systems until none is left
+    uint32_t waves = (b.n_systems + groups - 1u) / groups;
+    const uint32_t cap = 256u * 16u;
+    if (waves > cap) waves = cap;
+    if constexpr (one_wave) {
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+    } else {
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w2<NC, T, PROF>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+    }
+    return hipGetLastError();
+}
+
+static uint32_t grouped_columns(const DeviceBatch& b) { return b.max_free <= 16u ? 1u : 2u; }
+
+// LDS bytes per wavefront of the grouped kernel for this batch, 0 when the batch does not qualify
+size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t es) {
+    if (b.max_free == 0 || b.max_free > 32u || b.max_rows > 256u || b.max_vars > 4096u) return 0;
+    const GroupLayout L = make_group_layout(RS * grouped_columns(b), b.max_vars, b.max_rows, es, b.max_pairs_tri, b.max_ents);
+    return (size_t)(64u / (uint32_t)RS) * L.stride;
+}
+
+bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
+    // FIKSI_AMD_GROUPED=0 keeps every batch on the one-System-per-wavefront kernel, =1 sends every batch that
+    // qualifies here (tests, A/B measurements). By default a batch must be big enough to fill the chip four
+    // Systems per wavefront: below that one wavefront per System finishes sooner.
+    const char* sw = getenv("FIKSI_AMD_GROUPED");
+    if (sw && sw[0] == '0') return false;
+    const bool forced = sw && sw[0] == '1';
+    if (!forced && b.n_systems < 8192u) return false;
+    if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || p.lm.solver != FX_STEP_CHOLESKY) return false;
+    if (p.prof && p.lm.precision == 32) return false;
+    if (!b.work_counter) return false;
+    const size_t lds = grouped_lds_bytes(b, p.lm.precision == 32 ? 4u : 8u);
+    // four wavefronts (16 Systems) per CU or more
+    return lds != 0 && lds <= (160u * 1024u) / 4u;
+}
+
+hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (b.n_systems == 0) return hipSuccess;
+    const bool two = grouped_columns(b) == 2u;
+    if (p.prof) return two ? launch_grouped_t<2, double, true>(b, p, b.work_counter, stream)
+                           : launch_grouped_t<1, double, true>(b, p, b.work_counter, stream);
+    if (p.lm.precision == 32)
+        return two ? launch_grouped_t<2, float>(b, p, b.work_counter, stream) : launch_grouped_t<1, float>(b, p, b.work_counter, stream);
+    return two ? launch_grouped_t<2, double>(b, p, b.work_counter, stream) : launch_grouped_t<1, double>(b, p, b.work_counter, stream);
+}
+
+}  // namespace fx

@@ -1173,6 +1173,7 @@ static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStr
 
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
+    if (p.prof && grouped_applies(b, p)) return launch_solve_grouped(b, p, stream);
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);
         if (n != 32 || p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS))) return hipErrorInvalidValue;
@@ -1191,6 +1192,8 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
         if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);
         return e;
     }
+    // components of at most 32 free variables: several Systems per wavefront (fx_grouped.hip)
+    if (grouped_applies(b, p)) return launch_solve_grouped(b, p, stream);
     return p.lm.precision == 32 ? launch_solve_t<float, false, 0>(b, p, stream) : launch_solve_t<double, false, 0>(b, p, stream);
 }
 
