@@ -92,20 +92,24 @@ __device__ __forceinline__ float rbcast(float v) {
 // acc = fma(-(m's lane K of the row), w, acc) in one VOP2-DPP instruction (gfx90a+: 64-bit DPP takes row_newbcast)
 template <int K>
 __device__ __forceinline__ void fnma_rbcast(double& acc, double m, double w) {
-    asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
+    asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
 }
 template <int K>
 __device__ __forceinline__ void fnma_rbcast(float& acc, float m, float w) {
-    asm("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
+    asm volatile("v_fmac_f32_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "v"(w), "n"(K));
 }
+// two wait states between the VALU instruction that produced `v` and a DPP read of it (inline asm is opaque to the
+// compiler's hazard recogniser); the value passes through so that the order is a data dependence
+__device__ __forceinline__ void dpp_settle(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+__device__ __forceinline__ void dpp_settle(float& v) { asm volatile("s_nop 1" : "+v"(v)); }
 // the same with m == acc (the register is read through DPP before it is written)
 template <int K>
 __device__ __forceinline__ void fnma_rbcast_self(double& acc, double w) {
-    asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
+    asm volatile("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
 }
 template <int K>
 __device__ __forceinline__ void fnma_rbcast_self(float& acc, float w) {
-    asm("v_fmac_f32_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
+    asm volatile("v_fmac_f32_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "n"(K));
 }
 // sum over the 16 lanes of a row, identical bits in every lane: the DPP butterfly of wave_sum
 template <typename T>
@@ -170,21 +174,27 @@ struct RStep {
         asm volatile("s_nop 1");
         if constexpr (K + 1 < N) RStep<NC, T, K + 1>::factor(a, invd, bad, hl);
     }
+    // acc[q] -= a[q][K] * y_K, y_K = (acc * invd) of column K's lane: the broadcast is the DPP operand of the
+    // multiply-add; lanes that must not take part get a zero factor.
     static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl) {
-        const T yk = rbcast<KL>(acc[KA] * invd[KA]);
+        T t = acc[KA] * invd[KA];
+        dpp_settle(t);
 #pragma unroll
-        for (int q = KA; q < NC; ++q) {
+        for (int q = NC - 1; q >= KA; --q) {
             if (q == KA && KL == RS - 1) continue;
-            if (q > KA || hl > KL) acc[q] = fma(-a[q][K], yk, acc[q]);
+            const T w = (q > KA || hl > KL) ? a[q][K] : T(0);
+            fnma_rbcast<KL>(acc[q], t, w);
         }
         if constexpr (K + 1 < N) RStep<NC, T, K + 1>::forward(a, invd, acc, hl);
     }
     static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl) {
-        const T xi = rbcast<KL>(acc[KA] * invd2[KA]);
+        T t = acc[KA] * invd2[KA];
+        dpp_settle(t);
 #pragma unroll
         for (int q = 0; q <= KA; ++q) {
             if (q == KA && KL == 0) continue;  // no column of this array lies below K
-            if (q < KA || hl < KL) acc[q] = fma(-a[q][K], xi, acc[q]);
+            const T w = (q < KA || hl < KL) ? a[q][K] : T(0);
+            fnma_rbcast<KL>(acc[q], t, w);
         }
         if constexpr (K > 0) RStep<NC, T, K - 1>::backward(a, invd2, acc, hl);
     }
@@ -346,19 +356,57 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
     // K3: the lower triangle of Jt J and -Jt r from the packed lists (ds_add_f64 / ds_add_f32)
     auto form_normal = [&]() {
-        for (uint32_t i = hl; i < (uint32_t)(N * (N + 1) / 2); i += RS) At[i] = T(0);
+        {  // zero the triangle, 16 bytes per lane and instruction
+            using V = typename Vec16<T>::type;
+            constexpr uint32_t NV = (uint32_t)(N * (N + 1) / 2) / (uint32_t)Vec16<T>::n;
+            static_assert((N * (N + 1) / 2) % Vec16<T>::n == 0, "triangle is a whole number of 16-byte vectors");
+            V z;
+            for (int q = 0; q < Vec16<T>::n; ++q) reinterpret_cast<T*>(&z)[q] = T(0);
+            for (uint32_t i = hl; i < NV; i += RS) reinterpret_cast<V*>(At)[i] = z;
+        }
 #pragma unroll
         for (int q = 0; q < NC; ++q) rhsv[hl + RS * q] = T(0);
         group_sync();
-        for (uint32_t t = hl; t < n_pw; t += RS) {
-            const uint32_t w = PW[t];
-            const uint32_t gb = (w >> 19) * 8u;
-            lds_add(&At[w & 0x1FFFu], G[gb + ((w >> 16) & 7u)] * G[gb + ((w >> 13) & 7u)]);
+        // four products per lane at a time: their list words first, then their eight factors, then the four atomics
+        // (three LDS round trips per batch instead of three per product)
+        constexpr int U = 4;
+        for (uint32_t t0 = 0; t0 < n_pw; t0 += RS * U) {
+            uint32_t w[U];
+            T g1[U], g2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t t = t0 + (uint32_t)(u * RS + hl);
+                w[u] = (t < n_pw) ? PW[t] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ww = (w[u] == 0xFFFFFFFFu) ? 0u : w[u];
+                const uint32_t gb = (ww >> 19) * 8u;
+                g1[u] = G[gb + ((ww >> 16) & 7u)];
+                g2[u] = G[gb + ((ww >> 13) & 7u)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (w[u] != 0xFFFFFFFFu) lds_add(&At[w[u] & 0x1FFFu], g1[u] * g2[u]);
         }
-        for (uint32_t t = hl; t < n_pe; t += RS) {
-            const uint32_t w = PE[t];
-            const uint32_t row = w >> (3 + CB);
-            lds_add(&rhsv[w & (uint32_t)(N - 1)], G[row * 8u + ((w >> CB) & 7u)] * -R[row]);
+        for (uint32_t t0 = 0; t0 < n_pe; t0 += RS * U) {
+            uint32_t w[U];
+            T g1[U], rr[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t t = t0 + (uint32_t)(u * RS + hl);
+                w[u] = (t < n_pe) ? (uint32_t)PE[t] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t ww = (w[u] == 0xFFFFFFFFu) ? 0u : w[u];
+                const uint32_t row = ww >> (3 + CB);
+                g1[u] = G[row * 8u + ((ww >> CB) & 7u)];
+                rr[u] = -R[row];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (w[u] != 0xFFFFFFFFu) lds_add(&rhsv[w[u] & (uint32_t)(N - 1)], g1[u] * rr[u]);
         }
         group_sync();
 #pragma unroll
