@@ -202,13 +202,16 @@ def main() -> int:
                 "launches": k1_launches,
             },
             "solve_kernel": {
-                "kernel": "lm_solve_kernel<32> (fused scale+perturb+assembly+LM+write-back, one wavefront per system)",
+                "kernel": ("lm_solve_grouped_kernel<2 columns per lane, f64> (fused scale+perturb+assembly+LM+write-back, four "
+                           "Systems per wavefront: one per DPP row, fx_grouped.hip)") if db.solve_route() == 1 else
+                          "lm_solve_kernel<32> (fused scale+perturb+assembly+LM+write-back, one wavefront per system)",
                 "avg_launch_ms": solve_ms,
                 "algorithmic_hbm_bytes_per_launch": b_solve,
                 "achieved_GBps": b_solve / (solve_ms * 1e-3) / 1e9,
                 "frac_of_hbm_peak": b_solve / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "latency/f64-VALU bound by construction (~14 kflop per LM trial on a serial "
-                        "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d)",
+                        "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d). "
+                        "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead",
             },
         }
         if world == 1:

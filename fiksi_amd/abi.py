@@ -278,6 +278,13 @@ class DeviceBatch:
         check(lib.fx_debug_phase_cycles(self.ctx.handle, self._h, C.byref(o), c), "fx_debug_phase_cycles")
         return dict(zip(("setup", "eval", "form", "factor", "solve", "tail"), [int(x) for x in c]))
 
+    def solve_route(self, opts=None) -> int:
+        """0: one System per wavefront, 1: the grouped kernel (diagnostic; launches nothing)."""
+        o = opts if opts is not None else solving_opts()
+        r = C.c_int(0)
+        check(lib.fx_debug_solve_route(self.ctx.handle, self._h, C.byref(o), C.byref(r)), "fx_debug_solve_route")
+        return int(r.value)
+
     def eval_residual_jacobian(self, which: int = 0):
         check(lib.fx_eval_residual_jacobian_device(self.ctx.handle, self._h, which), "fx_eval_residual_jacobian_device")
 

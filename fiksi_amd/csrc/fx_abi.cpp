@@ -1270,6 +1270,19 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     return solve_large_systems(ctx, db, p);
 }
 
+int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* route) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !route) return fail(FX_ERR_INVALID, "bad argument");
+    fx_solving_opts o;
+    if (opts) o = *opts; else fx_solving_opts_default(&o);
+    fx::LmParams p;
+    p.lm = o.lm;
+    p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
+    *route = fx::grouped_applies(db->d, p) ? 1 : 0;
+    return FX_OK;
+}
+
 // Diagnostic (not part of the drop-in surface): runs the stamped build of the fused kernel once and
 // returns the shader cycles summed over all wavefronts for {setup, eval, form, factor, solve, tail}.
 int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, uint64_t cycles[6]) {

@@ -234,8 +234,13 @@ int fx_timer_begin(fx_ctx* ctx);
 int fx_timer_end(fx_ctx* ctx, float* milliseconds);
 
 /* Diagnostic only: shader cycles per phase {setup, eval, form, factor, solve, tail}, summed over all
- * wavefronts, from a stamped build of the fused kernel (32-free-variable shape only). */
+ * wavefronts, from a stamped build of the fused kernel (32-free-variable shape only). For a batch the
+ * grouped kernel takes, the sums are lane 0's: the first System row's view of its wavefront's time. */
 int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, uint64_t cycles[6]);
+/* Diagnostic only: which kernel fx_system_solve_device would launch for the Systems of up to 64 free
+ * variables of this batch with these options: 0 = lm_solve_kernel (one System per wavefront),
+ * 1 = the grouped kernel (four Systems per wavefront, fx_grouped.hip). Launches nothing. */
+int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* route);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */
 /* == assemble::solve: batch->vars in: unscaled values, out: solved values. results may be NULL. */
