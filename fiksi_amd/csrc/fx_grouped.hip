@@ -280,6 +280,16 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     double lambda = 0.0;
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
     bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
+    // The product list of a component does not change between its assemblies: the 32-column f64 build (one wavefront
+    // per SIMD, registers to spare) keeps each lane's first PWR / PER list words in registers, which takes the list
+    // read — one of three dependent LDS round trips per batch of products — out of every assembly.
+    constexpr int PWR = (NC == 2 && sizeof(T) == 8) ? 28 : 0;
+    constexpr int PER = (NC == 2 && sizeof(T) == 8) ? 10 : 0;
+    uint32_t pw_reg[PWR > 0 ? PWR : 1], pe_reg[PER > 0 ? PER : 1];
+#pragma unroll
+    for (int u = 0; u < (PWR > 0 ? PWR : 1); ++u) pw_reg[u] = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < (PER > 0 ? PER : 1); ++u) pe_reg[u] = 0xFFFFFFFFu;
     // Batches whose Systems all have the same structure (one sketch, many parameter sets): the row lists, the
     // product lists and the free-variable map of a single-component System are built for the first System a row
     // takes and kept for the following ones — only values change. Per lane: the column of variable hl + 16 k and
@@ -367,10 +377,40 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 #pragma unroll
         for (int q = 0; q < NC; ++q) rhsv[hl + RS * q] = T(0);
         group_sync();
-        // four products per lane at a time: their list words first, then their eight factors, then the four atomics
-        // (three LDS round trips per batch instead of three per product)
         constexpr int U = 4;
-        for (uint32_t t0 = 0; t0 < n_pw; t0 += RS * U) {
+        if constexpr (PWR > 0) {  // the list words held in registers: seven products' factors in flight at a time
+            constexpr int UB = 7;
+#pragma unroll
+            for (int u0 = 0; u0 < PWR; u0 += UB) {
+                T g1[UB], g2[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const uint32_t ww = (pw_reg[u0 + u] == 0xFFFFFFFFu) ? 0u : pw_reg[u0 + u];
+                    const uint32_t gb = (ww >> 19) * 8u;
+                    g1[u] = G[gb + ((ww >> 16) & 7u)];
+                    g2[u] = G[gb + ((ww >> 13) & 7u)];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u)
+                    if (pw_reg[u0 + u] != 0xFFFFFFFFu) lds_add(&At[pw_reg[u0 + u] & 0x1FFFu], g1[u] * g2[u]);
+            }
+            {
+                T g1[PER], rr[PER];
+#pragma unroll
+                for (int u = 0; u < PER; ++u) {
+                    const uint32_t ww = (pe_reg[u] == 0xFFFFFFFFu) ? 0u : pe_reg[u];
+                    const uint32_t row = ww >> (3 + CB);
+                    g1[u] = G[row * 8u + ((ww >> CB) & 7u)];
+                    rr[u] = -R[row];
+                }
+#pragma unroll
+                for (int u = 0; u < PER; ++u)
+                    if (pe_reg[u] != 0xFFFFFFFFu) lds_add(&rhsv[pe_reg[u] & (uint32_t)(N - 1)], g1[u] * rr[u]);
+            }
+        }
+        // the rest of the lists (all of them in the other builds) from LDS, four products per lane at a time: their
+        // list words first, then their eight factors, then the four atomics (three LDS round trips per batch)
+        for (uint32_t t0 = (uint32_t)(RS * PWR); t0 < n_pw; t0 += RS * U) {
             uint32_t w[U];
             T g1[U], g2[U];
 #pragma unroll
@@ -389,7 +429,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             for (int u = 0; u < U; ++u)
                 if (w[u] != 0xFFFFFFFFu) lds_add(&At[w[u] & 0x1FFFu], g1[u] * g2[u]);
         }
-        for (uint32_t t0 = 0; t0 < n_pe; t0 += RS * U) {
+        for (uint32_t t0 = (uint32_t)(RS * PER); t0 < n_pe; t0 += RS * U) {
             uint32_t w[U];
             T g1[U], rr[U];
 #pragma unroll
@@ -693,6 +733,18 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         n_pe += (uint32_t)__shfl((int)inc1, RS - 1, RS);
                     }
                     group_sync();
+                    if constexpr (PWR > 0) {
+#pragma unroll
+                        for (int u = 0; u < PWR; ++u) {
+                            const uint32_t t = (uint32_t)(u * RS + hl);
+                            pw_reg[u] = (t < n_pw && t < L.pw_cap) ? PW[t] : 0xFFFFFFFFu;
+                        }
+#pragma unroll
+                        for (int u = 0; u < PER; ++u) {
+                            const uint32_t t = (uint32_t)(u * RS + hl);
+                            pe_reg[u] = (t < n_pe && t < L.pe_cap) ? (uint32_t)PE[t] : 0xFFFFFFFFu;
+                        }
+                    }
                 }
                 }  // !reuse
                 if (have_comp) {
