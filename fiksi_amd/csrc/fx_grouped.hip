@@ -80,10 +80,9 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
 // lane K of the caller's row of 16 (DPP row_newbcast; the lane is an instruction immediate)
 template <int K>
 __device__ __forceinline__ double rbcast(double v) {
-    // (mov_dpp: every source lane of a row broadcast is valid, so no `old` value has to be set up first)
-    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + K, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + K, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
+    // one v_mov_b64_dpp (gfx90a+: 64-bit DPP exists for row_newbcast); mov_dpp, not update_dpp: every source lane of
+    // a row broadcast is valid, so no `old` value has to be set up first
+    return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + K, 0xF, 0xF, false));
 }
 template <int K>
 __device__ __forceinline__ float rbcast(float v) {
@@ -160,41 +159,74 @@ struct RStep {
         // a[q][i] -= A_iK (from the lane of column K, which still holds A_iK = L_iK * d_K) * mul[q]: ONE instruction
         // each, v_fmac_f64_dpp with the broadcast as its DPP operand. Array KA last: its update leaves the lane of
         // column K untouched (mul = 0 there), and so no DPP read follows a write of the same register.
+        if constexpr (NC <= 2) {
 #pragma unroll
-        for (int i = K + 1; i < N; ++i) {
+            for (int i = K + 1; i < N; ++i) {
 #pragma unroll
-            for (int q = NC - 1; q >= KA; --q) {
-                if (q == KA && KL == RS - 1) continue;  // no column of this array lies above K
-                if (q == KA) fnma_rbcast_self<KL>(a[q][i], mul[q]);
-                else fnma_rbcast<KL>(a[q][i], a[KA][i], mul[q]);
+                for (int q = NC - 1; q >= KA; --q) {
+                    if (q == KA && KL == RS - 1) continue;  // no column of this array lies above K
+                    if (q == KA) fnma_rbcast_self<KL>(a[q][i], mul[q]);
+                    else fnma_rbcast<KL>(a[q][i], a[KA][i], mul[q]);
+                }
+            }
+            // (inline asm is opaque to the hazard recogniser: a DPP read needs two wait states after a VALU write of
+            // its source, and the next pivot broadcast may read what the last instruction above wrote)
+            asm volatile("s_nop 1");
+        } else {
+            // the 48-column build lives at the register limit, where the compiler has to reload operands right in
+            // front of their use — a VALU write the hand-written DPP read could not be protected from. It takes the
+            // compiler's own instructions: one v_mov_b64_dpp per broadcast, shared by the three multiply-adds.
+#pragma unroll
+            for (int i = K + 1; i < N; ++i) {
+                const T aik = rbcast<KL>(a[KA][i]);
+#pragma unroll
+                for (int q = KA; q < NC; ++q) {
+                    if (q == KA && KL == RS - 1) continue;
+                    a[q][i] = fma(-aik, mul[q], a[q][i]);
+                }
             }
         }
-        // (inline asm is opaque to the hazard recogniser: a DPP read needs two wait states after a VALU write of its
-        // source, and the next pivot broadcast may read what the last instruction above wrote)
-        asm volatile("s_nop 1");
         if constexpr (K + 1 < N) RStep<NC, T, K + 1>::factor(a, invd, bad, hl);
     }
     // acc[q] -= a[q][K] * y_K, y_K = (acc * invd) of column K's lane: the broadcast is the DPP operand of the
     // multiply-add; lanes that must not take part get a zero factor.
     static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl) {
         T t = acc[KA] * invd[KA];
-        dpp_settle(t);
+        if constexpr (NC <= 2) {
+            dpp_settle(t);
 #pragma unroll
-        for (int q = NC - 1; q >= KA; --q) {
-            if (q == KA && KL == RS - 1) continue;
-            const T w = (q > KA || hl > KL) ? a[q][K] : T(0);
-            fnma_rbcast<KL>(acc[q], t, w);
+            for (int q = NC - 1; q >= KA; --q) {
+                if (q == KA && KL == RS - 1) continue;
+                const T w = (q > KA || hl > KL) ? a[q][K] : T(0);
+                fnma_rbcast<KL>(acc[q], t, w);
+            }
+        } else {
+            const T yk = rbcast<KL>(t);
+#pragma unroll
+            for (int q = KA; q < NC; ++q) {
+                if (q == KA && KL == RS - 1) continue;
+                if (q > KA || hl > KL) acc[q] = fma(-a[q][K], yk, acc[q]);
+            }
         }
         if constexpr (K + 1 < N) RStep<NC, T, K + 1>::forward(a, invd, acc, hl);
     }
     static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl) {
         T t = acc[KA] * invd2[KA];
-        dpp_settle(t);
+        if constexpr (NC <= 2) {
+            dpp_settle(t);
 #pragma unroll
-        for (int q = 0; q <= KA; ++q) {
-            if (q == KA && KL == 0) continue;  // no column of this array lies below K
-            const T w = (q < KA || hl < KL) ? a[q][K] : T(0);
-            fnma_rbcast<KL>(acc[q], t, w);
+            for (int q = 0; q <= KA; ++q) {
+                if (q == KA && KL == 0) continue;  // no column of this array lies below K
+                const T w = (q < KA || hl < KL) ? a[q][K] : T(0);
+                fnma_rbcast<KL>(acc[q], t, w);
+            }
+        } else {
+            const T xi = rbcast<KL>(t);
+#pragma unroll
+            for (int q = 0; q <= KA; ++q) {
+                if (q == KA && KL == 0) continue;
+                if (q < KA || hl < KL) acc[q] = fma(-a[q][K], xi, acc[q]);
+            }
         }
         if constexpr (K > 0) RStep<NC, T, K - 1>::backward(a, invd2, acc, hl);
     }
@@ -232,7 +264,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
     if (PROF) t_last = __builtin_amdgcn_s_memtime();
     constexpr int N = RS * NC;
-    constexpr int CB = (NC == 2) ? 5 : 4;  // column bits of a packed entry
+    constexpr int CB = (NC == 1) ? 4 : (NC == 2) ? 5 : 6;  // column bits of a packed entry
+    constexpr uint32_t CMASK = (1u << CB) - 1u;
     const int lane = threadIdx.x;
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
@@ -295,12 +328,12 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     // takes and kept for the following ones — only values change. Per lane: the column of variable hl + 16 k and
     // the row of expression hl + 16 k (or -1).
     bool built = false;
-    int c_col[2] = {-1, -1}, c_row[2] = {-1, -1};
+    int c_col[3] = {-1, -1, -1}, c_row[3] = {-1, -1, -1};
 
     // The System's own arrays, fetched in one round trip when the row takes the System: lane r keeps
     // elements r and r + 16 of every per-variable / per-expression array (all of them for the headline
     // shape); elements past 32 are loaded where they are used.
-    constexpr int PF = 2;  // (the selects in for_vars / for_exprs are written for two chunks)
+    constexpr int PF = NC >= 3 ? 3 : 2;  // chunks of 16 kept in registers (the selects below pick among up to three)
     double c_var[PF], c_param[PF];
     uint32_t c_info[PF], c_tag[PF], c_comp[PF];
     ushort4 c_idx[PF];
@@ -313,12 +346,17 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     // f(i, value, info) over all variables / f(i, tag, param, comp, idx) over all expressions of the System,
     // 16 at a time in ascending order; i may lie past the end (then the other arguments are zero / 0xFFFF)
     // (one dynamic loop each, the cached chunks picked by selects: one copy of every loop body in the code)
+    auto pick = [&](uint32_t at, const auto& arr) {
+        auto r = arr[PF - 1];
+        if constexpr (PF >= 3) r = (at == (uint32_t)RS) ? arr[1] : r;
+        return (at == 0u) ? arr[0] : r;
+    };
     auto for_vars = [&](auto&& f) {
 #pragma unroll 1
         for (uint32_t at = 0; at < nvt; at += RS) {
             const uint32_t i = at + (uint32_t)hl;
-            double v = (at == 0) ? c_var[0] : c_var[1];
-            uint32_t info = (at == 0) ? c_info[0] : c_info[1];
+            double v = pick(at, c_var);
+            uint32_t info = pick(at, c_info);
             if (at >= (uint32_t)(RS * PF)) {
                 const bool have = i < nvt;
                 v = have ? b.vars0[v0 + i] : 0.0;
@@ -331,10 +369,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 #pragma unroll 1
         for (uint32_t at = 0; at < net; at += RS) {
             const uint32_t i = at + (uint32_t)hl;
-            int tag = (int)((at == 0) ? c_tag[0] : c_tag[1]);
-            double param = (at == 0) ? c_param[0] : c_param[1];
-            uint32_t comp = (at == 0) ? c_comp[0] : c_comp[1];
-            ushort4 idx = (at == 0) ? c_idx[0] : c_idx[1];
+            int tag = (int)pick(at, c_tag);
+            double param = pick(at, c_param);
+            uint32_t comp = pick(at, c_comp);
+            ushort4 idx = pick(at, c_idx);
             if (at >= (uint32_t)(RS * PF)) {
                 const bool have = i < net;
                 tag = have ? (int)(b.expr_tag[e0 + i] & 0x7F) : 0;
@@ -405,7 +443,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 }
 #pragma unroll
                 for (int u = 0; u < PER; ++u)
-                    if (pe_reg[u] != 0xFFFFFFFFu) lds_add(&rhsv[pe_reg[u] & (uint32_t)(N - 1)], g1[u] * rr[u]);
+                    if (pe_reg[u] != 0xFFFFFFFFu) lds_add(&rhsv[pe_reg[u] & CMASK], g1[u] * rr[u]);
             }
         }
         // the rest of the lists (all of them in the other builds) from LDS, four products per lane at a time: their
@@ -446,7 +484,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (w[u] != 0xFFFFFFFFu) lds_add(&rhsv[w[u] & (uint32_t)(N - 1)], g1[u] * rr[u]);
+                if (w[u] != 0xFFFFFFFFu) lds_add(&rhsv[w[u] & CMASK], g1[u] * rr[u]);
         }
         group_sync();
 #pragma unroll
@@ -618,7 +656,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     if (in && pos < (uint32_t)N) fidx[pos] = (uint16_t)i;
                     if (i < (uint32_t)(RS * PF)) {
                         const int cc = in ? (int)pos : -1;
-                        if (i < (uint32_t)RS) c_col[0] = cc; else c_col[1] = cc;
+                        if (i < (uint32_t)RS) c_col[0] = cc; else if (i < 2u * RS) c_col[1] = cc; else c_col[2] = cc;
                     }
                     if (in && (prm.mode & 2u)) {
                         uint32_t st = lcg_jump(rng, 2u * pos);
@@ -654,7 +692,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         const uint32_t pos = m_rows + (uint32_t)__popc(mk & below);
                         if (i < (uint32_t)(RS * PF)) {
                             const int rr = in ? (int)pos : -1;
-                            if (i < (uint32_t)RS) c_row[0] = rr; else c_row[1] = rr;
+                            if (i < (uint32_t)RS) c_row[0] = rr; else if (i < 2u * RS) c_row[1] = rr; else c_row[2] = rr;
                         }
                         if (in) {
                             uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
@@ -823,7 +861,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 if (go) {
                     // |delta|^2 block by block of 16 columns, as wave_sum adds it
                     T dn2 = row_sum(delta[0] * delta[0]);
-                    if constexpr (NC == 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
+                    if constexpr (NC >= 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
+                    if constexpr (NC >= 3) dn2 = dn2 + row_sum(delta[2] * delta[2]);
                     if (!(dn2 == dn2)) {
                         exit_code = FX_EXIT_NAN;
                         phase = GP_FINISH;
@@ -951,7 +990,7 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     const GroupLayout L = make_group_layout((uint32_t)(RS * NC), b.max_vars, b.max_rows, (uint32_t)sizeof(T), b.max_pairs_tri, b.max_ents);
     constexpr uint32_t groups = 64u / (uint32_t)RS;
     const uint32_t per_wave = groups * L.stride;
-    constexpr bool one_wave = (NC == 2 && sizeof(T) == 8);
+    constexpr bool one_wave = (NC >= 2 && sizeof(T) == 8);
     const void* fn;
     if constexpr (one_wave) fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w1<NC, T, PROF>);
     else fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w2<NC, T, PROF>);
@@ -971,11 +1010,12 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     return hipGetLastError();
 }
 
-static uint32_t grouped_columns(const DeviceBatch& b) { return b.max_free <= 16u ? 1u : 2u; }
+static uint32_t grouped_columns(const DeviceBatch& b) { return b.max_free <= 16u ? 1u : b.max_free <= 32u ? 2u : 3u; }
 
 // LDS bytes per wavefront of the grouped kernel for this batch, 0 when the batch does not qualify
 size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t es) {
-    if (b.max_free == 0 || b.max_free > 32u || b.max_rows > 256u || b.max_vars > 4096u) return 0;
+    if (b.max_free == 0 || b.max_free > 48u || b.max_rows > 256u || b.max_vars > 4096u) return 0;
+    if (b.max_free > 32u && b.max_rows > 128u) return 0;  // 7 row bits in a packed right-hand-side entry of the 48-column build
     const GroupLayout L = make_group_layout(RS * grouped_columns(b), b.max_vars, b.max_rows, es, b.max_pairs_tri, b.max_ents);
     return (size_t)(64u / (uint32_t)RS) * L.stride;
 }
@@ -990,15 +1030,19 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     if (!forced && b.n_systems < 8192u) return false;
     if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     if (p.prof && p.lm.precision == 32) return false;
+    if (grouped_columns(b) == 3u && (p.prof || p.lm.precision == 32)) return false;
     if (!b.work_counter) return false;
     const size_t lds = grouped_lds_bytes(b, p.lm.precision == 32 ? 4u : 8u);
-    // four wavefronts (16 Systems) per CU or more
-    return lds != 0 && lds <= (160u * 1024u) / 4u;
+    // four wavefronts (16 Systems) per CU or more; two (8 Systems) for the 48-column build, whose Systems would
+    // otherwise sit five to a CU, one per wavefront
+    return lds != 0 && lds <= (160u * 1024u) / (grouped_columns(b) == 3u ? 2u : 4u);
 }
 
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
-    const bool two = grouped_columns(b) == 2u;
+    const uint32_t nc = grouped_columns(b);
+    const bool two = nc == 2u;
+    if (nc == 3u) return launch_grouped_t<3, double>(b, p, b.work_counter, stream);  // f64, no stamped build
     if (p.prof) return two ? launch_grouped_t<2, double, true>(b, p, b.work_counter, stream)
                            : launch_grouped_t<1, double, true>(b, p, b.work_counter, stream);
     if (p.lm.precision == 32)

@@ -57,6 +57,31 @@ def test_bit_identical_to_the_one_system_per_wavefront_kernel(fiksi, ctx, routin
         assert np.array_equal(_bits(a), _bits(c)) if a.dtype.kind == "f" else np.array_equal(a, c), f
 
 
+@pytest.mark.parametrize("n_tri", [8, 10, 11])
+def test_forty_eight_column_build_on_the_references_bench_sketch(fiksi, oracle, ctx, routing, n_tri):
+    """Chains of hinged triangles (`add_hinged_triangles`, fiksi_bench.rs:15-40; n = 11: 46 variables, 33
+    distances): 33 .. 48 free variables take three matrix columns per lane. Bit-identical to the
+    one-System-per-wavefront kernel, same LM path as the oracle."""
+    from fiksi_amd import workloads
+
+    b = workloads.hinged_triangles(1030, n_tri)
+    assert 32 < int(b["var_off"][1]) <= 48
+    routing("1")
+    v1, r1 = _solve(ctx, b)
+    routing("0")
+    v0, r0 = _solve(ctx, b)
+    assert np.array_equal(_bits(v1), _bits(v0))
+    for f in r1.dtype.names:
+        a, c = r1[f], r0[f]
+        assert np.array_equal(_bits(a), _bits(c)) if a.dtype.kind == "f" else np.array_equal(a, c), f
+    sub = workloads.shard(b, 0, 16)
+    n = len(sub["var_off"]) - 1
+    v_o, res_o = oracle.solve_batch(sub, mode=3, nthreads=8)
+    assert np.array_equal(r1["accepted"][:n], res_o["accepted"])
+    assert np.array_equal(r1["trials"][:n], res_o["trials"])
+    assert np.max(np.abs(v1[: len(v_o)] - v_o)) < 1e-8
+
+
 def test_against_the_oracle_on_the_headline_shape(fiksi, oracle, ctx, routing):
     """The comparison tests/test_gpu_parity.py makes for the one-System-per-wavefront kernel, on the grouped one."""
     from fiksi_amd import workloads
