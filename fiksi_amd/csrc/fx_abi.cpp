@@ -1068,6 +1068,9 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     d.max_ents = p.max_ents;
     d.max_pairs_tri = p.max_pairs_tri;
     d.uniform = p.uniform;
+    d.u_nvars = p.uniform ? batch->var_off[1] : 0;
+    d.u_nexprs = p.uniform ? batch->expr_off[1] : 0;
+    d.u_ncomp = p.uniform ? p.sys_ncomp[0] : 0;
     d.max_pairs_g = p.max_pairs_large;  // blocks of a large System hold at most its components' products
     d.max_ents_g = p.max_ents_large;
     const uint32_t zero_off[1] = {0};

@@ -49,6 +49,7 @@ struct DeviceBatch {
     uint32_t max_pairs_g, max_ents_g;      // the same over the Systems of the GLOBAL block walker
     uint32_t max_pairs_tri;                // per component: products of the lower triangle only (grouped kernel)
     uint32_t uniform;                      // 1: every System has the same structure (variables, fixed flags, expressions)
+    uint32_t u_nvars, u_nexprs, u_ncomp;   // ... and then its sizes: offsets are multiples, no table look-up needed
 
     uint32_t* var_off;     // [n_systems+1]
     uint32_t* expr_off;    // [n_systems+1]

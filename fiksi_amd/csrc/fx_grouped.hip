@@ -509,17 +509,26 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 uint32_t tk = 0;
                 if (hl == 0) tk = atomicAdd(next_system, 1u);
                 nxt = (uint32_t)__shfl((int)tk, 0, RS);
-                if (nxt >= b.n_systems || !b.sys_large[nxt]) break;  // large Systems belong to the other paths
+                // large Systems belong to the other paths (a batch of one shared structure has none here)
+                if (nxt >= b.n_systems || b.uniform || !b.sys_large[nxt]) break;
             }
             if (nxt >= b.n_systems) {
                 phase = GP_EXIT;
             } else {
                 s = nxt;
-                v0 = b.var_off[s];
-                nvt = b.var_off[s + 1] - v0;
-                e0 = b.expr_off[s];
-                net = b.expr_off[s + 1] - e0;
-                ncomp = b.sys_ncomp[s];
+                if (b.uniform) {  // offsets are multiples of the common sizes: one round trip less
+                    nvt = b.u_nvars;
+                    net = b.u_nexprs;
+                    v0 = s * nvt;
+                    e0 = s * net;
+                    ncomp = b.u_ncomp;
+                } else {
+                    v0 = b.var_off[s];
+                    nvt = b.var_off[s + 1] - v0;
+                    e0 = b.expr_off[s];
+                    net = b.expr_off[s + 1] - e0;
+                    ncomp = b.sys_ncomp[s];
+                }
 #pragma unroll
                 for (int k = 0; k < PF; ++k) {
                     const uint32_t i = (uint32_t)(RS * k + hl);
