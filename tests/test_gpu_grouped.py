@@ -160,3 +160,90 @@ def test_shared_structure_is_detected_per_batch_not_assumed(fiksi, ctx, routing)
         v0, r0 = _solve(ctx, batch)
         assert np.array_equal(_bits(v1), _bits(v0))
         assert np.array_equal(r1["trials"], r0["trials"])
+
+
+def _anchored_sketch(seed):
+    """20 fixed anchor points and 10 free ones tied to them (and three pairs to each other): 60 variables — past
+    the 48 a lane row keeps in registers —, 20 free ones, 28 expressions, fixed values that must come back untouched."""
+    import helpers
+    from fiksi_amd import System, constraints, elements
+
+    g = helpers.Lcg(seed)
+    s = System()
+    anchors = [elements.Point.create(s, g.u(-20, 20), g.u(-20, 20)) for _ in range(20)]
+    for a in anchors:
+        a.fix(s)
+    free = [elements.Point.create(s, g.u(-20, 20), g.u(-20, 20)) for _ in range(10)]
+    for i, p in enumerate(free):
+        for k in range(2):
+            constraints.PointPointDistance.create(s, p, anchors[(2 * i + 7 * k + seed) % 20], g.u(5, 25))
+    for i in range(0, 6, 2):
+        constraints.PointPointDistance.create(s, free[i], free[i + 1], g.u(3, 12))
+    for i in range(5):
+        constraints.PointPointPointAngle.create(s, anchors[i], free[i], anchors[i + 10], g.u(-1.5, 1.5))
+    return s
+
+
+def _angle_sketch(seed):
+    """16 free points under 24 three-point angles (six entries per row, all free): 504 products in the triangle of
+    JtJ — more than the 448 list words the f64 build keeps in registers — and fewer rows than variables."""
+    import helpers
+    from fiksi_amd import System, constraints, elements
+
+    g = helpers.Lcg(seed)
+    s = System()
+    P = [elements.Point.create(s, 10 * np.cos(0.39 * i) + g.u(-1, 1), 10 * np.sin(0.39 * i) + g.u(-1, 1)) for i in range(16)]
+    for k in range(24):
+        a, b2, c = (2 * k) % 16, (2 * k + 3 + k // 8) % 16, (2 * k + 7 + k // 8) % 16
+        constraints.PointPointPointAngle.create(s, P[a], P[b2], P[c], g.u(-1.5, 1.5))
+    return s
+
+
+def _overdetermined_sketch(seed):
+    """8 free points under 70 inconsistent distances: 16 columns, 70 rows (more than the 64 one pass of a wavefront
+    covers, and more expressions than a lane row keeps in registers): a least-squares fit."""
+    import helpers
+    from fiksi_amd import System, constraints, elements
+
+    g = helpers.Lcg(seed)
+    s = System()
+    P = [elements.Point.create(s, g.u(-10, 10), g.u(-10, 10)) for _ in range(8)]
+    k = 0
+    while k < 70:
+        a, b2 = int(g.u(0, 8)) % 8, int(g.u(0, 8)) % 8
+        if a != b2:
+            constraints.PointPointDistance.create(s, P[a], P[b2], g.u(2, 12))
+            k += 1
+    return s
+
+
+@pytest.mark.parametrize("builder,f32", [("anchored", False), ("angles", False), ("overdetermined", True)])
+def test_sketches_past_the_register_held_parts(fiksi, oracle, ctx, routing, builder, f32):
+    """Variables / expressions past the ones a lane row keeps in registers (loaded where they are used), product
+    lists longer than their register-held part, more than 64 rows — each within the 10 KB of LDS per System the
+    routing allows: against the one-System-per-wavefront kernel and (f64) the oracle."""
+    from fiksi_amd import abi, workloads
+
+    make = {"anchored": _anchored_sketch, "angles": _angle_sketch, "overdetermined": _overdetermined_sketch}[builder]
+    b = workloads.concat([make(s).flatten() for s in range(40)])
+    routing("1")
+    db = ctx.upload(b)
+    assert db.solve_route(abi.solving_opts(f32=f32)) == 1
+    db.free()
+    v1, r1 = _solve(ctx, b, f32=f32)
+    routing("0")
+    v0, r0 = _solve(ctx, b, f32=f32)
+    assert np.array_equal(r1["scale"], r0["scale"]) and np.array_equal(r1["ncomp"], r0["ncomp"])
+    fx_ = b["var_fixed"] == 1
+    assert np.array_equal(v1[fx_], b["vars"][fx_])
+    same = (r1["accepted"] == r0["accepted"]) & (r1["trials"] == r0["trials"])
+    assert same.mean() > 0.85
+    rtol = 1e-3 if f32 else 1e-6
+    assert np.allclose(r1["sse"][same], r0["sse"][same], rtol=rtol, atol=1e-12)
+    if not f32:
+        v_o, res_o = oracle.solve_batch(b, mode=3, trial_cap=4096, nthreads=8)
+        assert np.array_equal(r1["scale"], res_o["scale"]) and np.array_equal(r1["ncomp"], res_o["ncomp"])
+        same_o = (r1["accepted"] == res_o["accepted"]) & (r1["trials"] == res_o["trials"])
+        assert same_o.mean() > 0.7
+        d = np.abs(r1["sse"] - res_o["sse"])
+        assert np.all(d[same_o] <= 1e-9 + 1e-4 * np.abs(res_o["sse"][same_o]))
