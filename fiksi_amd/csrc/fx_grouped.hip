@@ -1,26 +1,29 @@
 // Grouped fused solve (gfx950, wave64): FOUR Systems per wavefront, one per row of 16 lanes, for batches
 // whose components have at most 32 free variables — the headline shape (BASELINE cfg3: 32 variables /
-// 32 expressions per System) and everything smaller.
+// 32 expressions per System) and everything smaller — and, in f64, up to 48 (the reference's own bench
+// sketch, fiksi_bench.rs:15-40: 46 variables).
 //
 // Same algorithm and the same arithmetic as lm_solve_kernel (fx_kernels.hip; reference:
 // fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193), reorganised around what that kernel's
 // profile shows: with N <= 32 columns only half of a wavefront's lanes hold a column of the
 // register-resident Cholesky, and every multiply-add of it pays two v_readlane for its broadcast. Here
-//   * a System lives in one DPP row: lane r of the row holds columns r and r + 16 of the matrix (NC = 2;
-//     NC = 1 for components of at most 16 free variables), and every broadcast is a
-//     `v_mov_b32_dpp row_newbcast:k` — a full-rate VALU move that serves the four Systems of the
-//     wavefront at once and feeds NC multiply-adds, with no SGPR and no LDS round trip;
+//   * a System lives in one DPP row: lane r of the row holds columns r, r + 16 (and r + 32) of the matrix
+//     (NC = 1, 2 or 3 columns per lane), and a broadcast is the DPP control `row_newbcast:k` — on gfx90a+
+//     also legal on 64-bit operations, so the factor's inner step is ONE instruction,
+//     `v_fmac_f64_dpp a, -src row_newbcast:k, mul`, serving the four Systems of the wavefront at once, with no
+//     SGPR and no LDS round trip (NC = 3 leaves the DPP to the compiler: `v_mov_b64_dpp` + three fma);
 //   * what was wave-uniform (lambda, SSE, trial counts, exit code) is row-uniform and kept per lane; the LM
 //     control flow is a per-row state machine (NEXT System -> COMPonent set-up -> RUN trials -> FINISH
 //     component), so rows only wait for each other inside one wave instruction;
 //   * rows take Systems from a device-side counter: a row that finishes early starts its next System
-//     while its neighbours are still iterating;
+//     while its neighbours are still iterating (trial counts are very uneven: ring16 3 .. 30+);
 //   * LDS per System is cut to 10 KB for the headline shape (JtJ as a packed lower triangle, one
 //     Jacobian-row buffer — the trial point's rows are only read after it was accepted —, the current point
-//     in registers, set-up scratch aliased with the triangle), so a CU still holds 16 Systems.
+//     in registers, set-up scratch aliased with the triangle), so a CU still holds 16 Systems;
+//   * a batch whose Systems all share one structure (DeviceBatch::uniform) keeps a row's lists between Systems.
 // Sums (SSE, |delta|^2, the system scale) are taken in the order lm_solve_kernel takes them, and the
 // factorization does the same operations on the same operands: results are bit-identical to that kernel's
-// (tests/test_gpu_grouped.py).
+// on the ring16 and hinged-triangle shapes (tests/test_gpu_grouped.py). DESIGN.md section 3.1a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
