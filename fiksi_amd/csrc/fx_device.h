@@ -112,7 +112,7 @@ hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_
 // several Systems per wavefront (fx_grouped.hip): batches of components with at most 32 free variables
 bool grouped_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
-size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size);
+size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool single_pass_blocks);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t wide_lds_bytes(const DeviceBatch& b);

@@ -250,7 +250,10 @@ enum GroupPhase : int { GP_NEXT = 0, GP_COMP = 1, GP_RUN = 2, GP_FINISH = 3, GP_
 // per phase over the wavefront (all four rows) into prm.prof — same six phases as lm_solve_kernel's.
 enum GPhase { GH_SETUP = 0, GH_EVAL = 1, GH_FORM = 2, GH_FACTOR = 3, GH_SOLVE = 4, GH_TAIL = 5, GH_COUNT = 6 };
 
-template <int NC, typename T, bool PROF>
+// UNITS = true is `Decomposer::SinglePass` (assemble/mod.rs:169-210), as in lm_solve_kernel: the loop runs over the
+// blocks of the host decomposition (fx_decompose.h), a component is perturbed before its first block, and a solved
+// block is written through to the working vector so later blocks see it.
+template <int NC, typename T, bool PROF, bool UNITS>
 __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParams& prm, const GroupLayout& L,
                                              uint32_t* __restrict__ next_system, unsigned char* smem) {
     unsigned long long ph[GH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -297,7 +300,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 
     // per-row state (identical in every lane of the row unless noted)
     int phase = GP_NEXT;
-    uint32_t s = 0, v0 = 0, nvt = 0, e0 = 0, net = 0, ncomp = 0, c = 0;
+    uint32_t s = 0, v0 = 0, nvt = 0, e0 = 0, net = 0, ncomp = 0, c = 0;  // UNITS: ncomp / c count blocks
+    uint32_t unit0 = 0, unit_flags = 0;
     double scale = 1.0, scale_recip = 1.0;
     uint32_t rng = 42u;
     uint32_t tot_accept = 0, tot_trials = 0, last_exit = FX_EXIT_SSE, comps_done = 0;
@@ -532,6 +536,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     net = b.expr_off[s + 1] - e0;
                     ncomp = b.sys_ncomp[s];
                 }
+                if constexpr (UNITS) {
+                    unit0 = b.sys_unit_off[s];
+                    ncomp = b.sys_unit_off[s + 1] - unit0;
+                }
 #pragma unroll
                 for (int k = 0; k < PF; ++k) {
                     const uint32_t i = (uint32_t)(RS * k + hl);
@@ -622,7 +630,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 phase = GP_NEXT;
                 stamp(GH_SETUP);
             } else {
-                const bool reuse = b.uniform != 0u && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
+                const bool reuse = !UNITS && b.uniform != 0u && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
                 if (reuse) {
                     // same structure as the System before: perturb and re-scale the parameters, nothing else
 #pragma unroll
@@ -654,7 +662,74 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     }
                 }
                 bool have_comp = reuse;
-                if (!reuse) {
+                bool rows_listed = false;
+                if constexpr (UNITS) {
+                    const UnitDesc ud = b.unit_desc[unit0 + c];
+                    unit_flags = ud.flags;
+                    if (ud.flags & UNIT_FIRST) {  // the component's perturbation comes before its first block (:91-111)
+                        comps_done += 1;
+                        last_exit = FX_EXIT_SSE;
+                        if (prm.mode & 2u) {
+                            uint32_t rank0 = 0;
+                            for_vars([&](uint32_t i, double v, uint32_t info) {
+                                const bool in = i < nvt && (info & VAR_COMP_MASK) == ud.comp && !(info & VAR_FIXED_BIT);
+                                const uint32_t m = gballot(in);
+                                if (in) {
+                                    uint32_t st = lcg_jump(rng, 2u * (rank0 + (uint32_t)__popc(m & below)));
+                                    st = st * 1664525u + 1013904223u;
+                                    const double f1 = (1.0 / 4294967295.0) * (double)st;
+                                    st = st * 1664525u + 1013904223u;
+                                    const double f2 = (1.0 / 4294967295.0) * (double)st;
+                                    double x = (prm.mode & 1u) ? v * scale_recip : v;
+                                    x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                                    XS[i] = (T)x;
+                                }
+                                rank0 += (uint32_t)__popc(m);
+                            });
+                            rng = lcg_jump(rng, 2u * rank0);
+                        }
+                    }
+                    if (ud.flags & UNIT_EMPTY) {
+                        c += 1;  // a component no expression could be matched in
+                    } else {
+                        have_comp = true;
+                        rows_listed = true;
+                        nfree = ud.nvars;
+                        m_rows = ud.nrows;
+                        for_vars([&](uint32_t i, double, uint32_t) {
+                            if (i < nvt) colof[i] = (int16_t)-1;
+                        });
+                        group_sync();
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const uint32_t j = (uint32_t)(hl + RS * q);
+                            my_vi[q] = 0u;
+                            if (j < nfree) {
+                                my_vi[q] = (uint32_t)b.unit_vars[ud.var_off + j];
+                                colof[my_vi[q]] = (int16_t)j;
+                            }
+                        }
+                        group_sync();
+                        for (uint32_t pos = hl; pos < m_rows; pos += RS) {  // rows in block order
+                            const uint32_t i = b.unit_rows[ud.row_off + pos];
+                            const int tag = (int)(b.expr_tag[e0 + i] & 0x7F);
+                            const ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[e0 + i];
+                            uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+                            uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                            const int k = expand_vars(tag, ff, vars8);
+                            double prm_e = b.expr_param[e0 + i];
+                            if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                            rtag[pos] = (uint8_t)tag;
+                            P[pos] = (T)prm_e;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                                gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
+                            }
+                        }
+                    }
+                }
+                if (!UNITS && !reuse) {
                 // free variables of the component, ascending (BTreeSet order, assemble/mod.rs:91-111)
                 // (perturbed where they are found — K0b: 2 LCG draws each, in that order)
                 nfree = 0;
@@ -688,6 +763,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     c += 1;  // a component without variables is skipped by the reference (`elements.is_empty()`)
                 } else {
                     have_comp = true;
+                    rows_listed = true;
                     built = true;
                     if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
                     group_sync();
@@ -721,6 +797,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         }
                         m_rows += (uint32_t)__popc(mk);
                     });
+                }
+                }  // lists of a component
+                if (rows_listed) {
                     group_sync();
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
@@ -795,8 +874,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             pe_reg[u] = (t < n_pe && t < L.pe_cap) ? (uint32_t)PE[t] : 0xFFFFFFFFu;
                         }
                     }
-                }
-                }  // !reuse
+                }  // rows_listed
                 if (have_comp) {
                     stamp(GH_SETUP);
                     // the start point is evaluated and assembled by the RUN block (one copy of that code)
@@ -953,8 +1031,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     b.vars[v0 + my_vi[q]] = xo;
                     VOUT[my_vi[q]] = xo;
                     // later components are solved against the PRE-solve snapshot (only `system.variables` is
-                    // written back, quirk Q2): the working vector goes back to the perturbed start value
-                    XS[my_vi[q]] = xstart[q];
+                    // written back, quirk Q2): the working vector goes back to the perturbed start value.
+                    // SinglePass blocks update it instead (assemble/mod.rs:201-207).
+                    XS[my_vi[q]] = (UNITS && !(unit_flags & UNIT_RESTORE)) ? xc[q] : xstart[q];
                 }
             }
             group_sync();
@@ -963,7 +1042,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             last_exit = exit_code;
             tot_sse0 += (double)sse_start;
             tot_sse += (double)sse;
-            comps_done += 1;
+            if (!UNITS) comps_done += 1;
             c += 1;
             phase = GP_COMP;
             stamp(GH_TAIL);
@@ -981,31 +1060,36 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 
 // The occupancy hint is part of the kernel's signature: the 32-column f64 build is LDS-bound to one wavefront
 // per SIMD anyway (4 x 10 KB per wavefront) and may use the registers that frees; the others run two.
-template <int NC, typename T, bool PROF>
+template <int NC, typename T, bool PROF, bool UNITS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_kernel_w1(
     DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_body<NC, T, PROF>(b, prm, L, next_system, smem);
+    grouped_body<NC, T, PROF, UNITS>(b, prm, L, next_system, smem);
 }
-template <int NC, typename T, bool PROF>
+template <int NC, typename T, bool PROF, bool UNITS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void lm_solve_grouped_kernel_w2(
     DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_body<NC, T, PROF>(b, prm, L, next_system, smem);
+    grouped_body<NC, T, PROF, UNITS>(b, prm, L, next_system, smem);
 }
 
 // ------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------
-template <int NC, typename T, bool PROF = false>
+template <int NC, typename T, bool PROF = false, bool UNITS = false>
 static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint32_t* counter, hipStream_t stream) {
-    const GroupLayout L = make_group_layout((uint32_t)(RS * NC), b.max_vars, b.max_rows, (uint32_t)sizeof(T), b.max_pairs_tri, b.max_ents);
+    // SinglePass: rows and products per BLOCK (a row holds at most 8 entries: 36 products of the triangle plus 28
+    // repeats, 8 right-hand-side entries)
+    const uint32_t rows = UNITS ? b.max_unit_rows : b.max_rows;
+    const uint32_t pairs = UNITS ? (b.max_unit_rows * 64u < b.max_pairs_tri ? b.max_unit_rows * 64u : b.max_pairs_tri) : b.max_pairs_tri;
+    const uint32_t ents = UNITS ? (b.max_unit_rows * 8u < b.max_ents ? b.max_unit_rows * 8u : b.max_ents) : b.max_ents;
+    const GroupLayout L = make_group_layout((uint32_t)(RS * NC), b.max_vars, rows, (uint32_t)sizeof(T), pairs, ents);
     constexpr uint32_t groups = 64u / (uint32_t)RS;
     const uint32_t per_wave = groups * L.stride;
     constexpr bool one_wave = (NC >= 2 && sizeof(T) == 8);
     const void* fn;
-    if constexpr (one_wave) fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w1<NC, T, PROF>);
-    else fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w2<NC, T, PROF>);
+    if constexpr (one_wave) fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>);
+    else fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w2<NC, T, PROF, UNITS>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(counter, 0, sizeof(uint32_t), stream);
@@ -1015,20 +1099,26 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     const uint32_t cap = 256u * 16u;
     if (waves > cap) waves = cap;
     if constexpr (one_wave) {
-        hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
     } else {
-        hipLaunchKernelGGL((lm_solve_grouped_kernel_w2<NC, T, PROF>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w2<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
     }
     return hipGetLastError();
 }
 
-static uint32_t grouped_columns(const DeviceBatch& b) { return b.max_free <= 16u ? 1u : b.max_free <= 32u ? 2u : 3u; }
+static uint32_t grouped_columns(const DeviceBatch& b, bool units) {
+    const uint32_t f = units ? b.max_unit_free : b.max_free;
+    return f <= 16u ? 1u : f <= 32u ? 2u : 3u;
+}
 
 // LDS bytes per wavefront of the grouped kernel for this batch, 0 when the batch does not qualify
-size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t es) {
-    if (b.max_free == 0 || b.max_free > 48u || b.max_rows > 256u || b.max_vars > 4096u) return 0;
-    if (b.max_free > 32u && b.max_rows > 128u) return 0;  // 7 row bits in a packed right-hand-side entry of the 48-column build
-    const GroupLayout L = make_group_layout(RS * grouped_columns(b), b.max_vars, b.max_rows, es, b.max_pairs_tri, b.max_ents);
+size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t es, bool units) {
+    const uint32_t free_ = units ? b.max_unit_free : b.max_free, rows = units ? b.max_unit_rows : b.max_rows;
+    if (free_ == 0 || free_ > 48u || rows > 256u || b.max_vars > 4096u) return 0;
+    if (free_ > 32u && rows > 128u) return 0;  // 7 row bits in a packed right-hand-side entry of the 48-column build
+    const uint32_t pairs = units ? (rows * 64u < b.max_pairs_tri ? rows * 64u : b.max_pairs_tri) : b.max_pairs_tri;
+    const uint32_t ents = units ? (rows * 8u < b.max_ents ? rows * 8u : b.max_ents) : b.max_ents;
+    const GroupLayout L = make_group_layout(RS * grouped_columns(b, units), b.max_vars, rows, es, pairs, ents);
     return (size_t)(64u / (uint32_t)RS) * L.stride;
 }
 
@@ -1040,19 +1130,27 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     if (sw && sw[0] == '0') return false;
     const bool forced = sw && sw[0] == '1';
     if (!forced && b.n_systems < 8192u) return false;
-    if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || p.lm.solver != FX_STEP_CHOLESKY) return false;
+    if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
+    const bool units = (p.mode & MODE_UNITS) != 0;
+    if (units && (!b.sys_unit_off || p.prof || p.lm.precision == 32)) return false;  // SinglePass here: f64
     if (p.prof && p.lm.precision == 32) return false;
-    if (grouped_columns(b) == 3u && (p.prof || p.lm.precision == 32)) return false;
+    if (grouped_columns(b, units) == 3u && (p.prof || p.lm.precision == 32)) return false;
     if (!b.work_counter) return false;
-    const size_t lds = grouped_lds_bytes(b, p.lm.precision == 32 ? 4u : 8u);
+    const size_t lds = grouped_lds_bytes(b, p.lm.precision == 32 ? 4u : 8u, units);
     // four wavefronts (16 Systems) per CU or more; two (8 Systems) for the 48-column build, whose Systems would
     // otherwise sit five to a CU, one per wavefront
-    return lds != 0 && lds <= (160u * 1024u) / (grouped_columns(b) == 3u ? 2u : 4u);
+    return lds != 0 && lds <= (160u * 1024u) / (grouped_columns(b, units) == 3u ? 2u : 4u);
 }
 
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
-    const uint32_t nc = grouped_columns(b);
+    const bool units = (p.mode & MODE_UNITS) != 0;
+    const uint32_t nc = grouped_columns(b, units);
+    if (units) {
+        return nc == 1u   ? launch_grouped_t<1, double, false, true>(b, p, b.work_counter, stream)
+               : nc == 2u ? launch_grouped_t<2, double, false, true>(b, p, b.work_counter, stream)
+                          : launch_grouped_t<3, double, false, true>(b, p, b.work_counter, stream);
+    }
     const bool two = nc == 2u;
     if (nc == 3u) return launch_grouped_t<3, double>(b, p, b.work_counter, stream);  // f64, no stamped build
     if (p.prof) return two ? launch_grouped_t<2, double, true>(b, p, b.work_counter, stream)

@@ -82,6 +82,47 @@ def test_forty_eight_column_build_on_the_references_bench_sketch(fiksi, oracle, 
     assert np.max(np.abs(v1[: len(v_o)] - v_o)) < 1e-8
 
 
+@pytest.mark.parametrize("shape", ["hinged11", "hinged5", "ring16", "mixed"])
+def test_single_pass_blocks_on_the_grouped_kernel(fiksi, oracle, ctx, routing, shape):
+    """`Decomposer::SinglePass`: the grouped kernel walks the blocks of the host decomposition as lm_solve_kernel's
+    UNITS build does (perturbation before a component's first block, write-through after each block) — same bits,
+    and the oracle's solution on a sample."""
+    import helpers
+    from fiksi_amd import abi, workloads
+
+    b = {"hinged11": lambda: workloads.hinged_triangles(1030, 11), "hinged5": lambda: workloads.hinged_triangles(1030, 5),
+         "ring16": lambda: workloads.ring16(1030),
+         "mixed": lambda: workloads.concat([helpers.mixed_sketch(s, fix_some=bool(s & 1)).flatten() for s in range(150)]
+                                           + [helpers.random_sketch(s).flatten() for s in range(150)])}[shape]()
+    o = abi.solving_opts(decomposer=1)
+    out = {}
+    for tag in ("1", "0"):
+        routing(tag)
+        db = ctx.upload(b)
+        db.system_solve(o)
+        assert db.solve_route(o) == int(tag)
+        out[tag] = (db.get_vars().copy(), db.get_results().copy())
+        db.free()
+    (v1, r1), (v0, r0) = out["1"], out["0"]
+    if shape != "mixed":
+        assert np.array_equal(_bits(v1), _bits(v0))
+        for f in r1.dtype.names:
+            a, c = r1[f], r0[f]
+            assert np.array_equal(_bits(a), _bits(c)) if a.dtype.kind == "f" else np.array_equal(a, c), f
+        sub = workloads.shard(b, 0, 16)
+        n = len(sub["var_off"]) - 1
+        v_o, res_o = oracle.solve_single_pass_batch(sub, trial_cap=4096, nthreads=8)
+        assert np.array_equal(r1["accepted"][:n], res_o["accepted"])
+        assert np.max(np.abs(v1[: len(v_o)] - v_o)) < 1e-7
+    else:
+        assert np.array_equal(r1["scale"], r0["scale"]) and np.array_equal(r1["ncomp"], r0["ncomp"])
+        same = (r1["accepted"] == r0["accepted"]) & (r1["trials"] == r0["trials"])
+        assert same.mean() > 0.9
+        ok = ~(np.isnan(r1["sse"]) | np.isnan(r0["sse"]))
+        d = np.abs(r1["sse"] - r0["sse"])[same & ok]  # tests/test_gpu_fuzz.py's bound for these ill-conditioned sketches
+        assert np.all(d <= 1e-9 + 0.25 * np.abs(r0["sse"][same & ok]))
+
+
 def test_against_the_oracle_on_the_headline_shape(fiksi, oracle, ctx, routing):
     """The comparison tests/test_gpu_parity.py makes for the one-System-per-wavefront kernel, on the grouped one."""
     from fiksi_amd import workloads
