@@ -139,11 +139,12 @@ __device__ __forceinline__ void seq_add(double& sum, double t) { seq_add_impl(su
 // Cholesky of fx_chol.h with the columns of one matrix spread over a row: lane r holds column r + 16 q in
 // a[q][.] (same operations on the same operands as chol_factor / chol_solve: bit-identical results)
 // ------------------------------------------------------------------------------------------
-template <int NC, typename T, int K>
-struct RStep {
+template <int NC, typename T, int K, bool BOUNDED>
+struct RStep {  // one column step of the factorization / of a triangular solve
     static constexpr int N = RS * NC;
     static constexpr int KA = K / RS, KL = K % RS;  // array and lane of column K
-    static __device__ __forceinline__ void factor(T (&a)[NC][N], T (&invd)[NC], bool& bad, int hl) {
+    static __device__ __forceinline__ void factor(T (&a)[NC][N], T (&invd)[NC], bool& bad, int hl, int kmax) {
+        {
         const T piv = rbcast<KL>(a[KA][K]);
         bad = bad || !(piv > T(0)) || !(piv < Lim<T>::huge());
         const T rs = rsqrt_refined(piv);
@@ -189,11 +190,12 @@ struct RStep {
                 }
             }
         }
-        if constexpr (K + 1 < N) RStep<NC, T, K + 1>::factor(a, invd, bad, hl);
+        }
     }
     // acc[q] -= a[q][K] * y_K, y_K = (acc * invd) of column K's lane: the broadcast is the DPP operand of the
     // multiply-add; lanes that must not take part get a zero factor.
-    static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl) {
+    static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl, int kmax) {
+        {
         T t = acc[KA] * invd[KA];
         if constexpr (NC <= 2) {
             dpp_settle(t);
@@ -211,9 +213,10 @@ struct RStep {
                 if (q > KA || hl > KL) acc[q] = fma(-a[q][K], yk, acc[q]);
             }
         }
-        if constexpr (K + 1 < N) RStep<NC, T, K + 1>::forward(a, invd, acc, hl);
+        }
     }
-    static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl) {
+    static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl, int kmax) {
+        {
         T t = acc[KA] * invd2[KA];
         if constexpr (NC <= 2) {
             dpp_settle(t);
@@ -231,7 +234,41 @@ struct RStep {
                 if (q < KA || hl < KL) acc[q] = fma(-a[q][K], xi, acc[q]);
             }
         }
-        if constexpr (K > 0) RStep<NC, T, K - 1>::backward(a, invd2, acc, hl);
+        }
+    }
+};
+
+// The steps in blocks of eight columns. BOUNDED (the SinglePass build, whose blocks are mostly far smaller than N):
+// kmax is wave-uniform, no row of the wavefront has more than kmax columns in use; the columns past a System's free
+// variables are identity padding that no other column depends on, so a block of steps at or past kmax is skipped.
+// (One test per eight steps, and none in the other builds: the scheduler needs long straight-line regions here —
+// a test per step cost the headline shape 25 %.)
+template <int NC, typename T, int KB, bool BOUNDED>
+struct RBlock {
+    static constexpr int N = RS * NC;
+    template <int... I>
+    static __device__ __forceinline__ void factor8(T (&a)[NC][N], T (&invd)[NC], bool& bad, int hl, int kmax, std::integer_sequence<int, I...>) {
+        (RStep<NC, T, 8 * KB + I, BOUNDED>::factor(a, invd, bad, hl, kmax), ...);
+    }
+    template <int... I>
+    static __device__ __forceinline__ void forward8(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl, int kmax, std::integer_sequence<int, I...>) {
+        (RStep<NC, T, 8 * KB + I, BOUNDED>::forward(a, invd, acc, hl, kmax), ...);
+    }
+    template <int... I>
+    static __device__ __forceinline__ void backward8(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl, int kmax, std::integer_sequence<int, I...>) {
+        (RStep<NC, T, 8 * KB + 7 - I, BOUNDED>::backward(a, invd2, acc, hl, kmax), ...);
+    }
+    static __device__ __forceinline__ void factor(T (&a)[NC][N], T (&invd)[NC], bool& bad, int hl, int kmax) {
+        if (!BOUNDED || 8 * KB < kmax) factor8(a, invd, bad, hl, kmax, std::make_integer_sequence<int, 8>{});
+        if constexpr (8 * KB + 8 < N) RBlock<NC, T, KB + 1, BOUNDED>::factor(a, invd, bad, hl, kmax);
+    }
+    static __device__ __forceinline__ void forward(const T (&a)[NC][N], const T (&invd)[NC], T (&acc)[NC], int hl, int kmax) {
+        if (!BOUNDED || 8 * KB < kmax) forward8(a, invd, acc, hl, kmax, std::make_integer_sequence<int, 8>{});
+        if constexpr (8 * KB + 8 < N) RBlock<NC, T, KB + 1, BOUNDED>::forward(a, invd, acc, hl, kmax);
+    }
+    static __device__ __forceinline__ void backward(const T (&a)[NC][N], const T (&invd2)[NC], T (&acc)[NC], int hl, int kmax) {
+        if (!BOUNDED || 8 * KB < kmax) backward8(a, invd2, acc, hl, kmax, std::make_integer_sequence<int, 8>{});
+        if constexpr (KB > 0) RBlock<NC, T, KB - 1, BOUNDED>::backward(a, invd2, acc, hl, kmax);
     }
 };
 
@@ -894,6 +931,14 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
         }
 
+        // the most columns any row of the wavefront factors in this pass (wave-uniform: the four row leaders)
+        int kmax;
+        {
+            const int km = (phase == GP_RUN && !fresh) ? (int)nfree : 0;
+            const int k0 = __builtin_amdgcn_readlane(km, 0), k1 = __builtin_amdgcn_readlane(km, 16);
+            const int k2 = __builtin_amdgcn_readlane(km, 32), k3 = __builtin_amdgcn_readlane(km, 48);
+            kmax = max(max(k0, k1), max(k2, k3));
+        }
         // ================= RUN: one lambda trial (lm.rs:115-191) =================
         if (phase == GP_RUN) {
             stamp(GH_TAIL);
@@ -930,7 +975,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 #pragma unroll
                     for (int q = 0; q < NC; ++q) invd[q] = T(1);
                     bool bad = false;
-                    RStep<NC, T, 0>::factor(a, invd, bad, hl);
+                    RBlock<NC, T, 0, UNITS>::factor(a, invd, bad, hl, kmax);
                     stamp(GH_FACTOR);
                     if (bad) {  // lm.rs:134-137
                         lambda *= o.singular_factor;
@@ -942,8 +987,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             acc[q] = rhs_l[q];
                             invd2[q] = invd[q] * invd[q];
                         }
-                        RStep<NC, T, 0>::forward(a, invd, acc, hl);
-                        RStep<NC, T, N - 1>::backward(a, invd2, acc, hl);
+                        RBlock<NC, T, 0, UNITS>::forward(a, invd, acc, hl, kmax);
+                        RBlock<NC, T, N / 8 - 1, UNITS>::backward(a, invd2, acc, hl, kmax);
 #pragma unroll
                         for (int q = 0; q < NC; ++q) delta[q] = ((uint32_t)(hl + RS * q) < nfree) ? acc[q] * invd2[q] : T(0);
                     }
