@@ -630,43 +630,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             stamp(GH_SETUP);
         }
 
-        // ================= COMP: set up component c, or close the System =================
+        // ================= COMP: set up component (SinglePass: block) c =================
         if (phase == GP_COMP) {
-            if (c >= ncomp) {
-                // post-solve check on unscaled variables (constraints/mod.rs:96-109)
-                double part[4] = {0.0, 0.0, 0.0, 0.0};
-                for_exprs([&](uint32_t i, int tag, double param, uint32_t, ushort4 f4) {
-                    if (i < net) {
-                        uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-                        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        expand_vars(tag, ff, vars8);
-                        double v[8], g[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
-                        const double r = eval_expression<double, false>(tag, v, param, g);
-                        const double r2 = r * r;
-                        const uint32_t blk = (i >> 4) & 3u;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : 0.0;
-                    }
-                });
-                const double sse_u = block_sum4(part);
-                if (hl == 0) {
-                    fx_result res;
-                    res.accepted = tot_accept;
-                    res.trials = tot_trials;
-                    res.exit = last_exit;
-                    res.ncomp = comps_done;
-                    res.scale = scale;
-                    res.sse0 = tot_sse0;
-                    res.sse = tot_sse;
-                    res.sse_unscaled = sse_u;
-                    b.results[s] = res;
-                }
-                group_sync();
-                phase = GP_NEXT;
-                stamp(GH_SETUP);
-            } else {
+            if (c < ncomp) {
                 const bool reuse = !UNITS && b.uniform != 0u && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
                 if (reuse) {
                     // same structure as the System before: perturb and re-scale the parameters, nothing else
@@ -1091,6 +1057,44 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             c += 1;
             phase = GP_COMP;
             stamp(GH_TAIL);
+        }
+
+        // ================= CLOSE: all components done (in the pass of the last FINISH, so that the row takes its next
+        // System at the top of the next pass instead of sitting one out) =================
+        if (phase == GP_COMP && c >= ncomp) {
+                // post-solve check on unscaled variables (constraints/mod.rs:96-109)
+                double part[4] = {0.0, 0.0, 0.0, 0.0};
+                for_exprs([&](uint32_t i, int tag, double param, uint32_t, ushort4 f4) {
+                    if (i < net) {
+                        uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+                        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        expand_vars(tag, ff, vars8);
+                        double v[8], g[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
+                        const double r = eval_expression<double, false>(tag, v, param, g);
+                        const double r2 = r * r;
+                        const uint32_t blk = (i >> 4) & 3u;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : 0.0;
+                    }
+                });
+                const double sse_u = block_sum4(part);
+                if (hl == 0) {
+                    fx_result res;
+                    res.accepted = tot_accept;
+                    res.trials = tot_trials;
+                    res.exit = last_exit;
+                    res.ncomp = comps_done;
+                    res.scale = scale;
+                    res.sse0 = tot_sse0;
+                    res.sse = tot_sse;
+                    res.sse_unscaled = sse_u;
+                    b.results[s] = res;
+                }
+                group_sync();
+                phase = GP_NEXT;
+                stamp(GH_SETUP);
         }
 
         if (__ballot(phase != GP_EXIT) == 0ull) break;
