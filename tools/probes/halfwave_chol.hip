@@ -1,4 +1,6 @@
-// Probe: register-resident Cholesky factor+solve of 32x32 SPD systems, one system per wavefront
+// Probe (the measurement that started fx_grouped.hip; the kernel ended up on DPP row broadcasts instead — in the
+// full kernel every ds_swizzle became an LDS-pipe operation the compiler would not pipeline):
+// register-resident Cholesky factor+solve of 32x32 SPD systems, one system per wavefront
 // (v_readlane broadcasts, as fx_chol.h) against two systems per wavefront, one per 32-lane half
 // (ds_swizzle broadcasts inside each half). Prints ns per system for both and the max difference.
 //   hipcc -O3 --offload-arch=gfx950 -I fiksi_amd/csrc tools/probes/halfwave_chol.hip -o /tmp/hw && /tmp/hw
