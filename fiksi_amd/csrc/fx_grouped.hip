@@ -733,74 +733,74 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     }
                 }
                 if (!UNITS && !reuse) {
-                // free variables of the component, ascending (BTreeSet order, assemble/mod.rs:91-111)
-                // (perturbed where they are found — K0b: 2 LCG draws each, in that order)
-                nfree = 0;
-                bool any_var = false;
-                for_vars([&](uint32_t i, double v, uint32_t info) {
-                    const bool member = i < nvt && (info & VAR_COMP_MASK) == c;
-                    const bool in = member && !(info & VAR_FIXED_BIT);
-                    const uint32_t m = gballot(in);
-                    const uint32_t pos = nfree + (uint32_t)__popc(m & below);
-                    if (i < nvt) colof[i] = in ? (int16_t)pos : (int16_t)-1;
-                    if (in && pos < (uint32_t)N) fidx[pos] = (uint16_t)i;
-                    if (i < (uint32_t)(RS * PF)) {
-                        const int cc = in ? (int)pos : -1;
-                        if (i < (uint32_t)RS) c_col[0] = cc; else if (i < 2u * RS) c_col[1] = cc; else c_col[2] = cc;
-                    }
-                    if (in && (prm.mode & 2u)) {
-                        uint32_t st = lcg_jump(rng, 2u * pos);
-                        st = st * 1664525u + 1013904223u;
-                        const double f1 = (1.0 / 4294967295.0) * (double)st;
-                        st = st * 1664525u + 1013904223u;
-                        const double f2 = (1.0 / 4294967295.0) * (double)st;
-                        // from the f64 input, so the f64 start point is bit-identical to the reference
-                        double x = (prm.mode & 1u) ? v * scale_recip : v;
-                        x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
-                        XS[i] = (T)x;
-                    }
-                    nfree += (uint32_t)__popc(m);
-                    any_var = any_var || gballot(member) != 0u;
-                });
-                if (!any_var) {
-                    c += 1;  // a component without variables is skipped by the reference (`elements.is_empty()`)
-                } else {
-                    have_comp = true;
-                    rows_listed = true;
-                    built = true;
-                    if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
-                    group_sync();
-#pragma unroll
-                    for (int q = 0; q < NC; ++q) {
-                        const uint32_t j = (uint32_t)(hl + RS * q);
-                        my_vi[q] = (j < nfree) ? (uint32_t)fidx[j] : 0u;
-                    }
-                    // rows of the component: ascending expression id (assemble/mod.rs:139-145)
-                    m_rows = 0;
-                    for_exprs([&](uint32_t i, int tag, double prm_e, uint32_t comp, ushort4 f4) {
-                        const bool in = (i < net) && (comp == c);
-                        const uint32_t mk = gballot(in);
-                        const uint32_t pos = m_rows + (uint32_t)__popc(mk & below);
+                    // free variables of the component, ascending (BTreeSet order, assemble/mod.rs:91-111)
+                    // (perturbed where they are found — K0b: 2 LCG draws each, in that order)
+                    nfree = 0;
+                    bool any_var = false;
+                    for_vars([&](uint32_t i, double v, uint32_t info) {
+                        const bool member = i < nvt && (info & VAR_COMP_MASK) == c;
+                        const bool in = member && !(info & VAR_FIXED_BIT);
+                        const uint32_t m = gballot(in);
+                        const uint32_t pos = nfree + (uint32_t)__popc(m & below);
+                        if (i < nvt) colof[i] = in ? (int16_t)pos : (int16_t)-1;
+                        if (in && pos < (uint32_t)N) fidx[pos] = (uint16_t)i;
                         if (i < (uint32_t)(RS * PF)) {
-                            const int rr = in ? (int)pos : -1;
-                            if (i < (uint32_t)RS) c_row[0] = rr; else if (i < 2u * RS) c_row[1] = rr; else c_row[2] = rr;
+                            const int cc = in ? (int)pos : -1;
+                            if (i < (uint32_t)RS) c_col[0] = cc; else if (i < 2u * RS) c_col[1] = cc; else c_col[2] = cc;
                         }
-                        if (in) {
-                            uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-                            uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                            const int k = expand_vars(tag, ff, vars8);
-                            if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
-                            rtag[pos] = (uint8_t)tag;
-                            P[pos] = (T)prm_e;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                gvar[pos * 8 + e] = (uint16_t)vars8[e];
-                                gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
-                            }
+                        if (in && (prm.mode & 2u)) {
+                            uint32_t st = lcg_jump(rng, 2u * pos);
+                            st = st * 1664525u + 1013904223u;
+                            const double f1 = (1.0 / 4294967295.0) * (double)st;
+                            st = st * 1664525u + 1013904223u;
+                            const double f2 = (1.0 / 4294967295.0) * (double)st;
+                            // from the f64 input, so the f64 start point is bit-identical to the reference
+                            double x = (prm.mode & 1u) ? v * scale_recip : v;
+                            x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+                            XS[i] = (T)x;
                         }
-                        m_rows += (uint32_t)__popc(mk);
+                        nfree += (uint32_t)__popc(m);
+                        any_var = any_var || gballot(member) != 0u;
                     });
-                }
+                    if (!any_var) {
+                        c += 1;  // a component without variables is skipped by the reference (`elements.is_empty()`)
+                    } else {
+                        have_comp = true;
+                        rows_listed = true;
+                        built = true;
+                        if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
+                        group_sync();
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            const uint32_t j = (uint32_t)(hl + RS * q);
+                            my_vi[q] = (j < nfree) ? (uint32_t)fidx[j] : 0u;
+                        }
+                        // rows of the component: ascending expression id (assemble/mod.rs:139-145)
+                        m_rows = 0;
+                        for_exprs([&](uint32_t i, int tag, double prm_e, uint32_t comp, ushort4 f4) {
+                            const bool in = (i < net) && (comp == c);
+                            const uint32_t mk = gballot(in);
+                            const uint32_t pos = m_rows + (uint32_t)__popc(mk & below);
+                            if (i < (uint32_t)(RS * PF)) {
+                                const int rr = in ? (int)pos : -1;
+                                if (i < (uint32_t)RS) c_row[0] = rr; else if (i < 2u * RS) c_row[1] = rr; else c_row[2] = rr;
+                            }
+                            if (in) {
+                                uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+                                uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                                const int k = expand_vars(tag, ff, vars8);
+                                if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
+                                rtag[pos] = (uint8_t)tag;
+                                P[pos] = (T)prm_e;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    gvar[pos * 8 + e] = (uint16_t)vars8[e];
+                                    gcol[pos * 8 + e] = (e < k) ? (int8_t)colof[vars8[e]] : (int8_t)-1;
+                                }
+                            }
+                            m_rows += (uint32_t)__popc(mk);
+                        });
+                    }
                 }  // lists of a component
                 if (rows_listed) {
                     group_sync();
