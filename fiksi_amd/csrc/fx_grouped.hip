@@ -1181,9 +1181,9 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     if (!forced && b.n_systems < 8192u) return false;
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     const bool units = (p.mode & MODE_UNITS) != 0;
-    if (units && (!b.sys_unit_off || p.prof || p.lm.precision == 32)) return false;  // SinglePass here: f64
+    if (units && (!b.sys_unit_off || p.prof)) return false;
     if (p.prof && p.lm.precision == 32) return false;
-    if (grouped_columns(b, units) == 3u && (p.prof || p.lm.precision == 32)) return false;
+    if (grouped_columns(b, units) == 3u && p.prof) return false;
     if (!b.work_counter) return false;
     const size_t lds = grouped_lds_bytes(b, p.lm.precision == 32 ? 4u : 8u, units);
     // four wavefronts (16 Systems) per CU or more; two (8 Systems) for the 48-column build, whose Systems would
@@ -1195,16 +1195,21 @@ hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStre
     if (b.n_systems == 0) return hipSuccess;
     const bool units = (p.mode & MODE_UNITS) != 0;
     const uint32_t nc = grouped_columns(b, units);
+    const bool f32 = p.lm.precision == 32;
     if (units) {
+        if (f32)
+            return nc == 1u   ? launch_grouped_t<1, float, false, true>(b, p, b.work_counter, stream)
+                   : nc == 2u ? launch_grouped_t<2, float, false, true>(b, p, b.work_counter, stream)
+                              : launch_grouped_t<3, float, false, true>(b, p, b.work_counter, stream);
         return nc == 1u   ? launch_grouped_t<1, double, false, true>(b, p, b.work_counter, stream)
                : nc == 2u ? launch_grouped_t<2, double, false, true>(b, p, b.work_counter, stream)
                           : launch_grouped_t<3, double, false, true>(b, p, b.work_counter, stream);
     }
     const bool two = nc == 2u;
-    if (nc == 3u) return launch_grouped_t<3, double>(b, p, b.work_counter, stream);  // f64, no stamped build
+    if (nc == 3u) return f32 ? launch_grouped_t<3, float>(b, p, b.work_counter, stream) : launch_grouped_t<3, double>(b, p, b.work_counter, stream);
     if (p.prof) return two ? launch_grouped_t<2, double, true>(b, p, b.work_counter, stream)
                            : launch_grouped_t<1, double, true>(b, p, b.work_counter, stream);
-    if (p.lm.precision == 32)
+    if (f32)
         return two ? launch_grouped_t<2, float>(b, p, b.work_counter, stream) : launch_grouped_t<1, float>(b, p, b.work_counter, stream);
     return two ? launch_grouped_t<2, double>(b, p, b.work_counter, stream) : launch_grouped_t<1, double>(b, p, b.work_counter, stream);
 }

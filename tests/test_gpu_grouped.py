@@ -80,6 +80,12 @@ def test_forty_eight_column_build_on_the_references_bench_sketch(fiksi, oracle, 
     assert np.array_equal(r1["accepted"][:n], res_o["accepted"])
     assert np.array_equal(r1["trials"][:n], res_o["trials"])
     assert np.max(np.abs(v1[: len(v_o)] - v_o)) < 1e-8
+    # f32 (cfg5 precision): the same two kernels, the same bits
+    routing("1")
+    w1, q1 = _solve(ctx, b, f32=True)
+    routing("0")
+    w0, q0 = _solve(ctx, b, f32=True)
+    assert np.array_equal(_bits(w1), _bits(w0)) and np.array_equal(q1["trials"], q0["trials"])
 
 
 @pytest.mark.parametrize("shape", ["hinged11", "hinged5", "ring16", "mixed"])
@@ -114,6 +120,16 @@ def test_single_pass_blocks_on_the_grouped_kernel(fiksi, oracle, ctx, routing, s
         v_o, res_o = oracle.solve_single_pass_batch(sub, trial_cap=4096, nthreads=8)
         assert np.array_equal(r1["accepted"][:n], res_o["accepted"])
         assert np.max(np.abs(v1[: len(v_o)] - v_o)) < 1e-7
+        o32 = abi.solving_opts(decomposer=1, f32=True)
+        w = {}
+        for tag in ("1", "0"):
+            routing(tag)
+            db = ctx.upload(b)
+            db.system_solve(o32)
+            assert db.solve_route(o32) == int(tag)
+            w[tag] = (db.get_vars().copy(), db.get_results().copy())
+            db.free()
+        assert np.array_equal(_bits(w["1"][0]), _bits(w["0"][0])) and np.array_equal(w["1"][1]["trials"], w["0"][1]["trials"])
     else:
         assert np.array_equal(r1["scale"], r0["scale"]) and np.array_equal(r1["ncomp"], r0["ncomp"])
         same = (r1["accepted"] == r0["accepted"]) & (r1["trials"] == r0["trials"])
