@@ -1,7 +1,7 @@
 // Grouped fused solve (gfx950, wave64): FOUR Systems per wavefront, one per row of 16 lanes, for batches
 // whose components have at most 32 free variables — the headline shape (BASELINE cfg3: 32 variables /
-// 32 expressions per System) and everything smaller — and, in f64, up to 48 (the reference's own bench
-// sketch, fiksi_bench.rs:15-40: 46 variables).
+// 32 expressions per System) and everything smaller — and up to 48 (the reference's own bench sketch,
+// fiksi_bench.rs:15-40: 46 variables); Decomposer::None and SinglePass, f64 and f32.
 //
 // Same algorithm and the same arithmetic as lm_solve_kernel (fx_kernels.hip; reference:
 // fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193), reorganised around what that kernel's
