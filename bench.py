@@ -37,6 +37,8 @@ if ROOT not in sys.path:
 
 SYSTEMS_PER_GPU = 100_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X f64 vector (non-matrix) peak
+FLOPS_PER_TRIAL = 32 ** 3 / 3 + 2 * 32 ** 2 + 2 * 408 + 60 * 32  # ring16 component, see solve_kernel below
 
 
 def parse():
@@ -136,6 +138,7 @@ def main() -> int:
     converged = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))  # fiksi_bench.rs:65-72
     accepted = int(res["accepted"].sum())
     trials = int(res["trials"].sum())
+    trials_per_step = trials  # this rank's launch (the sums below are over all ranks)
 
     elapsed, (converged, accepted, trials, total_sys) = distributed.reduce_throughput(
         dist, elapsed, [converged, accepted, trials, n_sys], device=reduce_device)
@@ -209,6 +212,11 @@ def main() -> int:
                 "algorithmic_hbm_bytes_per_launch": b_solve,
                 "achieved_GBps": b_solve / (solve_ms * 1e-3) / 1e9,
                 "frac_of_hbm_peak": b_solve / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # useful f64 flops of one LM trial on a 32 x 32 component: Cholesky n^3/3, two triangular solves 2 n^2,
+                # JtJ over the triangle's 408 products, ~60 per expression row — against the f64 vector peak
+                "algorithmic_flops_per_launch": FLOPS_PER_TRIAL * trials_per_step,
+                "achieved_TFLOPs": FLOPS_PER_TRIAL * trials_per_step / (solve_ms * 1e-3) / 1e12,
+                "frac_of_f64_vector_peak": FLOPS_PER_TRIAL * trials_per_step / (solve_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
                 "note": "latency/f64-VALU bound by construction (~14 kflop per LM trial on a serial "
                         "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d). "
                         "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead",
