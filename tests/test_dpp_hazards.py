@@ -30,6 +30,11 @@ def test_the_scan_flags_a_hazard(tmp_path):
     bad.write_text("\tv_mul_f64 v[4:5], v[0:1], v[2:3]\n\tv_fmac_f64_dpp v[8:9], -v[4:5], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
     ok = tmp_path / "ok.s"
     ok.write_text("\tv_mul_f64 v[4:5], v[0:1], v[2:3]\n\ts_nop 1\n\tv_fmac_f64_dpp v[8:9], -v[4:5], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    # the write reaches the DPP read along a taken branch only (one wait state: the branch itself)
+    jump = tmp_path / "jump.s"
+    jump.write_text("\tv_mul_f64 v[4:5], v[0:1], v[2:3]\n\ts_cbranch_execz .L1\n\tv_mov_b32_e32 v9, v8\n\ts_nop 1\n.L1:\n"
+                    "\tv_fmac_f64_dpp v[8:9], -v[4:5], v[2:3] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
     tool = os.path.join(ROOT, "tools", "check_dpp_hazards.py")
     assert subprocess.run([sys.executable, tool, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([sys.executable, tool, str(jump)], capture_output=True).returncode == 1
     assert subprocess.run([sys.executable, tool, str(ok)], capture_output=True).returncode == 0
