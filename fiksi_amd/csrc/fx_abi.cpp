@@ -12,6 +12,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "fx_decompose.h"
@@ -46,6 +47,7 @@ struct HostPlan {
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
     uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0, max_pairs_tri = 0;
     uint32_t uniform = 0;  // every System has the same structure (one sketch, many parameter sets)
+    std::vector<uint32_t> sys_class;  // not uniform: the first System with this System's structure (empty: not computed)
     std::vector<uint16_t> sys_ncomp;
     std::vector<uint8_t> sys_large;  // 0 fused kernel, 2 wide kernel (65..128 free variables), 1 sparse path
     uint32_t n_large = 0;            // Systems with sys_large != 0
@@ -401,6 +403,60 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                    memcmp(&p.expr_idx16[4 * (size_t)s * ne0], &p.expr_idx16[0], 4 * (size_t)ne0 * sizeof(uint16_t)) == 0;
         }
         p.uniform = same ? 1u : 0u;
+    }
+    // Not one structure, but a batch the grouped kernel will take: the structure classes (a few sketches, each with
+    // many parameter sets, is the other common batch). Class = first System with the same sizes, components, fixed
+    // flags, kinds and element fields: found by a 64-bit hash of those arrays, confirmed by comparing them.
+    if (!p.uniform && n >= 8192 && p.max_free > 0 && p.max_free <= 48) {
+        auto slices = [&](uint32_t s, const void* ptr[4], size_t len[4]) {
+            const uint32_t v0 = b->var_off[s], nvs = b->var_off[s + 1] - v0, e0 = b->expr_off[s], nes = b->expr_off[s + 1] - e0;
+            ptr[0] = &p.var_info[v0];            len[0] = nvs * sizeof(uint16_t);
+            ptr[1] = &p.expr_tagx[e0];           len[1] = nes;
+            ptr[2] = &p.expr_comp[e0];           len[2] = nes * sizeof(uint16_t);
+            ptr[3] = &p.expr_idx16[4 * (size_t)e0]; len[3] = 4 * (size_t)nes * sizeof(uint16_t);
+        };
+        std::vector<uint64_t> hash(n);
+        parallel_ranges(n, (uint64_t)nv + ne, [&](uint32_t, uint32_t lo, uint32_t hi) {
+            for (uint32_t s = lo; s < hi; ++s) {
+                const void* ptr[4];
+                size_t len[4];
+                slices(s, ptr, len);
+                uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)len[0] << 32) ^ len[1];
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned char* q = static_cast<const unsigned char*>(ptr[k]);
+                    size_t i = 0;
+                    for (; i + 8 <= len[k]; i += 8) {
+                        uint64_t w;
+                        memcpy(&w, q + i, 8);
+                        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+                        h ^= h >> 29;
+                    }
+                    uint64_t w = 0;
+                    if (i < len[k]) memcpy(&w, q + i, len[k] - i);
+                    h = (h ^ w ^ (uint64_t)k) * 0xC4CEB9FE1A85EC53ull;
+                    h ^= h >> 32;
+                }
+                hash[s] = h;
+            }
+        });
+        std::unordered_map<uint64_t, uint32_t> first;
+        first.reserve(1024);
+        p.sys_class.resize(n);
+        for (uint32_t s = 0; s < n; ++s) {
+            auto it = first.find(hash[s]);
+            if (it == first.end()) {
+                first.emplace(hash[s], s);
+                p.sys_class[s] = s;
+                continue;
+            }
+            const void *pa[4], *pb[4];
+            size_t la[4], lb[4];
+            slices(s, pa, la);
+            slices(it->second, pb, lb);
+            bool eq = true;
+            for (int k = 0; eq && k < 4; ++k) eq = la[k] == lb[k] && memcmp(pa[k], pb[k], la[k]) == 0;
+            p.sys_class[s] = eq ? it->second : s;  // (a colliding hash: the System is its own class)
+        }
     }
     // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
     const uint32_t nblk = (ne + 255u) / 256u;
@@ -1101,6 +1157,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
+    if (!p.sys_class.empty()) FX_UP(sys_class, p.sys_class.data(), p.n_systems)
     FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
 #undef FX_UP
     size_t packed = 0;

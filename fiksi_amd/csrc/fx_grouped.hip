@@ -372,6 +372,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     // takes and kept for the following ones — only values change. Per lane: the column of variable hl + 16 k and
     // the row of expression hl + 16 k (or -1).
     bool built = false;
+    uint32_t cls = 0xFFFFFFFFu, built_cls = 0xFFFFFFFFu;  // structure class of the System / of the System the lists are from
     int c_col[3] = {-1, -1, -1}, c_row[3] = {-1, -1, -1};
 
     // The System's own arrays, fetched in one round trip when the row takes the System: lane r keeps
@@ -572,6 +573,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     e0 = b.expr_off[s];
                     net = b.expr_off[s + 1] - e0;
                     ncomp = b.sys_ncomp[s];
+                    cls = b.sys_class ? b.sys_class[s] : 0xFFFFFFFFu;
                 }
                 if constexpr (UNITS) {
                     unit0 = b.sys_unit_off[s];
@@ -633,7 +635,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
         // ================= COMP: set up component (SinglePass: block) c =================
         if (phase == GP_COMP) {
             if (c < ncomp) {
-                const bool reuse = !UNITS && b.uniform != 0u && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
+                const bool reuse = !UNITS && (b.uniform != 0u || (cls != 0xFFFFFFFFu && cls == built_cls)) && built && ncomp == 1u && nvt <= (uint32_t)(RS * PF) && net <= (uint32_t)(RS * PF);
                 if (reuse) {
                     // same structure as the System before: perturb and re-scale the parameters, nothing else
 #pragma unroll
@@ -768,6 +770,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         have_comp = true;
                         rows_listed = true;
                         built = true;
+                        built_cls = cls;
                         if (prm.mode & 2u) rng = lcg_jump(rng, 2u * nfree);
                         group_sync();
 #pragma unroll

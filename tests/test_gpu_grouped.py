@@ -219,6 +219,31 @@ def test_shared_structure_is_detected_per_batch_not_assumed(fiksi, ctx, routing)
         assert np.array_equal(r1["trials"], r0["trials"])
 
 
+def test_structure_classes_of_a_batch_of_several_sketches(fiksi, ctx, routing):
+    """Batches of 8192 Systems and more that are not of one structure get a structure class per System (the first
+    System with the same sizes, flags, kinds and fields); a row keeps its lists while the class stays the same.
+    Three sketches interleaved in runs of different lengths: the bits of the one-System-per-wavefront kernel."""
+    from fiksi_amd import workloads
+
+    a, g, h = workloads.ring16(7000), workloads.ring16(900, fix_gauge=True), workloads.hinged_triangles(500, 5)
+    parts = []
+    for k in range(100):
+        parts += [workloads.shard(a, k, 100), workloads.shard(g, k, 100), workloads.shard(h, k, 100)]
+    b = workloads.concat(parts)
+    assert len(b["var_off"]) - 1 == 8400
+    routing(None)  # the default routing takes it
+    db = ctx.upload(b)
+    assert db.solve_route() == 1
+    db.free()
+    v1, r1 = _solve(ctx, b)
+    routing("0")
+    v0, r0 = _solve(ctx, b)
+    assert np.array_equal(_bits(v1), _bits(v0))
+    for f in r1.dtype.names:
+        x, y = r1[f], r0[f]
+        assert np.array_equal(_bits(x), _bits(y)) if x.dtype.kind == "f" else np.array_equal(x, y), f
+
+
 def _anchored_sketch(seed):
     """20 fixed anchor points and 10 free ones tied to them (and three pairs to each other): 60 variables — past
     the 48 a lane row keeps in registers —, 20 free ones, 28 expressions, fixed values that must come back untouched."""
