@@ -32,7 +32,8 @@ _FIELDS = {
 
 
 def normalize_batch(arrays: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    """Contiguous arrays of the ABI dtypes, keyed by the fx_batch field names."""
+    """Contiguous arrays of the ABI dtypes, keyed by the fx_batch field names. The C side trusts the
+    pointers it is given, so the lengths are checked against the offsets here (ValueError otherwise)."""
     out = {}
     for k, dt in _FIELDS.items():
         a = arrays.get(k)
@@ -41,6 +42,13 @@ def normalize_batch(arrays: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
                 continue
             raise KeyError(f"batch is missing {k}")
         out[k] = np.ascontiguousarray(a, dtype=dt)
+    if len(out["var_off"]) < 1 or len(out["var_off"]) != len(out["expr_off"]):
+        raise ValueError("var_off and expr_off need n_systems + 1 entries each (at least one)")
+    nv, ne = int(out["var_off"][-1]), int(out["expr_off"][-1])
+    want = {"vars": nv, "var_fixed": nv, "var_comp": nv, "expr_tag": ne, "expr_param": ne, "expr_comp": ne, "expr_idx": 4 * ne}
+    for k, n in want.items():
+        if k in out and len(out[k]) != n:
+            raise ValueError(f"{k} has {len(out[k])} entries, the offsets say {n}")
     return out
 
 
@@ -122,6 +130,24 @@ def single_pass_blocks(arrays, system: int = 0):
                                     _ptr(var_off), _ptr(vs)), "fx_single_pass_blocks")
     return [(int(comp[k]), rows[row_off[k]:row_off[k + 1]].tolist(), vs[var_off[k]:var_off[k + 1]].tolist())
             for k in range(nb.value)]
+
+
+def qr_symbolic(nrows: int, ncols: int, colptr, rowidx, colamd: bool = True):
+    """SymbolicQr::build on a column pattern (host-side, no GPU needed): dict with col_perm, row_perm,
+    h_ptr / h_rows (Householder vectors) and r_ptr / r_rows (columns of R)."""
+    cp = np.ascontiguousarray(colptr, dtype=np.int32)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int32)
+    col_perm = np.zeros(ncols, dtype=np.int32)
+    row_perm = np.zeros(nrows, dtype=np.int32)
+    h_ptr = np.zeros(ncols + 1, dtype=np.int32)
+    r_ptr = np.zeros(ncols + 1, dtype=np.int32)
+    h_cap, r_cap = nrows * ncols + 1, ncols * (ncols + 1) // 2 + 1
+    h_rows = np.zeros(h_cap, dtype=np.int32)
+    r_rows = np.zeros(r_cap, dtype=np.int32)
+    check(lib.fx_qr_symbolic(nrows, ncols, _ptr(cp), _ptr(ri), 1 if colamd else 0, _ptr(col_perm), _ptr(row_perm),
+                             _ptr(h_ptr), _ptr(h_rows), h_cap, _ptr(r_ptr), _ptr(r_rows), r_cap), "fx_qr_symbolic")
+    return dict(col_perm=col_perm, row_perm=row_perm, h_ptr=h_ptr, h_rows=h_rows[: h_ptr[-1]].copy(), r_ptr=r_ptr,
+                r_rows=r_rows[: r_ptr[-1]].copy())
 
 
 class Context:

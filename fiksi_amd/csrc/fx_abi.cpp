@@ -18,6 +18,7 @@
 #include "fx_decompose.h"
 #include "fx_device.h"
 #include "fx_expr.h"
+#include "fx_qrplan.h"
 #include "fx_sparse.h"
 
 namespace {
@@ -549,6 +550,7 @@ struct fx_dbatch {
     fx::DeviceBatch comp_walk{};
     bool comp_walk_built = false;
     std::vector<uint8_t> h_comp_walk;  // per System: 1 = walked on the device
+    uint32_t n_units = 0, n_unit_rows = 0, n_unit_vars = 0;  // sizes of the SinglePass block arrays on the device
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -793,7 +795,233 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     d.max_unit_rows = max_unit_rows;
     if (fx::solve_lds_bytes_units(d) > 160u * 1024u)
         return fail(FX_ERR_TOO_LARGE, "SinglePass blocks need %zu bytes of LDS per wavefront (limit 163840)", fx::solve_lds_bytes_units(d));
+    db->n_units = (uint32_t)desc.size();
+    db->n_unit_rows = (uint32_t)unit_rows.size();
+    db->n_unit_vars = (uint32_t)unit_vars.size();
     d.sys_unit_off = off;  // set last: marks the plan as complete
+    return FX_OK;
+}
+
+// ---- FX_STEP_QR: plans of the reference's sparse QR (fx_qrplan.h) ---------------------------------------
+// One component (or SinglePass block) of one System: rows = its expressions in row order, free = its free
+// variables in column order (both system-local). The pattern of the augmented matrix [J; sqrt(lambda) I] as
+// lm.rs:81-98 builds it: column c holds the rows that read free[c] (ascending, an expression reading it twice
+// once) and, last, the damping row m + c.
+struct QrHostPlan {
+    uint32_t n = 0, m = 0;
+    std::vector<uint16_t> u16;  // colperm[n], rowperm[m + n], hptr[n + 1], hrows[nnzh]
+    std::vector<uint64_t> u64;  // colmask[n], rowmask[n]
+    uint32_t nnzh = 0;
+    bool ok = false;
+};
+
+bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const uint32_t* rows, uint32_t m, const uint32_t* free_,
+                   uint32_t n, uint32_t nvt, QrHostPlan& out) {
+    out = QrHostPlan();
+    out.n = n;
+    out.m = m;
+    if (n == 0 || n > 64u) return false;
+    std::vector<int32_t> colof(nvt, -1);
+    for (uint32_t c = 0; c < n; ++c) colof[free_[c]] = (int32_t)c;
+    std::vector<std::vector<int>> cols(n);
+    for (uint32_t r = 0; r < m; ++r) {
+        uint32_t vars8[8];
+        const int k = fx::expand_vars((int)(expr_tag[rows[r]] & 0x7F), expr_idx16 + 4 * (size_t)rows[r], vars8);
+        for (int q = 0; q < k; ++q) {
+            const int32_t c = vars8[q] < nvt ? colof[vars8[q]] : -1;
+            if (c >= 0 && (cols[c].empty() || cols[c].back() != (int)r)) cols[c].push_back((int)r);
+        }
+    }
+    fx::qr::Csc a;
+    a.nrows = (int)(m + n);
+    a.ncols = (int)n;
+    a.ptr.assign(1, 0);
+    for (uint32_t c = 0; c < n; ++c) {
+        a.idx.insert(a.idx.end(), cols[c].begin(), cols[c].end());
+        a.idx.push_back((int)(m + c));
+        a.ptr.push_back((int)a.idx.size());
+    }
+    fx::qr::Symbolic sy;
+    if (!fx::qr::analyze(a, true, sy)) return false;
+    if (sy.hrows.size() > 0xFFFFu) return false;
+    out.nnzh = (uint32_t)sy.hrows.size();
+    out.u16.reserve(n + (m + n) + (n + 1) + sy.hrows.size());
+    for (uint32_t j = 0; j < n; ++j) out.u16.push_back((uint16_t)sy.col_perm[j]);
+    for (uint32_t i = 0; i < m + n; ++i) out.u16.push_back((uint16_t)sy.row_perm[i]);
+    for (uint32_t j = 0; j <= n; ++j) out.u16.push_back((uint16_t)sy.hptr[j]);
+    for (int r : sy.hrows) out.u16.push_back((uint16_t)r);
+    out.u64.assign(2 * (size_t)n, 0);
+    for (uint32_t j = 0; j < n; ++j)
+        for (int p = sy.rptr[j]; p < sy.rptr[j + 1] - 1; ++p) {
+            const uint32_t k = (uint32_t)sy.rrows[p];
+            out.u64[j] |= 1ull << k;
+            out.u64[n + k] |= 1ull << j;
+        }
+    out.ok = true;
+    return true;
+}
+
+// Builds (once per resident batch and decomposer) the QR plans of every System the one-wavefront kernel takes.
+// Systems of one structure share a plan: a batch of one sketch with many parameter sets is analysed once.
+int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
+    fx::DeviceBatch& d = db->d;
+    fx::QrPlans& Q = units ? d.qr_units : d.qr_none;
+    if (Q.desc) return FX_OK;
+    const uint32_t n = d.n_systems;
+    std::vector<uint32_t> var_off((size_t)n + 1), expr_off((size_t)n + 1), sys_class;
+    std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs), expr_comp(d.n_exprs), sys_ncomp(n);
+    std::vector<uint8_t> expr_tag(d.n_exprs), sys_large(n);
+    std::vector<uint32_t> sys_unit_off, unit_rows;
+    std::vector<fx::UnitDesc> unit_desc;
+    std::vector<uint16_t> unit_vars;
+    FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_exprs) {
+        FX_HIP(hipMemcpyAsync(expr_idx.data(), d.expr_idx, expr_idx.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(expr_tag.data(), d.expr_tag, expr_tag.size(), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(expr_comp.data(), d.expr_comp, expr_comp.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n) {
+        FX_HIP(hipMemcpyAsync(sys_large.data(), d.sys_large, n, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
+        if (d.sys_class && !units) {
+            sys_class.resize(n);
+            FX_HIP(hipMemcpyAsync(sys_class.data(), d.sys_class, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    if (units) {
+        if (!d.sys_unit_off) return fail(FX_ERR_INVALID, "internal: SinglePass blocks are not built yet");
+        sys_unit_off.resize((size_t)n + 1);
+        unit_desc.resize(db->n_units);
+        unit_rows.resize(db->n_unit_rows);
+        unit_vars.resize(db->n_unit_vars);
+        FX_HIP(hipMemcpyAsync(sys_unit_off.data(), d.sys_unit_off, sys_unit_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (db->n_units) FX_HIP(hipMemcpyAsync(unit_desc.data(), d.unit_desc, unit_desc.size() * sizeof(fx::UnitDesc), hipMemcpyDeviceToHost, ctx->stream));
+        if (db->n_unit_rows) FX_HIP(hipMemcpyAsync(unit_rows.data(), d.unit_rows, unit_rows.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (db->n_unit_vars) FX_HIP(hipMemcpyAsync(unit_vars.data(), d.unit_vars, unit_vars.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+
+    // which System's analysis a System uses (itself, System 0 of a uniform batch, or its structure class)
+    auto owner = [&](uint32_t s) -> uint32_t {
+        if (units) return s;  // blocks are indexed per block
+        if (d.uniform) return 0u;
+        if (!sys_class.empty()) return sys_class[s];
+        return s;
+    };
+    struct Range {
+        std::vector<fx::QrDesc> desc;
+        std::vector<uint16_t> u16;
+        std::vector<uint64_t> u64;
+        std::vector<uint32_t> sys_first;  // per System of the range: its first desc (relative), or UINT32_MAX when it has none
+        uint32_t s_lo = 0, max_m = 0, max_h = 0;
+        bool failed = false;
+    } ranges[MAX_RANGES];
+    uint32_t n_ranges = 1;
+    parallel_ranges(n, (uint64_t)d.n_exprs * 64, [&](uint32_t t, uint32_t s_lo, uint32_t s_hi) {
+        Range& R = ranges[t];
+        R.s_lo = s_lo;
+        R.sys_first.assign(s_hi - s_lo, 0xFFFFFFFFu);
+        std::vector<uint32_t> rows, free_;
+        QrHostPlan hp;
+        auto emit = [&](const uint32_t* rw, uint32_t m, const uint32_t* fr, uint32_t nf, uint32_t s) {
+            const uint32_t e0 = expr_off[s], nvt = var_off[s + 1] - var_off[s];
+            fx::QrDesc qd{};
+            qd.u16_off = (uint32_t)R.u16.size();
+            qd.u64_off = (uint32_t)R.u64.size();
+            qd.n = (uint16_t)nf;
+            qd.m = (uint16_t)m;
+            if (nf > 0 && build_qr_plan(expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0, rw, m, fr, nf, nvt, hp)) {
+                qd.nnzh = (uint16_t)hp.nnzh;
+                qd.ok = 1;
+                R.u16.insert(R.u16.end(), hp.u16.begin(), hp.u16.end());
+                R.u64.insert(R.u64.end(), hp.u64.begin(), hp.u64.end());
+                R.max_m = std::max(R.max_m, m + nf);
+                R.max_h = std::max(R.max_h, hp.nnzh);
+            } else if (nf > 0) {
+                R.failed = true;
+            }
+            R.desc.push_back(qd);
+        };
+        for (uint32_t s = s_lo; s < s_hi; ++s) {
+            if (sys_large[s] || owner(s) != s) continue;
+            R.sys_first[s - s_lo] = (uint32_t)R.desc.size();
+            const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0, e0 = expr_off[s], net = expr_off[s + 1] - e0;
+            if (units) {
+                for (uint32_t u = sys_unit_off[s]; u < sys_unit_off[s + 1]; ++u) {
+                    const fx::UnitDesc& ud = unit_desc[u];
+                    rows.assign(unit_rows.begin() + ud.row_off, unit_rows.begin() + ud.row_off + ud.nrows);
+                    free_.clear();
+                    for (uint32_t k = 0; k < ud.nvars; ++k) free_.push_back(unit_vars[ud.var_off + k]);
+                    emit(rows.data(), ud.nrows, free_.data(), (ud.flags & fx::UNIT_EMPTY) ? 0u : ud.nvars, s);
+                }
+            } else {
+                for (uint32_t c = 0; c < sys_ncomp[s]; ++c) {
+                    rows.clear();
+                    free_.clear();
+                    for (uint32_t i = 0; i < nvt; ++i) {
+                        const uint16_t info = var_info[v0 + i];
+                        if ((info & fx::VAR_COMP_MASK) == c && !(info & fx::VAR_FIXED_BIT)) free_.push_back(i);
+                    }
+                    for (uint32_t i = 0; i < net; ++i)
+                        if (expr_comp[e0 + i] == c) rows.push_back(i);
+                    emit(rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), s);
+                }
+            }
+        }
+    }, &n_ranges);
+    std::vector<fx::QrDesc> desc;
+    std::vector<uint16_t> u16;
+    std::vector<uint64_t> u64;
+    std::vector<uint32_t> sys_first(n, 0);
+    uint32_t max_m = 0, max_h = 0;
+    for (uint32_t t = 0; t < n_ranges; ++t) {
+        Range& R = ranges[t];
+        if (R.failed) return fail(FX_ERR_UNSUPPORTED, "FX_STEP_QR: the symbolic analysis of a component failed (more than 64 columns or a malformed pattern)");
+        const uint32_t dbase = (uint32_t)desc.size(), b16 = (uint32_t)u16.size(), b64 = (uint32_t)u64.size();
+        for (fx::QrDesc qd : R.desc) {
+            qd.u16_off += b16;
+            qd.u64_off += b64;
+            desc.push_back(qd);
+        }
+        u16.insert(u16.end(), R.u16.begin(), R.u16.end());
+        u64.insert(u64.end(), R.u64.begin(), R.u64.end());
+        for (size_t k = 0; k < R.sys_first.size(); ++k)
+            if (R.sys_first[k] != 0xFFFFFFFFu) sys_first[R.s_lo + k] = dbase + R.sys_first[k];
+        max_m = std::max(max_m, R.max_m);
+        max_h = std::max(max_h, R.max_h);
+    }
+    std::vector<uint32_t> index;
+    if (units) {  // one desc per block, in block order
+        index.assign(db->n_units, 0);
+        for (uint32_t s = 0; s < n; ++s) {
+            if (sys_large[s]) continue;
+            for (uint32_t u = sys_unit_off[s]; u < sys_unit_off[s + 1]; ++u) index[u] = sys_first[s] + (u - sys_unit_off[s]);
+        }
+    } else {
+        index.assign(n, 0);
+        for (uint32_t s = 0; s < n; ++s) index[s] = sys_first[owner(s)];
+    }
+    fx::QrPlans q;
+    unsigned long long* d64 = nullptr;
+    int rc = dev_alloc_copy(ctx, db, &q.u16, u16.data(), u16.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d64, reinterpret_cast<const unsigned long long*>(u64.data()), u64.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &q.index, index.data(), index.size());
+    fx::QrDesc* ddesc = nullptr;
+    if (!rc) rc = dev_alloc_copy(ctx, db, &ddesc, desc.data(), desc.size());
+    if (rc) return rc;
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    q.u64 = d64;
+    q.max_m = max_m;
+    q.max_h = max_h;
+    q.desc = ddesc;  // set last: marks the plans as complete
+    Q = q;
+    if (fx::solve_lds_bytes_qr(d, units) > 160u * 1024u) {
+        Q.desc = nullptr;
+        return fail(FX_ERR_TOO_LARGE, "FX_STEP_QR keeps the (expressions + free variables) x (free variables + 1) matrix of a component in LDS: %zu bytes needed (limit 163840)",
+                    fx::solve_lds_bytes_qr(d, units));
+    }
     return FX_OK;
 }
 
@@ -1307,6 +1535,7 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs runs in f64 only");
 
     if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
+    if (o.lm.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", o.lm.solver);
     fx::LmParams p;
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u);
@@ -1315,7 +1544,13 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         if (rc) return rc;
         p.mode |= fx::MODE_UNITS;
     }
+    if (p.lm.solver == FX_STEP_QR) {
+        if (o.optimizer != 0 || p.lm.precision == 32) return fail(FX_ERR_UNSUPPORTED, "FX_STEP_QR is the f64 Levenberg-Marquardt step");
+        rc = ensure_qr_plans(ctx, db, o.decomposer == 1);
+        if (rc) return rc;
+    }
     FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
     return solve_large_systems(ctx, db, p);
 }
 
@@ -1326,7 +1561,14 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     fx::LmParams p;
     if (opts) p.lm = *opts; else fx_lm_opts_default(&p.lm);
     p.mode = 0;
+    if (p.lm.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", p.lm.solver);
+    if (p.lm.solver == FX_STEP_QR) {
+        if (p.lm.precision == 32) return fail(FX_ERR_UNSUPPORTED, "FX_STEP_QR is the f64 Levenberg-Marquardt step");
+        rc = ensure_qr_plans(ctx, db, false);
+        if (rc) return rc;
+    }
     FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
     return solve_large_systems(ctx, db, p);
 }
 
@@ -1519,6 +1761,28 @@ int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_bl
         }
     }
     if (n_blocks) *n_blocks = nb;
+    return FX_OK;
+}
+
+int fx_qr_symbolic(int32_t nrows, int32_t ncols, const int32_t* colptr, const int32_t* rowidx, int use_colamd,
+                   int32_t* col_perm, int32_t* row_perm, int32_t* h_ptr, int32_t* h_rows, int32_t h_cap, int32_t* r_ptr,
+                   int32_t* r_rows, int32_t r_cap) {
+    if (nrows < 0 || ncols < 0 || !colptr || (colptr[ncols] > 0 && !rowidx)) return fail(FX_ERR_INVALID, "bad argument");
+    fx::qr::Csc a;
+    a.nrows = nrows;
+    a.ncols = ncols;
+    a.ptr.assign(colptr, colptr + ncols + 1);
+    a.idx.assign(rowidx, rowidx + colptr[ncols]);
+    fx::qr::Symbolic sy;
+    if (!fx::qr::analyze(a, use_colamd != 0, sy)) return fail(FX_ERR_INVALID, "malformed or structurally rank-deficient pattern");
+    if ((h_rows && (int64_t)sy.hrows.size() > h_cap) || (r_rows && (int64_t)sy.rrows.size() > r_cap))
+        return fail(FX_ERR_INVALID, "output capacity too small (%zu / %zu entries needed)", sy.hrows.size(), sy.rrows.size());
+    if (col_perm) std::copy(sy.col_perm.begin(), sy.col_perm.end(), col_perm);
+    if (row_perm) std::copy(sy.row_perm.begin(), sy.row_perm.end(), row_perm);
+    if (h_ptr) std::copy(sy.hptr.begin(), sy.hptr.end(), h_ptr);
+    if (h_rows) std::copy(sy.hrows.begin(), sy.hrows.end(), h_rows);
+    if (r_ptr) std::copy(sy.rptr.begin(), sy.rptr.end(), r_ptr);
+    if (r_rows) std::copy(sy.rrows.begin(), sy.rrows.end(), r_rows);
     return FX_OK;
 }
 

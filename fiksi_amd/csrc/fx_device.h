@@ -32,6 +32,23 @@ constexpr uint16_t UNIT_FIRST = 1;  // first block of its component: the compone
 constexpr uint16_t UNIT_EMPTY = 2;  // placeholder of a component without any block
 constexpr uint16_t UNIT_RESTORE = 4;  // the block is a whole component of Decomposer::None: afterwards the working vector goes
                                       // back to the pre-solve snapshot (quirk Q2) instead of taking the solved values
+// Reference-numerics LM step (FX_STEP_QR): what the host's symbolic analysis (fx_qrplan.h) hands the kernel for one
+// component / SinglePass block. u16 blob at u16_off: colperm[n] (position -> free column), rowperm[m + n] (row of the
+// augmented matrix [J; sqrt(lambda) I] -> permuted row), hptr[n + 1], hrows[nnzh] (rows of Householder vector k,
+// ascending, first = k). u64 blob at u64_off: colmask[n] (bit k: vector k touches the column at position j),
+// rowmask[n] (bit j: R[k][j] is structurally non-zero, j > k).
+struct QrDesc {
+    uint32_t u16_off, u64_off;
+    uint16_t n, m, nnzh, ok;
+};
+struct QrPlans {
+    QrDesc* desc = nullptr;
+    uint16_t* u16 = nullptr;
+    unsigned long long* u64 = nullptr;
+    uint32_t* index = nullptr;  // Decomposer::None: [n_systems] first desc of the System (+ component); SinglePass: [units] desc of the block
+    uint32_t max_m = 0;         // rows of the largest augmented matrix (expressions + free variables)
+    uint32_t max_h = 0;         // entries of the largest Householder structure
+};
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
@@ -94,6 +111,8 @@ struct DeviceBatch {
     double* g_xs;             // [2 * total] working variables, two halves per System
     double* g_vout;           // [total] unscaled output values
     int16_t* g_colof;         // [total] variable -> free column of the block in flight
+    // FX_STEP_QR plans, built on first use (null until then)
+    QrPlans qr_none, qr_units;
 };
 
 struct LmParams {
@@ -119,6 +138,7 @@ hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_
 size_t wide_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes_units(const DeviceBatch& b);
+size_t solve_lds_bytes_qr(const DeviceBatch& b, bool units);
 size_t analyze_lds_bytes(uint32_t max_vars, uint32_t max_exprs);
 hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_vars, uint32_t max_exprs,
                           uint8_t* dependent, hipStream_t stream);

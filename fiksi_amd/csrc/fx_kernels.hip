@@ -31,11 +31,14 @@ struct SolveLayout {
     uint32_t off_xs, off_a, off_rhs, off_g, off_r, off_p, off_gvar, off_gcol, off_rtag, off_fidx, off_colof, off_vout;
     uint32_t off_pw, off_pe;  // packed work lists of the normal-equation assembly
     uint32_t pw_cap, pe_cap;  // their capacities in entries (0: the row-by-row assembly is used)
+    uint32_t off_qx, off_qp, off_qs;  // FX_STEP_QR: augmented matrix, plan (u16), per-vector scalars
+    uint32_t qr_m, qr_h;              // its row / Householder-entry capacities (0: not a QR launch)
     uint32_t total;
 };
 
 static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_rows, uint32_t es /* sizeof(T) */,
-                               bool lbfgs = false, uint32_t max_pairs = 0, uint32_t max_ents = 0) {
+                               bool lbfgs = false, uint32_t max_pairs = 0, uint32_t max_ents = 0, uint32_t qr_m = 0,
+                               uint32_t qr_h = 0) {
     SolveLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -64,6 +67,13 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     L.pe_cap = packed ? ((max_ents + 63u) & ~63u) : 0u;
     L.off_pw = take(L.pw_cap * 4u);
     L.off_pe = take(L.pe_cap * 4u);
+    // FX_STEP_QR: the dense (rows + columns) x (columns + 1) augmented matrix [J | -r; sqrt(lambda) I | 0] in the
+    // permuted order, the component's plan, v0 / beta of every Householder vector
+    L.qr_m = qr_m;
+    L.qr_h = qr_h;
+    L.off_qx = take(qr_m * (n_pad + 1u) * 8u);
+    L.off_qp = take(qr_m ? (qr_m + (n_pad + 1u) + qr_h + n_pad) * 2u : 0u);
+    L.off_qs = take(qr_m ? 2u * n_pad * 8u : 0u);
     L.total = o;
     return L;
 }
@@ -75,6 +85,11 @@ static uint32_t pad_n(uint32_t max_free) {
 
 size_t solve_lds_bytes(const DeviceBatch& b) {
     return make_layout(pad_n(b.max_free), b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents).total;
+}
+size_t solve_lds_bytes_qr(const DeviceBatch& b, bool units) {
+    const QrPlans& Q = units ? b.qr_units : b.qr_none;
+    const uint32_t rows = (units && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
+    return make_layout(pad_n(units ? b.max_unit_free : b.max_free), b.max_vars, rows, 8u, false, b.max_pairs, b.max_ents, Q.max_m, Q.max_h).total;
 }
 size_t solve_lds_bytes_units(const DeviceBatch& b) {
     return make_layout(pad_n(b.max_unit_free), b.max_vars, b.max_rows > b.max_unit_rows ? b.max_rows : b.max_unit_rows, 8u, false,
@@ -386,6 +401,157 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
             __syncthreads();
         }
 
+        // ---- FX_STEP_QR (reference numerics): the component's plan from the host's symbolic analysis ----
+        // The LM step is then the reference's own computation, operation by operation: Householder QR of the
+        // augmented matrix [J; sqrt(lambda) I] in the reference's column order (COLAMD) and row order (Davis 5.3),
+        // every inner product summed over the Householder vector's rows in ascending order, multiplications
+        // and additions unfused (solvi/src/decomposition/sparse/qr.rs:226-356). The matrix is kept dense in LDS,
+        // one column per lane; entries outside the symbolic patterns are exact zeros that no operation reads.
+        constexpr bool QR_BUILD = sizeof(T) == 8 && OPT == 0 && !GLOBAL && !PROF;
+        const bool qr = QR_BUILD && o.solver == FX_STEP_QR && L.qr_m != 0u;
+        constexpr uint32_t LDX = (uint32_t)N + 1u;
+        double* QX = reinterpret_cast<double*>(smem + L.off_qx);           // [m + n][LDX]
+        uint16_t* q_rowperm = reinterpret_cast<uint16_t*>(smem + L.off_qp);  // [qr_m]
+        uint16_t* q_hptr = q_rowperm + L.qr_m;                                // [N + 1]
+        uint16_t* q_hrows = q_hptr + (N + 1);                                 // [qr_h]
+        uint16_t* q_cpos = q_hrows + L.qr_h;                                  // [N] free column -> position
+        double* QV0 = reinterpret_cast<double*>(smem + L.off_qs);             // [N] first entry of vector k
+        double* QBETA = QV0 + N;                                              // [N]
+        unsigned long long q_colmask = 0ull, q_rowmask = 0ull;
+        uint32_t q_cp = 0;
+        bool qr_bad_plan = false;
+        if constexpr (QR_BUILD) {
+            if (qr) {
+                const QrPlans& Q = UNITS ? b.qr_units : b.qr_none;
+                const QrDesc qd = Q.desc[UNITS ? Q.index[unit0 + c] : Q.index[s] + c];
+                qr_bad_plan = !qd.ok || qd.n != nfree || qd.m != m_rows || (uint32_t)qd.m + qd.n > L.qr_m || qd.nnzh > L.qr_h;
+                if (!qr_bad_plan) {
+                    const uint16_t* pu = Q.u16 + qd.u16_off;
+                    const unsigned long long* pm = Q.u64 + qd.u64_off;
+                    const uint32_t Mq = m_rows + nfree;
+                    if ((uint32_t)lane < nfree) {
+                        q_cp = pu[lane];
+                        q_cpos[q_cp] = (uint16_t)lane;
+                        q_colmask = pm[lane];
+                        q_rowmask = pm[nfree + lane];
+                    }
+                    for (uint32_t i = lane; i < Mq; i += 64) q_rowperm[i] = pu[nfree + i];
+                    for (uint32_t i = lane; i <= nfree; i += 64) q_hptr[i] = pu[nfree + Mq + i];
+                    for (uint32_t i = lane; i < qd.nnzh; i += 64) q_hrows[i] = pu[nfree + Mq + nfree + 1u + i];
+                    __syncthreads();
+                }
+            }
+        }
+        // sum of squares in index order (lm.rs:195-197): every lane adds the same numbers in the same order
+        auto seq_sse_lm = [&](int buf) -> double {
+            double acc = 0.0;
+            for (uint32_t row = 0; row < m_rows; ++row) {
+                const double r = (double)R[buf * mr + row];
+                acc += r * r;
+            }
+            return bcast(acc, 0);
+        };
+        // One LM trial's step by the reference's QR. Returns false when R has an exactly zero diagonal entry
+        // (sparse_col_mat.rs:800-810). delta_out: this lane's free column; dn2_out: |delta|^2 summed in index order.
+        auto qr_step = [&](double lam, int buf, T& delta_out, T& dn2_out) -> bool {
+            bool ok = true;
+            if constexpr (QR_BUILD) {
+                const uint32_t Mq = m_rows + nfree;
+                const double sl = ::sqrt(lam);  // lm.rs:119
+                __syncthreads();
+                for (uint32_t i = lane; i < Mq * LDX; i += 64) QX[i] = 0.0;
+                __syncthreads();
+                // J (duplicates of a row summed in gradient order, sparse_col_mat.rs:710-711) and b = -r (lm.rs:86-91,130)
+                for (uint32_t row = lane; row < m_rows; row += 64) {
+                    const uint32_t pr = q_rowperm[row];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int cc = gcol[row * 8 + e];
+                        if (cc >= 0) QX[pr * LDX + q_cpos[cc]] += (double)G[(buf * mr + row) * 8 + e];
+                    }
+                    QX[pr * LDX + N] = -(double)R[buf * mr + row];
+                }
+                // the damping entry of every column (lm.rs:92-96,119-125)
+                if ((uint32_t)lane < nfree) QX[q_rowperm[m_rows + lane] * LDX + q_cpos[lane]] = sl;
+                __syncthreads();
+
+                // apply_householder (qr.rs:226-240) of vector k to column cx
+                auto apply_h = [&](uint32_t k, uint32_t cx, double v0n, double beta, uint32_t hb, uint32_t he) {
+                    double tau = 0.0;
+                    tau = tau + v0n * QX[k * LDX + cx];
+                    for (uint32_t t = hb + 1u; t < he; ++t) {
+                        const uint32_t r = q_hrows[t];
+                        tau = tau + QX[r * LDX + k] * QX[r * LDX + cx];
+                    }
+                    tau = tau * beta;
+                    QX[k * LDX + cx] = QX[k * LDX + cx] - v0n * tau;
+                    for (uint32_t t = hb + 1u; t < he; ++t) {
+                        const uint32_t r = q_hrows[t];
+                        QX[r * LDX + cx] = QX[r * LDX + cx] - QX[r * LDX + k] * tau;
+                    }
+                };
+                // the right-hand side rides along as column N: on the lane after the last column, or (64 columns) in a
+                // pass of its own below
+                const bool is_b = (uint32_t)lane == nfree;
+                const uint32_t cx = is_b ? (uint32_t)N : (uint32_t)lane;
+                for (uint32_t k = 0; k < nfree; ++k) {
+                    const uint32_t hb = q_hptr[k], he = q_hptr[k + 1];
+                    // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
+                    const double v0 = QX[k * LDX + k];
+                    double sigma = 0.0;
+                    for (uint32_t t = hb + 1u; t < he; ++t) {
+                        const double x = QX[q_hrows[t] * LDX + k];
+                        sigma = sigma + x * x;
+                    }
+                    double norm, beta, v0n;
+                    if (sigma == 0.0) {
+                        norm = ::fabs(v0);
+                        beta = (v0 >= 0.0) ? 0.0 : 2.0;
+                        v0n = 1.0;
+                    } else {
+                        norm = ::sqrt(sigma + v0 * v0);
+                        v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
+                        beta = -(1.0 / (norm * v0n));
+                    }
+                    if (is_b || ((uint32_t)lane < nfree && ((q_colmask >> k) & 1ull))) apply_h(k, cx, v0n, beta, hb, he);
+                    if (lane == 0) {
+                        QV0[k] = v0n;
+                        QBETA[k] = beta;
+                    }
+                    __syncthreads();
+                    if (lane == 0) QX[k * LDX + k] = norm;  // R's diagonal (qr.rs:319)
+                }
+                if (nfree == 64u) {  // Q^T b (qr.rs:328-346) with the stored vectors
+                    if (lane == 0)
+                        for (uint32_t k = 0; k < nfree; ++k) apply_h(k, (uint32_t)N, QV0[k], QBETA[k], q_hptr[k], q_hptr[k + 1]);
+                }
+                __syncthreads();
+                // back substitution with R (sparse_col_mat.rs:788-826), lane r holds entry r of the vector
+                double yv = ((uint32_t)lane < nfree) ? QX[lane * LDX + N] : 0.0;
+                for (int i = (int)nfree - 1; i >= 0; --i) {
+                    const double di = QX[i * LDX + i];
+                    if (di == 0.0) {
+                        ok = false;
+                        break;
+                    }
+                    const double coeff = bcast(yv, i) / di;
+                    if (lane == i) yv = coeff;
+                    if (lane < i && ((q_rowmask >> i) & 1ull)) yv = yv - coeff * QX[lane * LDX + i];
+                }
+                // undo the column permutation (qr.rs:354): delta[colperm[j]] = x_j
+                double* QD = QV0;
+                __syncthreads();
+                if ((uint32_t)lane < nfree) QD[q_cp] = yv;
+                __syncthreads();
+                delta_out = ((uint32_t)lane < nfree) ? (T)QD[lane] : T(0);
+                double acc = 0.0;
+                for (uint32_t cc = 0; cc < nfree; ++cc) acc += QD[cc] * QD[cc];
+                dn2_out = (T)bcast(acc, 0);
+                __syncthreads();
+            }
+            return ok;
+        };
+
         // evaluates all rows at XS[buf] into G[buf], R[buf]; returns SSE (wave-uniform)
         auto eval_rows = [&](int buf) -> T {
             const T* xs = XS + buf * vt;
@@ -454,6 +620,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         const T xstart = ((uint32_t)lane < nfree) ? XS[fidx[lane]] : T(0);  // perturbed start of this lane's variable
         stamp(PH_SETUP);
         T sse = eval_rows(0);
+        if (qr) sse = (T)seq_sse_lm(0);
         T sse_start = sse;
         uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
         if constexpr (OPT == 1) {
@@ -618,14 +785,14 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         } else {
         // ================= Optimizer::LevenbergMarquardt (lm.rs:21-193) =================
         stamp(PH_EVAL);
-        form_normal(0);
+        if (!qr) form_normal(0);
         stamp(PH_FORM);
-        T diag = (lane < N) ? Amat[lane * LD + lane] : T(1);
-        T rhs_l = (lane < N) ? rhsv[lane] : T(0);
+        T diag = (lane < N && !qr) ? Amat[lane * LD + lane] : T(1);
+        T rhs_l = (lane < N && !qr) ? rhsv[lane] : T(0);
 
         double lambda = o.lambda0;
         bool done = false;
-        if (!(sse == sse) || !(sse < Lim<T>::huge())) {
+        if (!(sse == sse) || !(sse < Lim<T>::huge()) || qr_bad_plan) {
             exit_code = FX_EXIT_NAN;
             done = true;
         }
@@ -642,6 +809,13 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     break;
                 }
                 trials += 1;
+                T delta = T(0), dn2 = T(0);
+                if (qr) {
+                    if (!uniform(qr_step(lambda, cur, delta, dn2))) {  // lm.rs:134-137
+                        lambda *= o.singular_factor;
+                        continue;
+                    }
+                } else {
                 // K4: factor (JtJ + lambda I) and solve for delta
                 T a[N];
                 if (lane < N) {
@@ -668,7 +842,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     lambda *= o.singular_factor;
                     continue;
                 }
-                T delta = chol_solve<N, T>(a, invd, rhs_l, lane);
+                delta = chol_solve<N, T>(a, invd, rhs_l, lane);
                 if ((uint32_t)lane >= nfree) delta = T(0);
                 if (o.solver == FX_STEP_CHOLESKY_REFINED) {
                     // One step of refinement on the least-squares problem itself (corrected semi-normal
@@ -713,7 +887,8 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     if ((uint32_t)lane < nfree) delta += corr;
                     __syncthreads();
                 }
-                T dn2 = wave_sum(delta * delta);
+                dn2 = wave_sum(delta * delta);
+                }  // normal-equation step
                 stamp(PH_SOLVE);
                 if (!(dn2 == dn2)) {
                     exit_code = FX_EXIT_NAN;
@@ -734,6 +909,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 __syncthreads();
                 stamp(PH_TAIL);
                 T sse_t = eval_rows(trial);
+                if (qr) sse_t = (T)seq_sse_lm(trial);
                 stamp(PH_EVAL);
                 if (sse_t < sse) {  // accept, lm.rs:151-186
                     lambda *= o.accept_factor;
@@ -749,9 +925,11 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     }
                     __syncthreads();
                     stamp(PH_TAIL);
-                    form_normal(cur);
-                    diag = (lane < N) ? Amat[lane * LD + lane] : T(1);
-                    rhs_l = (lane < N) ? rhsv[lane] : T(0);
+                    if (!qr) {
+                        form_normal(cur);
+                        diag = (lane < N) ? Amat[lane * LD + lane] : T(1);
+                        rhs_l = (lane < N) ? rhsv[lane] : T(0);
+                    }
                     stamp(PH_FORM);
                     break;
                 } else {  // reject, lm.rs:187-190
@@ -1157,7 +1335,12 @@ static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStr
     const uint32_t rows = (UNITS && b.max_unit_rows > b.max_rows) ? b.max_unit_rows : b.max_rows;
     // block walking: blocks of up to 8 rows never list their products (see the kernel), so no LDS for it
     const bool lists = !UNITS || b.max_unit_rows > 8u;
-    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, lists ? b.max_pairs : 0u, lists ? b.max_ents : 0u);
+    // FX_STEP_QR: the plans of the host's symbolic analysis size the augmented matrix
+    const QrPlans& Q = UNITS ? b.qr_units : b.qr_none;
+    const bool qr = p.lm.solver == FX_STEP_QR;
+    if (qr && (sizeof(T) != 8 || OPT != 0 || !Q.desc)) return hipErrorInvalidValue;
+    SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, lists ? b.max_pairs : 0u, lists ? b.max_ents : 0u,
+                                qr ? Q.max_m : 0u, qr ? Q.max_h : 0u);
     switch (n) {
         case 8: return launch_solve_n<8, T, false, UNITS, OPT>(b, p, L, stream);
         case 16: return launch_solve_n<16, T, false, UNITS, OPT>(b, p, L, stream);

@@ -116,11 +116,19 @@ typedef struct fx_batch {
 /* Which linear solve the LM step uses. */
 typedef enum fx_step_solver {
     FX_STEP_CHOLESKY = 0, /* (JtJ + lambda I) delta = -Jt r, dense Cholesky per wavefront       */
-    FX_STEP_CHOLESKY_REFINED = 1 /* + one refinement step on the least-squares problem itself
+    FX_STEP_CHOLESKY_REFINED = 1, /* + one refinement step on the least-squares problem itself
                                     (corrected semi-normal equations: the residual -r - J delta comes
                                     from the Jacobian rows, not from JtJ) — the step then has the
                                     accuracy of the reference's QR on ill-conditioned sketches, for
-                                    about a fifth more time. Fused and wide kernels; the sparse path ignores it */
+                                    about a fifth more time.                                        */
+    FX_STEP_QR = 2 /* the reference's own numerics (lm.rs:98-132, solvi qr.rs:226-356): Householder QR of
+                      [J; sqrt(lambda) I] in the reference's column order (COLAMD, computed on the host) and row
+                      order, every sum taken in the reference's order, nothing fused. On sketches without angle
+                      constraints the LM path — trial counts, every iterate — is bit-identical to the
+                      reference's; angle residuals go through atan2 (device libm vs the host's), so those
+                      paths agree to rounding. f64, Levenberg-Marquardt, Systems the one-wavefront kernel takes
+                      (components of up to FX_MAX_FREE_VARS free variables); larger Systems run
+                      FX_STEP_CHOLESKY_REFINED instead. Several times the cost of FX_STEP_CHOLESKY.        */
 } fx_step_solver;
 
 /* Levenberg-Marquardt constants; fx_lm_opts_default() == the literals of lm.rs:108-189. */
@@ -276,6 +284,17 @@ int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
  * a free variable exactly one. Any output pointer may be NULL. */
 int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_blocks, uint32_t* block_comp,
                           uint32_t* row_off, uint32_t* rows, uint32_t* var_off, uint32_t* vars);
+
+/* == SymbolicQr::build (solvi/src/decomposition/sparse/qr.rs:118-206), the host-side phase FX_STEP_QR replays the
+ * reference's numeric QR from: the COLAMD column order (use_colamd != 0; colamd_rs with its default knobs) or the
+ * natural one, the elimination tree, the row permutation of Davis section 5.3 and the row patterns of the Householder
+ * vectors (H) and of R, on the pattern of an nrows x ncols matrix given by columns (rows ascending inside a column).
+ * Host-only (no device needed). col_perm[ncols]: position -> column; row_perm[nrows]: row -> permuted row;
+ * h_ptr / r_ptr [ncols + 1] into h_rows / r_rows (capacities h_cap / r_cap; nrows * ncols and
+ * ncols * (ncols + 1) / 2 always suffice). Any output pointer may be NULL. */
+int fx_qr_symbolic(int32_t nrows, int32_t ncols, const int32_t* colptr, const int32_t* rowidx, int use_colamd,
+                   int32_t* col_perm, int32_t* row_perm, int32_t* h_ptr, int32_t* h_rows, int32_t h_cap, int32_t* r_ptr,
+                   int32_t* r_rows, int32_t r_cap);
 
 #ifdef __cplusplus
 }

@@ -162,6 +162,22 @@ int fo_symbolic(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64
 
 // solvi sparse QR: factorize the CSC matrix and solve min |A x - b| in place (b has nrows entries,
 // x is returned in b[0..ncols)). ordering: 0 natural, 1 colamd. R is returned in CSC form.
+// SymbolicQr::build (qr.rs:118-206): permutations and the structures of H and R.
+int fo_symbolic_qr(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowidx, int colamd_ordering,
+                   int64_t* col_perm, int64_t* row_perm, int64_t* h_ptr, int64_t* h_rows, int64_t* r_ptr, int64_t* r_rows) {
+    SparseColMatStructure a = make_structure(nrows, ncols, colptr, rowidx);
+    SymbolicQr s = SymbolicQr::build(a, colamd_ordering ? QrOrdering::Colamd : QrOrdering::Natural);
+    for (int64_t j = 0; j < ncols; ++j) col_perm[j] = static_cast<int64_t>(s.col_permutation[j]);
+    for (int64_t i = 0; i < nrows; ++i) row_perm[i] = static_cast<int64_t>(s.row_permutation[i]);
+    for (int64_t j = 0; j <= ncols; ++j) {
+        h_ptr[j] = static_cast<int64_t>(s.h_structure.column_pointers[j]);
+        r_ptr[j] = static_cast<int64_t>(s.r_structure.column_pointers[j]);
+    }
+    for (size_t k = 0; k < s.h_structure.row_indices.size(); ++k) h_rows[k] = static_cast<int64_t>(s.h_structure.row_indices[k]);
+    for (size_t k = 0; k < s.r_structure.row_indices.size(); ++k) r_rows[k] = static_cast<int64_t>(s.r_structure.row_indices[k]);
+    return 0;
+}
+
 int fo_qr_factor_solve(int64_t nrows, int64_t ncols, const int64_t* colptr, const int64_t* rowidx,
                        const double* values, int ordering, double* b, int64_t* r_colptr, int64_t* r_rowidx,
                        double* r_values, int64_t r_cap, int* solved) {

@@ -107,6 +107,22 @@ def symbolic(nrows: int, ncols: int, colptr, rowidx):
     return dict(parents=parents, post=post, row_counts=rc, col_counts=cc, l_colptr=lcp, l_rowidx=lri[: lcp[-1]].copy())
 
 
+def symbolic_qr(nrows: int, ncols: int, colptr, rowidx, ordering: str = "colamd"):
+    """SymbolicQr::build: permutations and the structures of H and R."""
+    cp = np.ascontiguousarray(colptr, dtype=np.int64)
+    ri = np.ascontiguousarray(rowidx, dtype=np.int64)
+    col_perm = np.zeros(ncols, dtype=np.int64)
+    row_perm = np.zeros(nrows, dtype=np.int64)
+    h_ptr = np.zeros(ncols + 1, dtype=np.int64)
+    r_ptr = np.zeros(ncols + 1, dtype=np.int64)
+    h_rows = np.zeros(nrows * ncols + 1, dtype=np.int64)
+    r_rows = np.zeros(ncols * (ncols + 1) // 2 + 1, dtype=np.int64)
+    lib().fo_symbolic_qr(C.c_int64(nrows), C.c_int64(ncols), _p(cp), _p(ri), C.c_int(1 if ordering == "colamd" else 0),
+                         _p(col_perm), _p(row_perm), _p(h_ptr), _p(h_rows), _p(r_ptr), _p(r_rows))
+    return dict(col_perm=col_perm, row_perm=row_perm, h_ptr=h_ptr, h_rows=h_rows[: h_ptr[-1]].copy(), r_ptr=r_ptr,
+                r_rows=r_rows[: r_ptr[-1]].copy())
+
+
 def qr_factor_solve(nrows: int, ncols: int, colptr, rowidx, values, b=None, ordering: str = "natural"):
     cp = np.ascontiguousarray(colptr, dtype=np.int64)
     ri = np.ascontiguousarray(rowidx, dtype=np.int64)
