@@ -1600,6 +1600,13 @@ int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opt
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u);
     p.prof = dev;
+    if (p.lm.solver == FX_STEP_QR) {
+        rc = ensure_qr_plans(ctx, db, false);
+        if (rc) {
+            (void)hipFree(dev);
+            return rc;
+        }
+    }
     // a batch of medium Systems only: the wide kernel's stamps; otherwise the fused kernel's (N = 32 build)
     hipError_t e = (db->d.n_wide && db->d.n_wide == db->d.n_systems) ? fx::launch_solve_wide(db->d, p, ctx->stream)
                                                                      : fx::launch_solve(db->d, p, ctx->stream);

@@ -49,7 +49,8 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     L.off_xs = take(2u * L.vt * es);
     // LM: the N x LD normal matrix. L-BFGS: 5 + 5 history vectors, a dot-product scratch vector, rho[5]
     // (padded to 16 doubles) and one "overwritten entry" byte mask per row.
-    L.off_a = take(lbfgs ? (11u * n_pad + 16u) * 8u + L.mr : n_pad * (n_pad + 16u / es) * es);
+    // (an FX_STEP_QR launch never forms the normal equations: no matrix, no product lists)
+    L.off_a = take(qr_m ? 16u : lbfgs ? (11u * n_pad + 16u) * 8u + L.mr : n_pad * (n_pad + 16u / es) * es);
     L.off_rhs = take(n_pad * es);
     L.off_g = take(2u * L.mr * 8u * es);
     L.off_r = take(2u * L.mr * es);
@@ -62,7 +63,7 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     L.off_vout = take(L.vt * 8u);  // unscaled output values (f64) for the post-solve check
     // one u32 per product g_a * g_b of the assembly (and per g * r of the right-hand side); worth its
     // LDS only while it stays small (ring16: 672 + 144 entries = 3.3 KB)
-    const bool packed = !lbfgs && max_pairs > 0 && max_pairs <= 4096u;
+    const bool packed = !lbfgs && !qr_m && max_pairs > 0 && max_pairs <= 4096u;
     L.pw_cap = packed ? ((max_pairs + 63u) & ~63u) : 0u;
     L.pe_cap = packed ? ((max_ents + 63u) & ~63u) : 0u;
     L.off_pw = take(L.pw_cap * 4u);
@@ -71,8 +72,8 @@ static SolveLayout make_layout(uint32_t n_pad, uint32_t max_vars, uint32_t max_r
     // permuted order, the component's plan, v0 / beta of every Householder vector
     L.qr_m = qr_m;
     L.qr_h = qr_h;
-    L.off_qx = take(qr_m * (n_pad + 1u) * 8u);
-    L.off_qp = take(qr_m ? (qr_m + (n_pad + 1u) + qr_h + n_pad) * 2u : 0u);
+    L.off_qx = take(qr_m ? (qr_m + 1u) * (n_pad + 1u) * 8u : 0u);  // + one row of zeros (the padding of the register window reads it)
+    L.off_qp = take(qr_m ? (qr_m + (n_pad + 1u) + qr_h + 32u + n_pad) * 2u : 0u);  // 32: slack of the register window
     L.off_qs = take(qr_m ? 2u * n_pad * 8u : 0u);
     L.total = o;
     return L;
@@ -121,9 +122,10 @@ enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4
 // the System-wide vectors (working variables, output values, variable -> column map) live in an
 // HBM scratch area instead of LDS — L2-resident for the one wavefront that walks the blocks — while
 // everything per block stays in LDS and registers as before.
-template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false>
-__global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// QR = true adds the reference-numerics step (FX_STEP_QR) — an instantiation of its own, so that the register
+// budget of the plain kernel (two wavefronts per SIMD) does not pay for the QR step's register window.
+template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false, bool QR = false>
+__device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmParams& prm, const SolveLayout& L, unsigned char* smem) {
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = 0;
     auto stamp = [&](int phase) {
@@ -407,14 +409,14 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         // every inner product summed over the Householder vector's rows in ascending order, multiplications
         // and additions unfused (solvi/src/decomposition/sparse/qr.rs:226-356). The matrix is kept dense in LDS,
         // one column per lane; entries outside the symbolic patterns are exact zeros that no operation reads.
-        constexpr bool QR_BUILD = sizeof(T) == 8 && OPT == 0 && !GLOBAL && !PROF;
+        constexpr bool QR_BUILD = QR && sizeof(T) == 8 && OPT == 0 && !GLOBAL;
         const bool qr = QR_BUILD && o.solver == FX_STEP_QR && L.qr_m != 0u;
         constexpr uint32_t LDX = (uint32_t)N + 1u;
         double* QX = reinterpret_cast<double*>(smem + L.off_qx);           // [m + n][LDX]
         uint16_t* q_rowperm = reinterpret_cast<uint16_t*>(smem + L.off_qp);  // [qr_m]
         uint16_t* q_hptr = q_rowperm + L.qr_m;                                // [N + 1]
-        uint16_t* q_hrows = q_hptr + (N + 1);                                 // [qr_h]
-        uint16_t* q_cpos = q_hrows + L.qr_h;                                  // [N] free column -> position
+        uint16_t* q_hoff = q_hptr + (N + 1);                                  // [qr_h] row of a vector entry, times LDX
+        uint16_t* q_cpos = q_hoff + L.qr_h + 32u;                             // [N] free column -> position
         double* QV0 = reinterpret_cast<double*>(smem + L.off_qs);             // [N] first entry of vector k
         double* QBETA = QV0 + N;                                              // [N]
         unsigned long long q_colmask = 0ull, q_rowmask = 0ull;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     }
                     for (uint32_t i = lane; i < Mq; i += 64) q_rowperm[i] = pu[nfree + i];
                     for (uint32_t i = lane; i <= nfree; i += 64) q_hptr[i] = pu[nfree + Mq + i];
-                    for (uint32_t i = lane; i < qd.nnzh; i += 64) q_hrows[i] = pu[nfree + Mq + nfree + 1u + i];
+                    for (uint32_t i = lane; i < qd.nnzh; i += 64) q_hoff[i] = (uint16_t)(pu[nfree + Mq + nfree + 1u + i] * LDX);
                     __syncthreads();
                 }
             }
@@ -445,9 +447,13 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
         // sum of squares in index order (lm.rs:195-197): every lane adds the same numbers in the same order
         auto seq_sse_lm = [&](int buf) -> double {
             double acc = 0.0;
-            for (uint32_t row = 0; row < m_rows; ++row) {
-                const double r = (double)R[buf * mr + row];
-                acc += r * r;
+            const T* rb = R + buf * mr;
+            for (uint32_t row0 = 0; row0 < m_rows; row0 += 16) {  // 16 loads in flight, then their squares in order
+                double rr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) rr[u] = (row0 + u < m_rows) ? (double)rb[row0 + u] : 0.0;  // + 0.0: exact
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += rr[u] * rr[u];
             }
             return bcast(acc, 0);
         };
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 const uint32_t Mq = m_rows + nfree;
                 const double sl = ::sqrt(lam);  // lm.rs:119
                 __syncthreads();
-                for (uint32_t i = lane; i < Mq * LDX; i += 64) QX[i] = 0.0;
+                for (uint32_t i = lane; i < (Mq + 1u) * LDX; i += 64) QX[i] = 0.0;  // row Mq stays zero
                 __syncthreads();
                 // J (duplicates of a row summed in gradient order, sparse_col_mat.rs:710-711) and b = -r (lm.rs:86-91,130)
                 for (uint32_t row = lane; row < m_rows; row += 64) {
@@ -467,53 +473,118 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int cc = gcol[row * 8 + e];
-                        if (cc >= 0) QX[pr * LDX + q_cpos[cc]] += (double)G[(buf * mr + row) * 8 + e];
+                        // (the matrix was just zeroed: an LDS add is the store, and the second entry of a repeated
+                        // column is added to the first; the adds of one lane execute in order)
+                        if (cc >= 0) lds_add(&QX[pr * LDX + q_cpos[cc]], (double)G[(buf * mr + row) * 8 + e]);
                     }
                     QX[pr * LDX + N] = -(double)R[buf * mr + row];
                 }
                 // the damping entry of every column (lm.rs:92-96,119-125)
                 if ((uint32_t)lane < nfree) QX[q_rowperm[m_rows + lane] * LDX + q_cpos[lane]] = sl;
                 __syncthreads();
+                stamp(PH_FORM);
 
-                // apply_householder (qr.rs:226-240) of vector k to column cx
+                // apply_householder (qr.rs:226-240) of vector k to column cx, entry by entry (vectors beyond the
+                // register window below, and the right-hand side pass of a 64-column component)
                 auto apply_h = [&](uint32_t k, uint32_t cx, double v0n, double beta, uint32_t hb, uint32_t he) {
                     double tau = 0.0;
                     tau = tau + v0n * QX[k * LDX + cx];
                     for (uint32_t t = hb + 1u; t < he; ++t) {
-                        const uint32_t r = q_hrows[t];
-                        tau = tau + QX[r * LDX + k] * QX[r * LDX + cx];
+                        const uint32_t r = q_hoff[t];
+                        tau = tau + QX[r + k] * QX[r + cx];
                     }
                     tau = tau * beta;
                     QX[k * LDX + cx] = QX[k * LDX + cx] - v0n * tau;
                     for (uint32_t t = hb + 1u; t < he; ++t) {
-                        const uint32_t r = q_hrows[t];
-                        QX[r * LDX + cx] = QX[r * LDX + cx] - QX[r * LDX + k] * tau;
+                        const uint32_t r = q_hoff[t];
+                        QX[r + cx] = QX[r + cx] - QX[r + k] * tau;
                     }
                 };
                 // the right-hand side rides along as column N: on the lane after the last column, or (64 columns) in a
                 // pass of its own below
                 const bool is_b = (uint32_t)lane == nfree;
                 const uint32_t cx = is_b ? (uint32_t)N : (uint32_t)lane;
+                const int my_hptr = (int)q_hptr[lane];          // hptr[0..63], one per lane
+                const uint32_t hptr_end = q_hptr[nfree];
+                constexpr int CHT = 32;  // entries of a Householder vector (below the diagonal) kept in registers
+                const uint32_t zero_row = Mq * LDX;
                 for (uint32_t k = 0; k < nfree; ++k) {
-                    const uint32_t hb = q_hptr[k], he = q_hptr[k + 1];
-                    // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
+                    const uint32_t hb = (uint32_t)__builtin_amdgcn_readlane(my_hptr, (int)k);
+                    const uint32_t he = (k + 1u < nfree) ? (uint32_t)__builtin_amdgcn_readlane(my_hptr, (int)(k + 1u)) : hptr_end;
+                    const uint32_t len1 = he - hb - 1u;
+                    const bool act = is_b || ((uint32_t)lane < nfree && ((q_colmask >> k) & 1ull));
                     const double v0 = QX[k * LDX + k];
-                    double sigma = 0.0;
-                    for (uint32_t t = hb + 1u; t < he; ++t) {
-                        const double x = QX[q_hrows[t] * LDX + k];
-                        sigma = sigma + x * x;
-                    }
-                    double norm, beta, v0n;
-                    if (sigma == 0.0) {
-                        norm = ::fabs(v0);
-                        beta = (v0 >= 0.0) ? 0.0 : 2.0;
-                        v0n = 1.0;
+                    const bool windowed = len1 <= (uint32_t)CHT;
+                    // the whole vector and this lane's column entries under it, fetched once: row offsets, then the two
+                    // columns — two LDS round trips per vector instead of two per entry and pass. (The offset array has CHT
+                    // entries of slack, so the reads past the vector's end stay inside it; their values are never used.)
+                    uint32_t ro[CHT];
+                    double vk[CHT], xj[CHT];
+                    double xk0 = 0.0, sigma = 0.0;
+                    if (windowed) {
+                        xk0 = QX[k * LDX + cx];
+#pragma unroll
+                        for (int blk = 0; blk < CHT / 8; ++blk)
+                            if (len1 > (uint32_t)(8 * blk)) {
+#pragma unroll
+                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) {
+                                    const uint32_t off = q_hoff[hb + 1u + (uint32_t)u];
+                                    ro[u] = ((uint32_t)u < len1) ? off : zero_row;
+                                }
+                            }
+#pragma unroll
+                        for (int blk = 0; blk < CHT / 8; ++blk)
+                            if (len1 > (uint32_t)(8 * blk)) {
+#pragma unroll
+                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) {
+                                    // slots past the vector's end read the row of zeros: their terms add +0.0 to a sum that is
+                                    // never -0.0 (it starts at +0.0), which changes nothing — no select on the dependent chain
+                                    vk[u] = QX[ro[u] + k];
+                                    xj[u] = QX[ro[u] + cx];
+                                }
+                            }
+#pragma unroll
+                        for (int blk = 0; blk < CHT / 8; ++blk)
+                            if (len1 > (uint32_t)(8 * blk)) {
+#pragma unroll
+                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) sigma = sigma + vk[u] * vk[u];
+                            }
                     } else {
+                        for (uint32_t t = hb + 1u; t < he; ++t) {
+                            const double x = QX[q_hoff[t] + k];
+                            sigma = sigma + x * x;
+                        }
+                    }
+                    // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
+                    double norm = ::fabs(v0), beta = (v0 >= 0.0) ? 0.0 : 2.0, v0n = 1.0;
+                    if (sigma != 0.0) {
                         norm = ::sqrt(sigma + v0 * v0);
                         v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
                         beta = -(1.0 / (norm * v0n));
                     }
-                    if (is_b || ((uint32_t)lane < nfree && ((q_colmask >> k) & 1ull))) apply_h(k, cx, v0n, beta, hb, he);
+                    if (windowed) {
+                        double tau = 0.0;
+                        tau = tau + v0n * xk0;
+#pragma unroll
+                        for (int blk = 0; blk < CHT / 8; ++blk)
+                            if (len1 > (uint32_t)(8 * blk)) {
+#pragma unroll
+                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) tau = tau + vk[u] * xj[u];
+                            }
+                        tau = tau * beta;
+                        if (act) {
+                            QX[k * LDX + cx] = xk0 - v0n * tau;
+#pragma unroll
+                            for (int blk = 0; blk < CHT / 8; ++blk)
+                                if (len1 > (uint32_t)(8 * blk)) {
+#pragma unroll
+                                    for (int u = 8 * blk; u < 8 * blk + 8; ++u)
+                                        if ((uint32_t)u < len1) QX[ro[u] + cx] = xj[u] - vk[u] * tau;
+                                }
+                        }
+                    } else if (act) {
+                        apply_h(k, cx, v0n, beta, hb, he);
+                    }
                     if (lane == 0) {
                         QV0[k] = v0n;
                         QBETA[k] = beta;
@@ -521,22 +592,31 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                     __syncthreads();
                     if (lane == 0) QX[k * LDX + k] = norm;  // R's diagonal (qr.rs:319)
                 }
+                stamp(PH_FACTOR);
                 if (nfree == 64u) {  // Q^T b (qr.rs:328-346) with the stored vectors
                     if (lane == 0)
                         for (uint32_t k = 0; k < nfree; ++k) apply_h(k, (uint32_t)N, QV0[k], QBETA[k], q_hptr[k], q_hptr[k + 1]);
                 }
                 __syncthreads();
-                // back substitution with R (sparse_col_mat.rs:788-826), lane r holds entry r of the vector
+                // back substitution with R (sparse_col_mat.rs:788-826), lane r holds entry r of the vector and row r of R
+                // (fetched up front: the loop itself is a chain of divisions with no memory access in it)
                 double yv = ((uint32_t)lane < nfree) ? QX[lane * LDX + N] : 0.0;
-                for (int i = (int)nfree - 1; i >= 0; --i) {
-                    const double di = QX[i * LDX + i];
-                    if (di == 0.0) {
-                        ok = false;
-                        break;
+                double rrow[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) rrow[i] = ((uint32_t)lane < nfree && (uint32_t)i < nfree) ? QX[lane * LDX + i] : 1.0;
+                double dg = 1.0;  // this lane's diagonal entry
+#pragma unroll
+                for (int i = 0; i < N; ++i) dg = (lane == i) ? rrow[i] : dg;
+                ok = __ballot((uint32_t)lane < nfree && dg == 0.0) == 0ull;
+                if (ok) {
+#pragma unroll
+                    for (int i = N - 1; i >= 0; --i) {
+                        if ((uint32_t)i < nfree) {
+                            const double coeff = bcast(yv, i) / bcast(dg, i);
+                            if (lane == i) yv = coeff;
+                            if (lane < i && ((q_rowmask >> i) & 1ull)) yv = yv - coeff * rrow[i];
+                        }
                     }
-                    const double coeff = bcast(yv, i) / di;
-                    if (lane == i) yv = coeff;
-                    if (lane < i && ((q_rowmask >> i) & 1ull)) yv = yv - coeff * QX[lane * LDX + i];
                 }
                 // undo the column permutation (qr.rs:354): delta[colperm[j]] = x_j
                 double* QD = QV0;
@@ -545,7 +625,16 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
                 __syncthreads();
                 delta_out = ((uint32_t)lane < nfree) ? (T)QD[lane] : T(0);
                 double acc = 0.0;
-                for (uint32_t cc = 0; cc < nfree; ++cc) acc += QD[cc] * QD[cc];
+#pragma unroll
+                for (int c0 = 0; c0 < N; c0 += 16) {
+                    if ((uint32_t)c0 < nfree) {
+                        double dd[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) dd[u] = ((uint32_t)(c0 + u) < nfree) ? QD[c0 + u] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc += dd[u] * dd[u];
+                    }
+                }
                 dn2_out = (T)bcast(acc, 0);
                 __syncthreads();
             }
@@ -1012,6 +1101,24 @@ __global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams pr
     }
 }
 
+template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false>
+__global__ __launch_bounds__(64) void lm_solve_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    lm_solve_body<N, T, PROF, UNITS, OPT, GLOBAL, false>(b, prm, L, smem);
+}
+// the FX_STEP_QR instantiations: up to 32 columns the register window of the QR step fits a 256-register budget
+// (two wavefronts per SIMD hide its LDS round trips); wider builds take what they need
+template <int N, bool PROF, bool UNITS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void lm_solve_qr_kernel_w2(DeviceBatch b, LmParams prm, SolveLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    lm_solve_body<N, double, PROF, UNITS, 0, false, true>(b, prm, L, smem);
+}
+template <int N, bool PROF, bool UNITS>
+__global__ __launch_bounds__(64) void lm_solve_qr_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    lm_solve_body<N, double, PROF, UNITS, 0, false, true>(b, prm, L, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // K1 / K2 over the whole batch: one thread per expression row
 // ------------------------------------------------------------------------------------------
@@ -1319,13 +1426,16 @@ hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_
     return launch_solve_global(b, p, stream);
 }
 
-template <int N, typename T, bool PROF, bool UNITS, int OPT>
+template <int N, typename T, bool PROF, bool UNITS, int OPT, bool QR = false>
 static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, T, PROF, UNITS, OPT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    void (*fn)(DeviceBatch, LmParams, SolveLayout);
+    if constexpr (QR && N <= 32) fn = &lm_solve_qr_kernel_w2<N, PROF, UNITS>;
+    else if constexpr (QR) fn = &lm_solve_qr_kernel<N, PROF, UNITS>;
+    else fn = &lm_solve_kernel<N, T, PROF, UNITS, OPT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((lm_solve_kernel<N, T, PROF, UNITS, OPT>), dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    hipLaunchKernelGGL(fn, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
 }
 
@@ -1341,6 +1451,21 @@ static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStr
     if (qr && (sizeof(T) != 8 || OPT != 0 || !Q.desc)) return hipErrorInvalidValue;
     SolveLayout L = make_layout(n, b.max_vars, rows, (uint32_t)sizeof(T), OPT == 1, lists ? b.max_pairs : 0u, lists ? b.max_ents : 0u,
                                 qr ? Q.max_m : 0u, qr ? Q.max_h : 0u);
+    if constexpr (sizeof(T) == 8 && OPT == 0) {
+        if (qr) {
+            switch (n) {
+                case 8: return launch_solve_n<8, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 16: return launch_solve_n<16, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 24: return launch_solve_n<24, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 32: return launch_solve_n<32, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 40: return launch_solve_n<40, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 48: return launch_solve_n<48, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 56: return launch_solve_n<56, T, false, UNITS, OPT, true>(b, p, L, stream);
+                case 64: return launch_solve_n<64, T, false, UNITS, OPT, true>(b, p, L, stream);
+                default: return hipErrorInvalidValue;
+            }
+        }
+    }
     switch (n) {
         case 8: return launch_solve_n<8, T, false, UNITS, OPT>(b, p, L, stream);
         case 16: return launch_solve_n<16, T, false, UNITS, OPT>(b, p, L, stream);
@@ -1360,6 +1485,11 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);
         if (n != 32 || p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS))) return hipErrorInvalidValue;
+        if (p.lm.solver == FX_STEP_QR) {
+            if (!b.qr_none.desc) return hipErrorInvalidValue;
+            SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents, b.qr_none.max_m, b.qr_none.max_h);
+            return launch_solve_n<32, double, true, false, 0, true>(b, p, L, stream);
+        }
         SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents);
         return launch_solve_n<32, double, true, false, 0>(b, p, L, stream);
     }
