@@ -132,6 +132,7 @@ SIGNATURES = [
     ("fx_analyze_batch", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     ("fx_eval_residual_dense_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp, _vp, _vp]),
     ("fx_single_pass_blocks", C.c_int, [C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("fx_atan2_cr_batch", None, [C.c_uint64, _vp, _vp, _vp]),
     ("fx_qr_symbolic", C.c_int, [C.c_int32, C.c_int32, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp, C.c_int32]),
     # builder
     ("fxs_system_new", C.c_int, [C.POINTER(_vp)]),

@@ -132,6 +132,16 @@ def single_pass_blocks(arrays, system: int = 0):
             for k in range(nb.value)]
 
 
+def atan2_cr(y, x) -> np.ndarray:
+    """The correctly rounded atan2 of the FX_STEP_QR kernels, host build (element-wise; no GPU needed)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert y.shape == x.shape
+    out = np.zeros_like(y)
+    lib.fx_atan2_cr_batch(y.size, _ptr(y), _ptr(x), _ptr(out))
+    return out
+
+
 def qr_symbolic(nrows: int, ncols: int, colptr, rowidx, colamd: bool = True):
     """SymbolicQr::build on a column pattern (host-side, no GPU needed): dict with col_perm, row_perm,
     h_ptr / h_rows (Householder vectors) and r_ptr / r_rows (columns of R)."""

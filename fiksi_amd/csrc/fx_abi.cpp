@@ -820,7 +820,13 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
     out = QrHostPlan();
     out.n = n;
     out.m = m;
-    if (n == 0 || n > 64u) return false;
+    if (n > 64u) return false;
+    if (n == 0) {  // every variable of the component is fixed: the reference's LM takes one trial with an empty step
+        for (uint32_t i = 0; i < m; ++i) out.u16.push_back((uint16_t)i);
+        out.u16.push_back(0);
+        out.ok = true;
+        return true;
+    }
     std::vector<int32_t> colof(nvt, -1);
     for (uint32_t c = 0; c < n; ++c) colof[free_[c]] = (int32_t)c;
     std::vector<std::vector<int>> cols(n);
@@ -925,21 +931,21 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
         R.sys_first.assign(s_hi - s_lo, 0xFFFFFFFFu);
         std::vector<uint32_t> rows, free_;
         QrHostPlan hp;
-        auto emit = [&](const uint32_t* rw, uint32_t m, const uint32_t* fr, uint32_t nf, uint32_t s) {
+        auto emit = [&](const uint32_t* rw, uint32_t m, const uint32_t* fr, uint32_t nf, uint32_t s, bool skip) {
             const uint32_t e0 = expr_off[s], nvt = var_off[s + 1] - var_off[s];
             fx::QrDesc qd{};
             qd.u16_off = (uint32_t)R.u16.size();
             qd.u64_off = (uint32_t)R.u64.size();
             qd.n = (uint16_t)nf;
             qd.m = (uint16_t)m;
-            if (nf > 0 && build_qr_plan(expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0, rw, m, fr, nf, nvt, hp)) {
+            if (!skip && build_qr_plan(expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0, rw, m, fr, nf, nvt, hp)) {
                 qd.nnzh = (uint16_t)hp.nnzh;
                 qd.ok = 1;
                 R.u16.insert(R.u16.end(), hp.u16.begin(), hp.u16.end());
                 R.u64.insert(R.u64.end(), hp.u64.begin(), hp.u64.end());
                 R.max_m = std::max(R.max_m, m + nf);
                 R.max_h = std::max(R.max_h, hp.nnzh);
-            } else if (nf > 0) {
+            } else if (!skip) {
                 R.failed = true;
             }
             R.desc.push_back(qd);
@@ -954,19 +960,21 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
                     rows.assign(unit_rows.begin() + ud.row_off, unit_rows.begin() + ud.row_off + ud.nrows);
                     free_.clear();
                     for (uint32_t k = 0; k < ud.nvars; ++k) free_.push_back(unit_vars[ud.var_off + k]);
-                    emit(rows.data(), ud.nrows, free_.data(), (ud.flags & fx::UNIT_EMPTY) ? 0u : ud.nvars, s);
+                    emit(rows.data(), ud.nrows, free_.data(), ud.nvars, s, (ud.flags & fx::UNIT_EMPTY) != 0);
                 }
             } else {
                 for (uint32_t c = 0; c < sys_ncomp[s]; ++c) {
                     rows.clear();
                     free_.clear();
+                    bool any_var = false;  // a component without variables is skipped by the kernel (and by the reference)
                     for (uint32_t i = 0; i < nvt; ++i) {
                         const uint16_t info = var_info[v0 + i];
+                        any_var = any_var || (info & fx::VAR_COMP_MASK) == c;
                         if ((info & fx::VAR_COMP_MASK) == c && !(info & fx::VAR_FIXED_BIT)) free_.push_back(i);
                     }
                     for (uint32_t i = 0; i < net; ++i)
                         if (expr_comp[e0 + i] == c) rows.push_back(i);
-                    emit(rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), s);
+                    emit(rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), s, !any_var);
                 }
             }
         }
@@ -1769,6 +1777,10 @@ int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_bl
     }
     if (n_blocks) *n_blocks = nb;
     return FX_OK;
+}
+
+void fx_atan2_cr_batch(uint64_t n, const double* y, const double* x, double* out) {
+    for (uint64_t i = 0; i < n; ++i) out[i] = fx::atan2_cr(y[i], x[i]);
 }
 
 int fx_qr_symbolic(int32_t nrows, int32_t ncols, const int32_t* colptr, const int32_t* rowidx, int use_colamd,

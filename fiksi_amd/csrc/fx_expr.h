@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fx_atan2.h"
+
 #define FX_TAG_VVE 0
 #define FX_TAG_PPD 1
 #define FX_TAG_PPPA 2
@@ -62,12 +64,19 @@ template <typename T> struct Math;
 template <> struct Math<double> {
     static __device__ __forceinline__ double sqrt_(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
+    template <bool CR>
+    static __device__ __forceinline__ double atan2_sel(double y, double x) {
+        if constexpr (CR) return atan2_cr(y, x);
+        else return ::atan2(y, x);
+    }
     static __device__ __forceinline__ double abs_(double x) { return ::fabs(x); }
     static __device__ __forceinline__ double pi() { return 3.14159265358979323846264338327950288; }
 };
 template <> struct Math<float> {
     static __device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
+    template <bool CR>
+    static __device__ __forceinline__ float atan2_sel(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return ::fabsf(x); }
     static __device__ __forceinline__ float pi() { return 3.14159265358979323846f; }
 };
@@ -97,7 +106,9 @@ __device__ __forceinline__ T wrap_pi(T a) {
 // Residual + gradient of one expression. v[] = gathered values in expand_vars order, g[] = partials
 // in the same order (entries >= tag_nvars(tag) are left untouched). WANT_G=false drops the
 // gradient arithmetic (residual-only evaluation, expressions.rs:883-961).
-template <typename T, bool WANT_G>
+// CR = true: the two angle residuals use the correctly rounded atan2 of fx_atan2.h instead of the device libm's
+// (FX_STEP_QR: every bit of the solve then follows from IEEE arithmetic alone).
+template <typename T, bool WANT_G, bool CR = false>
 __device__ __forceinline__ T eval_expression(int tag, const T v[8], T param, T g[8]) {
     switch (tag) {
         case FX_TAG_VVE: {  // expressions.rs:294-300
@@ -113,7 +124,7 @@ __device__ __forceinline__ T eval_expression(int tag, const T v[8], T param, T g
         case FX_TAG_PPPA: {  // expressions.rs:375-424: angle at p2 from (p1-p2) to (p3-p2)
             T ux = v[0] - v[2], uy = v[1] - v[3];
             T wx = v[4] - v[2], wy = v[5] - v[3];
-            T ang = wrap_pi<T>(Math<T>::atan2_(wy, wx) - Math<T>::atan2_(uy, ux));
+            T ang = wrap_pi<T>(Math<T>::template atan2_sel<CR>(wy, wx) - Math<T>::template atan2_sel<CR>(uy, ux));
             if (WANT_G) {
                 T ur = T(1) / (ux * ux + uy * uy);
                 T wr = T(1) / (wx * wx + wy * wy);
@@ -176,7 +187,7 @@ __device__ __forceinline__ T eval_expression(int tag, const T v[8], T param, T g
         case FX_TAG_LLA: {  // expressions.rs:643-695: angle from line1 direction to line2 direction
             T ux = v[2] - v[0], uy = v[3] - v[1];
             T wx = v[6] - v[4], wy = v[7] - v[5];
-            T ang = wrap_pi<T>(Math<T>::atan2_(wy, wx) - Math<T>::atan2_(uy, ux));
+            T ang = wrap_pi<T>(Math<T>::template atan2_sel<CR>(wy, wx) - Math<T>::template atan2_sel<CR>(uy, ux));
             if (WANT_G) {
                 T ur = T(1) / (ux * ux + uy * uy);
                 T wr = T(1) / (wx * wx + wy * wy);

@@ -137,6 +137,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
     };
     if (PROF) t_last = __builtin_amdgcn_s_memtime();
     const int lane = threadIdx.x;
+    constexpr bool CR_ATAN2 = QR && sizeof(T) == 8 && OPT == 0 && !GLOBAL;  // FX_STEP_QR: correctly rounded atan2 (fx_atan2.h)
     const uint32_t s = GLOBAL ? b.g_list[blockIdx.x] : blockIdx.x;
     if (!GLOBAL && b.sys_large[s]) return;  // handled by the GLOBAL launch or the sparse path (fx_sparse.hip)
     constexpr int LD = N + Vec16<T>::n;  // 16-byte aligned columns, conflict-free ds_read_b128
@@ -649,7 +650,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                 T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
-                T r = eval_expression<T, true>(rtag[row], v, P[row], g);
+                T r = eval_expression<T, true, CR_ATAN2>(rtag[row], v, P[row], g);
                 R[buf * mr + row] = r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
         double v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = XD[vars8[e]];
-        double r = eval_expression<double, false>(tag, v, ld_param(i), g);
+        double r = eval_expression<double, false, CR_ATAN2>(tag, v, ld_param(i), g);
         part += r * r;
     }
     double sse_u = wave_sum(part);

@@ -285,6 +285,12 @@ int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
 int fx_single_pass_blocks(const fx_batch* batch, uint32_t system, uint32_t* n_blocks, uint32_t* block_comp,
                           uint32_t* row_off, uint32_t* rows, uint32_t* var_off, uint32_t* vars);
 
+/* Host build of the correctly rounded atan2 the FX_STEP_QR kernels evaluate angle residuals with
+ * (fiksi_amd/csrc/fx_atan2.h; the reference: f64::atan2 at expressions.rs:393, :665 — the platform libm's, within
+ * an ulp of this value). Element-wise over n arguments; host-only, for verification against an independent
+ * high-precision atan2 (tests/test_atan2.py). */
+void fx_atan2_cr_batch(uint64_t n, const double* y, const double* x, double* out);
+
 /* == SymbolicQr::build (solvi/src/decomposition/sparse/qr.rs:118-206), the host-side phase FX_STEP_QR replays the
  * reference's numeric QR from: the COLAMD column order (use_colamd != 0; colamd_rs with its default knobs) or the
  * natural one, the elimination tree, the row permutation of Davis section 5.3 and the row patterns of the Householder

@@ -105,6 +105,13 @@ struct fo_result {
     double sse;         // final SSE (scaled space), summed over components
 };
 
+// 0: the platform libm's atan2 (the reference on this platform); 1: the correctly rounded atan2 (fo_expressions.hpp)
+void fo_set_atan2_mode(int mode) { fo::detail::atan2_mode() = mode ? 1 : 0; }
+int fo_get_atan2_mode(void) { return fo::detail::atan2_mode(); }
+void fo_atan2_batch(uint64_t n, const double* y, const double* x, double* out) {
+    for (uint64_t i = 0; i < n; ++i) out[i] = fo::detail::vatan2(fo::detail::V2{x[i], y[i]});
+}
+
 // fiksi/src/rand.rs
 void fo_rng_u32(uint32_t seed, uint32_t n, uint32_t* out) {
     Rng rng = Rng::from_seed(seed);

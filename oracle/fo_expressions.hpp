@@ -6,6 +6,8 @@
 // `distance_squared = (a-b).hypot2()`. Operation order below mirrors the Rust source so results
 // are bit-identical under IEEE-754 without FMA contraction (compile with -ffp-contract=off).
 #pragma once
+#include <quadmath.h>
+
 #include <cmath>
 #include <cstdint>
 
@@ -94,7 +96,20 @@ inline V2 sub(double ax, double ay, double bx, double by) { return V2{ax - bx, a
 inline double cross(V2 a, V2 b) { return a.x * b.y - a.y * b.x; }
 inline double dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
 inline double hypot2(V2 a) { return a.x * a.x + a.y * a.y; }
-inline double vatan2(V2 a) { return std::atan2(a.y, a.x); }
+// Rust's f64::atan2 is the platform libm's (std) or the `libm` crate's (fiksi/src/floatfuncs.rs:48-59): within an
+// ulp of the exact value, different bits on different platforms (glibc 2.35 misrounds ~0.07 % of arguments by an
+// ulp — tests/test_atan2.py). Mode 0 (default) is what the reference computes on THIS platform: glibc's atan2.
+// Mode 1 is the correctly rounded value every such libm approximates, computed independently of the product's
+// routine: libquadmath's atan2q in binary128, rounded to double. The bit-for-bit tests of FX_STEP_QR run both
+// sides in that canonical mode.
+inline int& atan2_mode() {
+    static int mode = 0;
+    return mode;
+}
+inline double vatan2(V2 a) {
+    if (atan2_mode() == 1) return static_cast<double>(atan2q(static_cast<__float128>(a.y), static_cast<__float128>(a.x)));
+    return std::atan2(a.y, a.x);
+}
 constexpr double PI = 3.14159265358979323846264338327950288;
 
 // expressions.rs:327-352

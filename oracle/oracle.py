@@ -61,6 +61,35 @@ def _p(a, t=None):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def set_atan2_mode(mode: str) -> None:
+    """'libm' (default): the platform's atan2, as the reference computes it here; 'correctly_rounded': binary128
+    atan2q rounded to double — the canonical value the bit-for-bit FX_STEP_QR tests run both sides with."""
+    lib().fo_set_atan2_mode(C.c_int({"libm": 0, "correctly_rounded": 1}[mode]))
+
+
+class atan2_mode:
+    """with oracle.atan2_mode('correctly_rounded'): ..."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = "correctly_rounded" if lib().fo_get_atan2_mode() else "libm"
+        set_atan2_mode(self.mode)
+
+    def __exit__(self, *exc):
+        set_atan2_mode(self.old)
+
+
+def atan2(y, x):
+    """Element-wise atan2 in the current mode."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(y)
+    lib().fo_atan2_batch(C.c_uint64(y.size), _p(y), _p(x), _p(out))
+    return out
+
+
 def rng_u32(seed: int, n: int) -> np.ndarray:
     out = np.zeros(n, dtype=np.uint32)
     lib().fo_rng_u32(C.c_uint32(seed), C.c_uint32(n), _p(out))
