@@ -426,6 +426,48 @@ __global__ __launch_bounds__(64) void sp_backward_kernel(SpChol c, ColLists cl, 
     }
 }
 
+// ---- FX_STEP_CHOLESKY_REFINED: one refinement step on the least-squares problem itself (corrected semi-normal
+// equations), as in the fused kernel: t = -r - J delta from the Jacobian rows, (JtJ + lambda I) e = Jt t - lambda delta
+// with the factor at hand, delta += e. All sums in a fixed order.
+__global__ void sp_refine_t_kernel(const uint32_t* __restrict__ jrow_ptr, const uint32_t* __restrict__ jcol,
+                                   const double* __restrict__ jvals, const double* __restrict__ r,
+                                   const double* __restrict__ delta, uint32_t m, double* __restrict__ t) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    double acc = -r[row];
+    for (uint32_t p = jrow_ptr[row]; p < jrow_ptr[row + 1]; ++p) acc -= jvals[p] * delta[jcol[p]];
+    t[row] = acc;
+}
+__global__ void sp_refine_rhs_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx,
+                                     const uint32_t* __restrict__ crow, const double* __restrict__ jvals,
+                                     const double* __restrict__ t, const double* __restrict__ delta, double lambda, uint32_t nv,
+                                     double* __restrict__ out) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nv) return;
+    double s = 0.0;
+    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * t[crow[p]];
+    out[c] = s - lambda * delta[c];
+}
+__global__ void sp_add_kernel(const double* __restrict__ e, uint32_t n, double* __restrict__ x) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += e[i];
+}
+// L y = b with the stored factor (the factorization kernel does this sweep on the fly; the refinement needs it again):
+// row gathers, lists in ascending order, levels bottom up. y overwrites b.
+__global__ __launch_bounds__(64) void sp_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl, const double* __restrict__ l,
+                                                        double* __restrict__ b) {
+    const int lane = threadIdx.x;
+    const uint32_t list = cl.first + blockIdx.x;
+    for (uint32_t q = cl.ptr[list]; q < cl.ptr[list + 1]; ++q) {
+        const uint32_t j = cl.cols[q];
+        double part = 0.0;
+        for (uint32_t p = lr.rptr[j] + lane; p < lr.rptr[j + 1]; p += 64) part = fma(l[lr.ridx[p]], ld_l2(b + lr.rcol[p]), part);
+        part = wave_sum64(part);
+        if (lane == 0) b[j] = (ld_l2(b + j) - part) / l[c.lcolptr[j]];
+        __syncthreads();
+    }
+}
+
 // trial point: xs_dst[fvar[perm[k]]] = xs_src[...] + delta[k]
 __global__ void sp_trial_kernel(const uint32_t* __restrict__ fvar, const uint32_t* __restrict__ perm, uint32_t nv,
                                 const double* __restrict__ delta, const double* __restrict__ xs_src,
@@ -685,6 +727,7 @@ struct ComponentPlan {
     uint32_t m = 0, nv = 0, nnz_j = 0, nnz_a = 0, nnz_l = 0;
     std::vector<uint32_t> rows, fvar;
     std::vector<uint32_t> jrow_ptr, jslot;
+    std::vector<uint32_t> jcol;                        // new column of every entry of J (row-major), for the refined step
     std::vector<uint32_t> perm;                        // new column -> old column
     std::vector<uint32_t> apair_ptr, apairs;           // gather lists of A
     std::vector<uint32_t> cptr, cidx, crow;            // columns of J (permuted order) for the rhs
@@ -703,6 +746,7 @@ struct BlockOnDevice {
     uint32_t* d_perm = nullptr;
     SpJac jac{};
     uint32_t *d_apair_ptr = nullptr, *d_apairs = nullptr, *d_cptr = nullptr, *d_cidx = nullptr, *d_crow = nullptr;
+    uint32_t* d_jcol = nullptr;
     SpChol chol{};
     SpRowsOfL lrows{};
     ColLists lists{};
@@ -784,6 +828,7 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
         P.jrow_ptr[r + 1] = (uint32_t)jcol.size();
     }
     P.nnz_j = (uint32_t)jcol.size();
+    P.jcol = jcol;
 
     // --- columns of J (for the rhs) and pattern of A (lower triangle, new numbering)
     std::vector<uint32_t> ccount(P.nv + 1, 0);
@@ -1193,6 +1238,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
             blk->d_cptr = sp.up(Q.cptr);
             blk->d_cidx = sp.up(Q.cidx);
             blk->d_crow = sp.up(Q.crow);
+            blk->d_jcol = sp.up(Q.jcol);
             blk->chol.lcolptr = sp.up(Q.lcolptr);
             blk->chol.lrow = sp.up(Q.lrow);
             blk->chol.l2a = sp.up(Q.l2a);
@@ -1232,6 +1278,9 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         double* d_l = pool.alloc<double>(P.nnz_l);
         double* d_rhs = pool.alloc<double>(nv);
         double* d_delta = pool.alloc<double>(nv);
+        const bool refined = !lbfgs && o.solver == FX_STEP_CHOLESKY_REFINED;
+        double* d_t = refined ? pool.alloc<double>(std::max(m, 1u)) : nullptr;
+        double* d_e = refined ? pool.alloc<double>(std::max(nv, 1u)) : nullptr;
         if (pool.err != hipSuccess) return pool.err;
 
         auto eval = [&](int buf, bool want_j, double* sse_out) -> hipError_t {
@@ -1369,6 +1418,21 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                     cl.first = P.level_ptr[v];
                     hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl,
                                        d_l, d_delta);
+                }
+                if (refined && nv && m) {
+                    hipLaunchKernelGGL(sp_refine_t_kernel, grid_for(m), dim3(256), 0, stream, jac.jrow_ptr, blk->d_jcol, d_j[cur], d_r[cur], d_delta, m, d_t);
+                    hipLaunchKernelGGL(sp_refine_rhs_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[cur], d_t, d_delta, lambda, nv, d_e);
+                    for (uint32_t v = 0; v < nlevels; ++v) {
+                        ColLists cl = lists;
+                        cl.first = P.level_ptr[v];
+                        hipLaunchKernelGGL(sp_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, lrows, cl, d_l, d_e);
+                    }
+                    for (uint32_t v = nlevels; v-- > 0;) {
+                        ColLists cl = lists;
+                        cl.first = P.level_ptr[v];
+                        hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl, d_l, d_e);
+                    }
+                    hipLaunchKernelGGL(sp_add_kernel, grid_for(nv), dim3(256), 0, stream, d_e, nv, d_delta);
                 }
                 hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_delta, nv, d_scal + 3);
                 if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);

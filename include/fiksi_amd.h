@@ -120,7 +120,9 @@ typedef enum fx_step_solver {
                                     (corrected semi-normal equations: the residual -r - J delta comes
                                     from the Jacobian rows, not from JtJ) — the step then has the
                                     accuracy of the reference's QR on ill-conditioned sketches, for
-                                    about a fifth more time.                                        */
+                                    about a fifth more time. Every path honours it (fused, wide, walker,
+                                    sparse) except the grouped kernel, whose batches then run one System
+                                    per wavefront.                                                     */
     FX_STEP_QR = 2 /* the reference's own numerics (lm.rs:98-132, solvi qr.rs:226-356): Householder QR of
                       [J; sqrt(lambda) I] in the reference's column order (COLAMD, computed on the host) and row
                       order, every sum taken in the reference's order, nothing fused. On sketches without angle

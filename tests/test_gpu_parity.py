@@ -412,6 +412,31 @@ def test_refined_step_follows_the_qr_oracle_more_closely(fiksi, oracle, ctx):
     assert np.array_equal(r0["accepted"], r1["accepted"]) and np.max(np.abs(v0 - v1)) < 1e-8
 
 
+def test_refined_step_on_the_sparse_path(fiksi, oracle, ctx):
+    """Systems beyond one wavefront (fx_sparse.hip) honour FX_STEP_CHOLESKY_REFINED too — it is also what FX_STEP_QR
+    runs them with: on large ill-conditioned sketches the final SSE follows the oracle an order of magnitude more
+    closely than the plain normal-equation step; well-conditioned ones keep their path."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import random_big_sketch
+
+    b = workloads.concat([random_big_sketch(1000 * 90 + s, 90).flatten() for s in range(24)])
+    v_o, r_o = oracle.solve_batch(b, mode=3, trial_cap=4096, nthreads=8)
+    q = {}
+    for solver in (0, 1, 2):
+        v, r = ctx.system_solve_batch(b, abi.solving_opts(solver=solver))
+        ok = np.isfinite(r["sse"]) & np.isfinite(r_o["sse"])
+        d = (np.abs(r["sse"] - r_o["sse"]) / np.maximum(np.abs(r_o["sse"]), 1e-12))[ok]
+        q[solver] = (float(np.median(d)), float(np.quantile(d, 0.9)), v)
+    assert q[1][1] <= 0.3 * q[0][1] and q[1][1] <= 1e-9, q
+    assert np.array_equal(q[1][2], q[2][2])  # FX_STEP_QR == the refined step on these
+    for big in (workloads.hinged_triangles(2, 64), workloads.large_sketch(300)):
+        v, r = ctx.system_solve_batch(big, abi.solving_opts(solver=1))
+        vo, ro = oracle.solve_batch(big, mode=3)
+        assert np.array_equal(r["accepted"], ro["accepted"]) and np.array_equal(r["trials"], ro["trials"])
+        assert np.allclose(r["sse"], ro["sse"], rtol=1e-6, atol=1e-12)
+
+
 def test_dense_jacobian_entry_point_bit_exact(fiksi, oracle, ctx):
     """fx_eval_residual_dense_jacobian == Problem::calculate_residuals_and_jacobian (subsystem.rs:106-124):
     every variant, fixed variables dropped, and the dense scatter's overwrite of a repeated column (the
