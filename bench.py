@@ -12,13 +12,24 @@ check), every step starting from the same start values. Inputs are uploaded befo
 N > 1: one process per GPU (torchrun / torch.distributed, backend nccl == RCCL); each rank solves
 its own 100k-system shard (weak scaling, no data-path collective); RCCL is used only for the
 barrier, the max-over-ranks time and the sum of the throughput counters.
+`--scaling strong` is BASELINE configs[3] (cfg4) as written instead: ONE 100k-system batch, rank r solves its
+contiguous shard of 100k / N systems (workloads.shard). At N = 1 the line also carries `cfg4_prediction`: the
+measured time of the 1/2, 1/4 and 1/8 shards on this GPU, i.e. the strong-scaling curve before an 8-GPU node
+shows up.
 
 Prints ONE JSON line (rank 0). Besides the contract fields it carries
   roofline      — the Jacobian-assembly kernel (K1, `eval_rows_kernel<true>`), the HBM-bound kernel the
                   north-star prices against the 8 TB/s roofline: algorithmic bytes (SURVEY §8d:
-                  2560 B per ring16 evaluation) / mean launch time from HIP events on the launch stream
+                  2560 B per ring16 evaluation) / mean launch time from HIP events on the launch stream;
+                  + the same kernel on a 500k-system batch whose footprint (1.15 GB per launch) is 4.5x the
+                  256 MiB Infinity Cache (`frac_past_l3`), and both fractions by counter bytes
   solve_kernel  — the fused per-system solve kernel that the timed region consists of (latency /
                   f64-VALU bound by construction; its HBM traffic is ~1.5 KB per system)
+  step_solvers  — what the other LM step solvers cost on the same resident batch: FX_STEP_CHOLESKY_REFINED and
+                  FX_STEP_QR (the reference's numerics, bit-identical paths)
+  reference_bench_group — the reference's own criterion group (fiksi_bench.rs:46-73: hinged triangles, sizes
+                  1 / 4 / 16 / 64) as batches and as single System::solve latency, each beside the oracle
+  host_path     — fx_system_solve_batch end to end (host analysis + upload + solve + download)
   cpu_baseline  — the CPU oracle (C++ restatement of the reference algorithm: COO->CSC, COLAMD,
                   sparse Householder QR LM) on the same systems, on this box's host cores.
 """
@@ -47,7 +58,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--systems", type=int, default=SYSTEMS_PER_GPU, help="systems per GPU (default: the BASELINE config)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --systems per GPU (default); strong: --systems in total, split over the GPUs (cfg4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="the headline + roofline only (no side workloads)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="systems in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -107,9 +121,14 @@ def main() -> int:
             dist.init_process_group(backend=backend)
         reduce_device = "cuda" if backend == "nccl" else None
 
-    # ---- inputs: this rank's shard (weak scaling: a full cfg3 batch per GPU, distinct seeds) ----
-    n_sys = args.systems
-    batch = workloads.ring16(n_sys, seed0=distributed.rank_seed(1000, rank, n_sys))
+    # ---- inputs: this rank's shard. weak scaling: a full cfg3 batch per GPU, distinct seeds; strong scaling
+    # (cfg4): the one batch of --systems sketches, rank r takes its contiguous shard
+    if args.scaling == "strong":
+        batch = workloads.shard(workloads.ring16(args.systems, seed0=1000), rank, world)
+        n_sys = len(batch["var_off"]) - 1
+    else:
+        n_sys = args.systems
+        batch = workloads.ring16(n_sys, seed0=distributed.rank_seed(1000, rank, n_sys))
     ctx = fiksi_amd.Context(local_rank)
     db = ctx.upload(batch)
     opts = abi.solving_opts()  # SolvingOptions::DEFAULT + the reference LM constants
@@ -176,7 +195,7 @@ def main() -> int:
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -198,8 +217,11 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": k1_gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("eval_rows_kernel<true>", n_sys),
-                "traffic_source": "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                  "passes; read bytes = 2 x FETCH_SIZE KiB per the gfx950 correction)",
+                "traffic_source": "profiles/round2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                  "passes; read bytes = 2 x FETCH_SIZE KiB per the gfx950 correction, checked on a "
+                                  "known-byte kernel with K1's access widths: tools/probes/fetch_calib.hip)",
+                "frac_by_counter_bytes": (lambda t: None if t is None else t / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)(
+                    pmc_traffic("eval_rows_kernel<true>", n_sys)),
                 "algorithmic_bytes_per_launch": k1_bytes,
                 "avg_launch_ms": k1_ms,
                 "launches": k1_launches,
@@ -222,8 +244,14 @@ def main() -> int:
                         "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead",
             },
         }
-        if world == 1:
+        if world == 1 and args.scaling == "weak":
+            out["roofline"].update(k1_past_l3(ctx, workloads))
+        if world == 1 and not args.quick:
+            out["step_solvers"] = step_solvers(ctx, db, abi, np, n_sys, solve_ms)
+            out["cfg4_prediction"] = cfg4_prediction(ctx, abi, workloads, batch, solve_ms)
             out["other_workloads"] = other_workloads(ctx, abi, workloads, np, n_sys)
+            out["reference_bench_group"] = reference_bench_group(ctx, abi, workloads, np)
+            out["host_path"] = host_path(ctx, batch, np)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -234,6 +262,138 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+
+def k1_past_l3(ctx, workloads, n_big: int = 500_000):
+    """K1 again on a batch whose per-launch traffic (500k ring16 sketches: 1.15 GB moved, 1.28 GB algorithmic) is
+    4.5x the 256 MiB Infinity Cache: nothing one launch reads can still be on the die from the launch before."""
+    b = workloads.ring16(n_big, seed0=5_000_000)
+    db = ctx.upload(b)
+    for _ in range(2):
+        db.eval_residual_jacobian(0)
+    ctx.synchronize()
+    n = 12
+    ctx.timer_begin()
+    for _ in range(n):
+        db.eval_residual_jacobian(0)
+    ms = ctx.timer_end() / n
+    nbytes = workloads.k1_algorithmic_bytes(b, db.nnz)
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic = pmc_traffic("eval_rows_kernel<true>", n_big)
+    db.free()
+    return {
+        "achieved_past_l3": gbs, "frac_past_l3": gbs / HBM_PEAK_GBS, "past_l3_systems": n_big, "past_l3_avg_launch_ms": ms,
+        "past_l3_algorithmic_bytes_per_launch": nbytes, "past_l3_traffic": traffic,
+        "frac_past_l3_by_counter_bytes": None if traffic is None else traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    }
+
+
+def _time_solves(ctx, db, opts, reps=3):
+    db.system_solve(opts)  # warm-up (plans of the mode are built here)
+    ctx.synchronize()
+    ctx.timer_begin()
+    for _ in range(reps):
+        db.system_solve(opts)
+    return ctx.timer_end() / reps
+
+
+def step_solvers(ctx, db, abi, np, n_sys, default_ms):
+    """The same resident batch with the other LM step solvers (include/fiksi_amd.h: fx_step_solver)."""
+    out = {"cholesky": {"ms_per_step": default_ms, "note": "the headline: plain normal equations, grouped kernel"}}
+    for name, solver in (("cholesky_refined", 1), ("qr_reference_numerics", 2)):
+        ms = _time_solves(ctx, db, abi.solving_opts(solver=solver), reps=2)
+        res = db.get_results()
+        conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+        out[name] = {"ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3), "converged_fraction": conv / n_sys,
+                     "lm_trials": int(res["trials"].sum()), "cost_vs_headline": ms / default_ms}
+    out["qr_reference_numerics"]["note"] = ("solvi's sparse Householder QR replayed operation by operation (COLAMD order from the host), "
+                                            "correctly rounded atan2: every iterate bit-identical to the reference algorithm")
+    return out
+
+
+def cfg4_prediction(ctx, abi, workloads, batch, full_ms):
+    """Strong scaling (BASELINE configs[3]) predicted from one GPU: the time of the first 1/N shard of the same batch.
+    An N-GPU run takes as long as its slowest shard; efficiency = t(1) / (N t(1/N))."""
+    out = {"systems_total": len(batch["var_off"]) - 1, "ms_1_gpu": full_ms, "shards": {}}
+    for n in (2, 4, 8):
+        sh = workloads.shard(batch, 0, n)
+        db = ctx.upload(sh)
+        ms = _time_solves(ctx, db, abi.solving_opts(), reps=5)
+        db.free()
+        out["shards"][str(n)] = {"systems": len(sh["var_off"]) - 1, "ms_per_step": ms, "predicted_speedup": full_ms / ms,
+                                 "predicted_efficiency": full_ms / (n * ms)}
+    return out
+
+
+def reference_bench_group(ctx, abi, workloads, np):
+    """fiksi/benches/fiksi_bench.rs:46-73: `solve/hinged_triangles`, sizes 1, 4, 16, 64 (6 / 18 / 66 / 258 variables).
+    The reference measures the latency of ONE System::solve per size; here each size is reported (a) as that
+    latency through the builder API (System::solve on a fresh upload: host flattening + analysis + upload + solve +
+    download), next to the oracle's single-thread time for the same solve, and (b) as a resident batch."""
+    import time as _t
+
+    import fiksi_amd
+    from oracle import oracle as O
+
+    out = {}
+    for n_tri, n_batch in ((1, 100_000), (4, 100_000), (16, 20_000), (64, 256)):
+        entry = {"variables": 2 + 4 * n_tri, "constraints": 3 * n_tri}
+        # (a) one System::solve through the builder API, values reset between solves as the reference bench does
+        s = fiksi_amd.System()
+        hinge = fiksi_amd.elements.Point.create(s, 0., 0.)
+        pts = [(hinge, 0., 0.)]
+        for t in range(n_tri):
+            p1 = fiksi_amd.elements.Point.create(s, -1., float(t))
+            p2 = fiksi_amd.elements.Point.create(s, 1., float(t))
+            pts += [(p1, -1., float(t)), (p2, 1., float(t))]
+            fiksi_amd.constraints.PointPointDistance.create(s, hinge, p1, 2.)
+            fiksi_amd.constraints.PointPointDistance.create(s, hinge, p2, 2.)
+            fiksi_amd.constraints.PointPointDistance.create(s, p1, p2, 3.)
+        reps = 30 if n_tri < 64 else 8
+        s.solve(ctx=ctx)
+        dt = 0.0
+        for _ in range(reps):
+            for h, x, y in pts:
+                h.update_value(s, x, y)
+            t0 = _t.perf_counter()
+            s.solve(ctx=ctx)
+            dt += _t.perf_counter() - t0
+        r = s.constraint_residuals(ctx=ctx)
+        entry["single_solve_ms"] = dt / reps * 1e3
+        entry["single_solve_sse"] = float((r * r).sum())  # fiksi_bench.rs:65-72 asserts < 1e-4
+        one = workloads.hinged_triangles(1, n_tri)
+        O.solve_batch(one, mode=3)
+        t0 = _t.perf_counter()
+        for _ in range(reps):
+            O.solve_batch(one, mode=3)
+        entry["single_solve_ms_oracle_1_thread"] = (_t.perf_counter() - t0) / reps * 1e3
+        # (b) a resident batch of the same sketch
+        b = workloads.hinged_triangles(n_batch, n_tri)
+        db = ctx.upload(b)
+        ms = _time_solves(ctx, db, abi.solving_opts(), reps=2)
+        res = db.get_results()
+        conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+        entry["batch"] = {"systems": n_batch, "ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3),
+                          "converged_fraction": conv / n_batch, "triangles_per_sec": conv * n_tri / (ms * 1e-3)}
+        db.free()
+        out[f"hinged_triangles_{n_tri}"] = entry
+    return out
+
+
+def host_path(ctx, batch, np):
+    """fx_system_solve_batch on host buffers: host analysis + upload + solve + download (PCIe inclusive; never `value`)."""
+    import time as _t
+
+    n = len(batch["var_off"]) - 1
+    ctx.system_solve_batch(batch)
+    t0 = _t.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        v, res = ctx.system_solve_batch(batch)
+    dt = (_t.perf_counter() - t0) / reps
+    conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+    return {"entry_point": "fx_system_solve_batch", "systems": n, "ms_per_call": dt * 1e3, "converged_systems_per_sec": conv / dt}
 
 
 def other_workloads(ctx, abi, workloads, np, n_sys: int):
@@ -274,25 +434,30 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
     out["cfg5_share_f32"] = {
         "systems": 125_000, "dtype": "f32", "ms_per_step": ms, "settled_systems_per_sec": settled / (ms * 1e-3),
         "settled_fraction": settled / 125_000, "gn_iters_per_sec": int(res["accepted"].sum()) / (ms * 1e-3),
+        "lm_trials": int(res["trials"].sum()),
     }
+    ms64 = _time_solves(ctx, db, abi.solving_opts())
+    res = db.get_results()
+    out["cfg5_share_f64_same_batch"] = {"systems": 125_000, "dtype": "f64", "ms_per_step": ms64, "lm_trials": int(res["trials"].sum()),
+                                        "settled_fraction": int(np.count_nonzero(res["exit"] <= 2)) / 125_000}
     db.free()
     return out
 
 
 def pmc_traffic(kernel_substr: str, n_sys: int):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summary (collected in separate
-    --pmc passes on the same workload); None when the summary does not cover this batch size."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if int(d.get("n_systems", -1)) != int(n_sys):
-            return None
-        for name, v in d["kernels"].items():
-            if kernel_substr in name:
-                return int(v["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (collected in separate
+    --pmc passes on the same workload; one file per batch size); None when no summary covers this size."""
+    for name in ("round2_pmc_traffic.json", "round2_pmc_traffic_500k.json", "round1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if int(d.get("n_systems", -1)) != int(n_sys):
+                continue
+            for kname, v in d["kernels"].items():
+                if kernel_substr in kname:
+                    return int(v["hbm_bytes_per_launch"])
+        except Exception:
+            continue
     return None
 
 

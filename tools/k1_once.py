@@ -1,0 +1,12 @@
+"""Diagnostic driver for rocprofv3: the Jacobian-assembly kernel (K1) alone on a batch of n ring16 sketches."""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import fiksi_amd
+from fiksi_amd import workloads
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ctx = fiksi_amd.Context(0)
+db = ctx.upload(workloads.ring16(n, seed0=5_000_000))
+for _ in range(reps):
+    db.eval_residual_jacobian(0)
+ctx.synchronize()
