@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfiksi_amd.so")
+# FIKSI_AMD_LIBRARY: another build of the same C ABI — the host-only sanitizer build (`make -C fiksi_amd/csrc asan`,
+# tests/test_host_sanitizers.py); every device entry point of that one reports FX_ERR_NO_DEVICE
+LIB_PATH = os.environ.get("FIKSI_AMD_LIBRARY") or os.path.join(_HERE, "libfiksi_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -101,6 +103,7 @@ SIGNATURES = [
     ("fx_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("fx_ctx_create", C.c_int, [C.POINTER(_vp), C.c_int]),
     ("fx_ctx_destroy", None, [_vp]),
+    ("fx_ctx_set_routing", C.c_int, [_vp, C.c_int, C.c_uint32]),
     ("fx_ctx_synchronize", C.c_int, [_vp]),
     ("fx_ctx_device_name", C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     ("fx_lm_opts_default", None, [C.POINTER(FxLmOpts)]),

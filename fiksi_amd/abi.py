@@ -195,6 +195,10 @@ class Context:
         check(lib.fx_ctx_device_name(self._h, buf, 256), "fx_ctx_device_name")
         return buf.value.decode()
 
+    def set_routing(self, grouped: int = -1, grouped_min_systems: int = 0):
+        """grouped: -1 by batch size (default), 0 never, 1 whenever the batch qualifies (fx_ctx_set_routing)."""
+        check(lib.fx_ctx_set_routing(self._h, grouped, grouped_min_systems), "fx_ctx_set_routing")
+
     def synchronize(self):
         check(lib.fx_ctx_synchronize(self._h), "fx_ctx_synchronize")
 

@@ -1,12 +1,17 @@
 // C ABI of libfiksi_amd.so (include/fiksi_amd.h): validation, Jacobian structure, HBM residency,
 // kernel launches. Host logic only; every numeric result comes from the HIP kernels in
 // fx_kernels.hip. There is deliberately no CPU compute path in this library.
+#ifdef FX_HOST_ONLY
+#include "fx_hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -474,7 +479,12 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             bool simple = true;
             for (uint32_t i = 0; i < nrw; ++i) {
                 simple = simple && p.row_simple[r0 + i];
-                p.row_sysoff[r0 + i] = (uint8_t)(p.expr_sys[r0 + i] - bi.sys0);  // < 256: at most 256 rows per block
+                // one byte per row: fits while the block's rows belong to at most 256 consecutive Systems. Systems
+                // without expressions take an index without taking a row, so a block can span more — such a block
+                // is not "simple": its rows then read their System's first variable from expr_var0 instead
+                const uint32_t off = p.expr_sys[r0 + i] - bi.sys0;
+                simple = simple && off <= 255u;
+                p.row_sysoff[r0 + i] = (uint8_t)(off & 0xFFu);
             }
             bi.flags = simple ? 1u : 0u;  // jbase / jcount are filled when the CSR structure is built
             p.blk_info[blk] = bi;
@@ -496,6 +506,13 @@ struct fx_ctx {
     struct Block { void* p; size_t size; };
     std::vector<Block> free_blocks;
     size_t free_bytes = 0;
+    // routing of batches of small Systems (fx_ctx_set_routing)
+    int route_grouped = -1;
+    uint32_t grouped_min_systems = 8192u;
+    void route(fx::LmParams& p) const {
+        p.route_grouped = route_grouped;
+        p.grouped_min_systems = grouped_min_systems;
+    }
     static constexpr size_t MAX_CACHED_BYTES = size_t(4) << 30;  // beyond this, released blocks go back to the driver
 
     void* take(size_t bytes, hipError_t& err) {
@@ -1246,6 +1263,10 @@ int fx_ctx_create(fx_ctx** out, int device) {
     fx_ctx* ctx = new (std::nothrow) fx_ctx();
     if (!ctx) return fail(FX_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    if (const char* sw = getenv("FIKSI_AMD_GROUPED")) {  // the default of fx_ctx_set_routing's first option
+        if (sw[0] == '0') ctx->route_grouped = 0;
+        if (sw[0] == '1') ctx->route_grouped = 1;
+    }
     snprintf(ctx->name, sizeof(ctx->name), "%s", prop.name);
     snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
     e = hipSetDevice(device);
@@ -1271,6 +1292,14 @@ void fx_ctx_destroy(fx_ctx* ctx) {
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     ctx->drop_cache();
     delete ctx;
+}
+
+int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    if (grouped < -1 || grouped > 1) return fail(FX_ERR_INVALID, "grouped must be -1 (by batch size), 0 or 1");
+    ctx->route_grouped = grouped;
+    if (grouped_min_systems) ctx->grouped_min_systems = grouped_min_systems;
+    return FX_OK;
 }
 
 int fx_ctx_synchronize(fx_ctx* ctx) {
@@ -1545,6 +1574,7 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
     if (o.lm.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", o.lm.solver);
     fx::LmParams p;
+    ctx->route(p);
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u);
     if (o.decomposer == 1) {
@@ -1567,6 +1597,7 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     if (rc) return rc;
     if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
     fx::LmParams p;
+    ctx->route(p);
     if (opts) p.lm = *opts; else fx_lm_opts_default(&p.lm);
     p.mode = 0;
     if (p.lm.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", p.lm.solver);
@@ -1587,6 +1618,7 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
     fx_solving_opts o;
     if (opts) o = *opts; else fx_solving_opts_default(&o);
     fx::LmParams p;
+    ctx->route(p);
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
     *route = fx::grouped_applies(db->d, p) ? 1 : 0;
@@ -1605,6 +1637,7 @@ int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opt
     FX_HIP(hipMalloc((void**)&dev, 6 * sizeof(unsigned long long)));
     FX_HIP(hipMemsetAsync(dev, 0, 6 * sizeof(unsigned long long), ctx->stream));
     fx::LmParams p;
+    ctx->route(p);
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u);
     p.prof = dev;

@@ -1,6 +1,10 @@
 // Host <-> device plumbing shared by fx_abi.cpp and fx_kernels.hip (not part of the public ABI).
 #pragma once
+#ifdef FX_HOST_ONLY
+#include "fx_hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/fiksi_amd.h"
@@ -119,6 +123,10 @@ struct LmParams {
     fx_lm_opts lm;
     uint32_t mode;  // bit0: scale by system RMS, bit1: LCG perturbation, bit2: MODE_UNITS, bit3: MODE_LBFGS
     unsigned long long* prof = nullptr;  // diagnostic build only: 6 per-phase cycle sums
+    // routing of batches of small Systems (fx_ctx_set_routing): -1 = by batch size, 0 = never the grouped kernel,
+    // 1 = whenever the batch qualifies; the size from which a batch takes it
+    int route_grouped = -1;
+    uint32_t grouped_min_systems = 8192u;
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

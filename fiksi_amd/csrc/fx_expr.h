@@ -7,7 +7,11 @@
 // arithmetic (sqrt and division are correctly rounded on gfx950); the only ulp-level difference
 // is atan2 (device libm vs the host's) in the two angle variants' residuals.
 #pragma once
+#ifdef FX_HOST_ONLY
+#include "fx_hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "fx_atan2.h"

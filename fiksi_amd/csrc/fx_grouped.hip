@@ -26,7 +26,6 @@
 // on the ring16 and hinged-triangle shapes (tests/test_gpu_grouped.py). DESIGN.md section 3.1a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <utility>
 
 #include "fx_device.h"
@@ -1175,13 +1174,12 @@ size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t es, bool units) {
 }
 
 bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
-    // FIKSI_AMD_GROUPED=0 keeps every batch on the one-System-per-wavefront kernel, =1 sends every batch that
-    // qualifies here (tests, A/B measurements). By default a batch must be big enough to fill the chip four
-    // Systems per wavefront: below that one wavefront per System finishes sooner.
-    const char* sw = getenv("FIKSI_AMD_GROUPED");
-    if (sw && sw[0] == '0') return false;
-    const bool forced = sw && sw[0] == '1';
-    if (!forced && b.n_systems < 8192u) return false;
+    // The context's routing option (fx_ctx_set_routing; its default comes from FIKSI_AMD_GROUPED when the context is
+    // created): 0 keeps every batch on the one-System-per-wavefront kernel, 1 sends every batch that qualifies here
+    // (tests, A/B measurements). By default a batch must be big enough to fill the chip four Systems per wavefront:
+    // below that one wavefront per System finishes sooner.
+    if (p.route_grouped == 0) return false;
+    if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     const bool units = (p.mode & MODE_UNITS) != 0;
     if (units && (!b.sys_unit_off || p.prof)) return false;

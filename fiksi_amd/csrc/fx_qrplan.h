@@ -10,7 +10,7 @@
 // The north-star keeps that phase on the host. This header redoes it for one component of one System and
 // hands the device kernel (fx_kernels.hip, qr_step) exactly what it needs to replay the numeric phase
 // operation by operation: the two permutations, the Householder row lists, and which Householder vectors
-// touch which column. Plain C++ (no HIP), so the CPU tests can check it against the oracle.
+// touch which column. Plain C++ (no HIP): tests/test_qr_plan.py checks it on the CPU against an independent restatement of SymbolicQr::build.
 #pragma once
 #include <algorithm>
 #include <climits>

@@ -1,6 +1,10 @@
 // Large-component path (fx_sparse.hip): host structure + device numeric sparse Cholesky LM.
 #pragma once
+#ifdef FX_HOST_ONLY
+#include "fx_hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include "fx_device.h"
 

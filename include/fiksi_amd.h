@@ -196,6 +196,12 @@ const char* fx_last_error(void);           /* thread-local text of the last fail
 int fx_device_count(int* count);           /* HIP devices visible to this process              */
 int fx_ctx_create(fx_ctx** ctx, int device);
 void fx_ctx_destroy(fx_ctx* ctx);
+/* Which kernel batches of small Systems (components of at most 48 free variables) take: grouped = -1 (default): the
+ * grouped kernel — four Systems per wavefront — from grouped_min_systems Systems on (default 8192; 0 keeps the current
+ * value), one wavefront per System below; 0: never the grouped kernel; 1: whenever the batch qualifies. Results do not
+ * depend on it beyond the last bits of sums of LDS float atomics on sketches where several rows add into one entry.
+ * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment. */
+int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);
 int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
 

@@ -238,3 +238,27 @@ def test_large_system_of_many_small_components_is_walked_on_the_device(fiksi, or
     db.system_solve()
     assert np.array_equal(db.get_vars(), v2)
     db.free()
+
+
+def test_k1_with_hundreds_of_constraint_free_systems_between_rows(fiksi, oracle, ctx):
+    """Systems without expressions take a System index without taking a row, so one 256-row block of the
+    Jacobian-assembly kernel can span more than 256 Systems: the per-row System offset (one byte) must not wrap —
+    such blocks read their System's first variable from the per-row table instead."""
+    from fiksi_amd import workloads
+
+    def empty(n):  # n Systems of one unconstrained point each
+        return {"var_off": (2 * np.arange(n + 1)).astype(np.uint32), "expr_off": np.zeros(n + 1, dtype=np.uint32),
+                "vars": np.arange(2.0 * n), "var_fixed": np.zeros(2 * n, dtype=np.uint8), "expr_tag": np.zeros(0, dtype=np.uint8),
+                "expr_idx": np.zeros(0, dtype=np.uint32), "expr_param": np.zeros(0), "var_comp": np.full(2 * n, 0xFFFF, dtype=np.uint16),
+                "expr_comp": np.zeros(0, dtype=np.uint16)}
+
+    b = workloads.concat([workloads.ring16(3), empty(300), workloads.ring16(2, seed0=50), empty(700), workloads.hinged_triangles(2, 4),
+                          empty(1), workloads.ring16(9, seed0=60)])
+    r, (rp, ci, vals) = ctx.eval_residual_jacobian(b)
+    r_o, (rp_o, ci_o, vals_o) = oracle.eval_batch(b)
+    assert np.array_equal(rp.astype(np.int64), rp_o) and np.array_equal(ci.astype(np.int32), ci_o)
+    assert np.array_equal(vals, vals_o)
+    assert np.allclose(r, r_o, rtol=0, atol=4e-15)
+    v, res = ctx.system_solve_batch(b)
+    v_o, res_o = oracle.solve_batch(b, mode=3)
+    assert np.array_equal(res["accepted"], res_o["accepted"]) and np.array_equal(res["ncomp"], res_o["ncomp"])

@@ -1,7 +1,7 @@
 """The grouped kernel (fx_grouped.hip: four Systems per wavefront, components of at most 32 free variables)
 against the oracle and against the one-System-per-wavefront kernel it replaces for large batches.
-`FIKSI_AMD_GROUPED` is read at every launch: "1" sends every qualifying batch to the grouped kernel,
-"0" none; unset, batches of 8192 Systems and more take it."""
+The context's routing option (fx_ctx_set_routing): 1 sends every qualifying batch to the grouped kernel, 0 none;
+by default (-1) batches of 8192 Systems and more take it."""
 import os
 
 import numpy as np
@@ -11,17 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture()
-def routing():
-    old = os.environ.get("FIKSI_AMD_GROUPED")
-
+def routing(ctx):
     def set_(v):
-        if v is None:
-            os.environ.pop("FIKSI_AMD_GROUPED", None)
-        else:
-            os.environ["FIKSI_AMD_GROUPED"] = v
+        ctx.set_routing(-1 if v is None else int(v))
 
     yield set_
-    set_(old)
+    ctx.set_routing(-1)
 
 
 def _solve(ctx, b, **kw):

@@ -167,24 +167,18 @@ def test_two_runs_are_bit_identical_on_mixed_and_random_batches(fiksi, ctx, solv
     """Run-to-run determinism where several rows of one wave instruction add into the same normal-matrix entry
     (LDS float atomics) and with every expression kind: two solves of the same batch give the same bits — for
     each step solver, on the one-System-per-wavefront kernels and (forced) on the grouped kernel."""
-    import os
-
     from fiksi_amd import abi, workloads
 
     flats = [mixed_sketch(300 + s, fix_some=(s % 2 == 0)).flatten() for s in range(120)] + [random_sketch(700 + s).flatten() for s in range(400)]
     b = workloads.concat(flats)
     runs = []
-    for grouped in ("0", "1"):
-        old = os.environ.get("FIKSI_AMD_GROUPED")
-        os.environ["FIKSI_AMD_GROUPED"] = grouped
+    for grouped in (0, 1):
+        ctx.set_routing(grouped)
         try:
             a = ctx.system_solve_batch(b, abi.solving_opts(solver=solver))
             c = ctx.system_solve_batch(b, abi.solving_opts(solver=solver))
         finally:
-            if old is None:
-                os.environ.pop("FIKSI_AMD_GROUPED", None)
-            else:
-                os.environ["FIKSI_AMD_GROUPED"] = old
+            ctx.set_routing(-1)
         assert np.array_equal(_bits(a[0]), _bits(c[0])), grouped
         assert a[1].tobytes() == c[1].tobytes(), grouped
         runs.append(a)

@@ -1,0 +1,35 @@
+"""The library's host-side logic (batch analysis, Jacobian structure, SinglePass decomposition, QR planning with its
+COLAMD, the System builder — ~3 000 lines of index arithmetic) under AddressSanitizer + UndefinedBehaviorSanitizer:
+`make -C fiksi_amd/csrc asan` compiles fx_abi.cpp / fx_builder.cpp with g++ against stubs of the HIP runtime
+(fx_hip_shim.h: every device entry point answers FX_ERR_NO_DEVICE), and the CPU tests of those parts run against that
+library in a child process with the sanitizer runtimes preloaded. GPU AddressSanitizer is not available on the pool;
+the kernels' own indexing is covered by the parity tests."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_logic_under_asan_and_ubsan():
+    csrc = os.path.join(ROOT, "fiksi_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-s", "asan"])
+    lib = os.path.join(ROOT, "fiksi_amd", "libfiksi_host_asan.so")
+    pre = []
+    for name in ("libasan.so", "libubsan.so"):
+        path = subprocess.check_output(["gcc", f"-print-file-name={name}"], text=True).strip()
+        if not os.path.isabs(path):
+            pytest.skip(f"{name} not installed")
+        pre.append(path)
+    env = dict(os.environ, LD_PRELOAD=" ".join(pre), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               FIKSI_AMD_LIBRARY=lib, FIKSI_AMD_HIP_RUNTIME="system")
+    tests = ["tests/test_host.py", "tests/test_single_pass.py", "tests/test_qr_plan.py", "tests/test_reference_suite.py"]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    out = p.stdout + p.stderr
+    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert p.returncode == 0, out[-4000:]

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def harness(tmp_path_factory, oracle):
     so = str(tmp_path_factory.mktemp("hz") / "libhz_harness.so")
     cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-Wall",
-           os.path.join(ROOT, "tests", "cpp", "hz_harness.cpp"), "-o", so]
+           os.path.join(ROOT, "tests", "cpp", "hz_harness.cpp"), "-o", so, "-lquadmath"]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     return C.CDLL(so)

@@ -14,7 +14,7 @@ for k in range(50):
 mixed = workloads.concat(parts)
 for name, b in (("shared structure", workloads.ring16(100000)), ("every 50th sketch differs", mixed)):
     for tag in ('1', '0'):
-        os.environ['FIKSI_AMD_GROUPED'] = tag
+        ctx.set_routing(int(tag))
         db = ctx.upload(b)
         db.system_solve(); ctx.synchronize()
         ctx.timer_begin()

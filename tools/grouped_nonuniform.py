@@ -12,7 +12,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 b = workloads.concat(flats * reps)
 n = len(b['var_off']) - 1
 for tag in ('1', '0'):
-    os.environ['FIKSI_AMD_GROUPED'] = tag
+    ctx.set_routing(int(tag))
     db = ctx.upload(b)
     db.system_solve(); ctx.synchronize()
     ctx.timer_begin()

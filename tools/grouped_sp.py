@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 for name, b in (('hinged11', workloads.hinged_triangles(n, 11)), ('ring16', workloads.ring16(n)), ('hinged5', workloads.hinged_triangles(n, 5))):
     out = {}
     for tag in ('1', '0'):
-        os.environ['FIKSI_AMD_GROUPED'] = tag
+        ctx.set_routing(int(tag))
         db = ctx.upload(b)
         o = abi.solving_opts(decomposer=1)
         db.system_solve(o); ctx.synchronize()
