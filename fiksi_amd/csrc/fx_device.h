@@ -126,7 +126,7 @@ struct LmParams {
     // routing of batches of small Systems (fx_ctx_set_routing): -1 = by batch size, 0 = never the grouped kernel,
     // 1 = whenever the batch qualifies; the size from which a batch takes it
     int route_grouped = -1;
-    uint32_t grouped_min_systems = 8192u;
+    uint32_t grouped_min_systems = 1024u;
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

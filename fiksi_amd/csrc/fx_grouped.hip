@@ -359,8 +359,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     // The product list of a component does not change between its assemblies: the 32-column f64 build (one wavefront
     // per SIMD, registers to spare) keeps each lane's first PWR / PER list words in registers, which takes the list
     // read — one of three dependent LDS round trips per batch of products — out of every assembly.
-    constexpr int PWR = (NC == 2 && sizeof(T) == 8) ? 28 : 0;
-    constexpr int PER = (NC == 2 && sizeof(T) == 8) ? 10 : 0;
+    constexpr int PWR = (NC == 2) ? 28 : 0;
+    constexpr int PER = (NC == 2) ? 10 : 0;
     uint32_t pw_reg[PWR > 0 ? PWR : 1], pe_reg[PER > 0 ? PER : 1];
 #pragma unroll
     for (int u = 0; u < (PWR > 0 ? PWR : 1); ++u) pw_reg[u] = 0xFFFFFFFFu;
@@ -1013,6 +1013,13 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     lambda *= o.reject_factor;
                     if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
                         exit_code = FX_EXIT_NAN;  // NaN trial point: the reference would double lambda forever
+                        phase = GP_FINISH;
+                    } else if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) {
+                        // f32 only (fx_lm_opts_default_f32): a rejected trial whose SSE is within ftol of the current one
+                        // is round-off, not a worse point — the solve has stagnated at what f32 can resolve. Without this
+                        // exit such Systems double lambda dozens of times until |delta|^2 < step_tol, and a batch waits
+                        // for them.
+                        exit_code = FX_EXIT_FTOL;
                         phase = GP_FINISH;
                     }
                 }

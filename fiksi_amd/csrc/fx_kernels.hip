@@ -1030,6 +1030,13 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                         done = true;
                         break;
                     }
+                    if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) {
+                        // f32 only: a rejected trial within ftol of the current SSE is round-off — stagnated
+                        // (see fx_lm_opts_default_f32, and the same branch in fx_grouped.hip)
+                        exit_code = FX_EXIT_FTOL;
+                        done = true;
+                        break;
+                    }
                 }
             }
         }

@@ -197,7 +197,8 @@ int fx_device_count(int* count);           /* HIP devices visible to this proces
 int fx_ctx_create(fx_ctx** ctx, int device);
 void fx_ctx_destroy(fx_ctx* ctx);
 /* Which kernel batches of small Systems (components of at most 48 free variables) take: grouped = -1 (default): the
- * grouped kernel — four Systems per wavefront — from grouped_min_systems Systems on (default 8192; 0 keeps the current
+ * grouped kernel — four Systems per wavefront — from grouped_min_systems Systems on (default 1024 — measured: at least as fast as one wavefront
+ * per System from 1000 Systems up, tools/route_threshold.py; 0 keeps the current
  * value), one wavefront per System below; 0: never the grouped kernel; 1: whenever the batch qualifies. Results do not
  * depend on it beyond the last bits of sums of LDS float atomics on sketches where several rows add into one entry.
  * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment. */
@@ -206,7 +207,9 @@ int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
 
 void fx_lm_opts_default(fx_lm_opts* opts);           /* lm.rs:108-189 literals                */
-/* f32 variant: same schedule, ftol 1e-5 and lambda_min 1e-7 (what f32 round-off can resolve). */
+/* f32 variant: same schedule, ftol 1e-4 and lambda_min 1e-7 (what f32 round-off can resolve). With precision = 32
+ * ftol also ends a solve on a REJECTED trial whose SSE exceeds the current one by no more than ftol * SSE: that is
+ * round-off, not a worse point (the f64 path keeps the reference's rule: only accepted steps test ftol). */
 void fx_lm_opts_default_f32(fx_lm_opts* opts);
 void fx_solving_opts_default(fx_solving_opts* opts); /* SolvingOptions::DEFAULT, lib.rs:232-236 */
 

@@ -1,7 +1,7 @@
 """The grouped kernel (fx_grouped.hip: four Systems per wavefront, components of at most 32 free variables)
 against the oracle and against the one-System-per-wavefront kernel it replaces for large batches.
 The context's routing option (fx_ctx_set_routing): 1 sends every qualifying batch to the grouped kernel, 0 none;
-by default (-1) batches of 8192 Systems and more take it."""
+by default (-1) batches of 1024 Systems and more take it."""
 import os
 
 import numpy as np
@@ -176,10 +176,10 @@ def test_mixed_kinds_fixed_variables_and_several_components(fiksi, oracle, ctx, 
     if not f32:
         # the criteria of tests/test_gpu_fuzz.py (random sketches are often ill-conditioned or degenerate; uncapped,
         # the reference loops forever on some of them)
-        from test_gpu_fuzz import _compare
+        from helpers import compare_outcomes
 
         v_o, res_o = oracle.solve_batch(b, mode=3, trial_cap=4096, nthreads=8)
-        same, verdict = _compare(b, res, res_o, v, v_o)
+        same, verdict = compare_outcomes(b, v, res, v_o, res_o, oracle, tight=False)
         assert same > 0.6 and verdict > 0.85, (same, verdict)
 
 

@@ -332,7 +332,7 @@ def test_f32_mode_matches_f64_oracle_within_f32_tolerances(fiksi, oracle, ctx):
     from fiksi_amd import abi, workloads
 
     o32 = abi.solving_opts(f32=True)
-    assert o32.lm.precision == 32 and o32.lm.ftol == 1e-5 and o32.lm.lambda_min == 1e-7
+    assert o32.lm.precision == 32 and o32.lm.ftol == 1e-4 and o32.lm.lambda_min == 1e-7
     b = workloads.ring16(2048)
     v, res = ctx.system_solve_batch(b, o32)
     v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
