@@ -301,6 +301,11 @@ def _time_solves(ctx, db, opts, reps=3):
 def step_solvers(ctx, db, abi, np, n_sys, default_ms):
     """The same resident batch with the other LM step solvers (include/fiksi_amd.h: fx_step_solver)."""
     out = {"cholesky": {"ms_per_step": default_ms, "note": "the headline: plain normal equations, grouped kernel"}}
+    # NOT the headline: the same solve with the Systems handed out longest-first, by the trial counts of the previous
+    # solve of this resident batch (fx_batch_schedule_by_last_solve; results bit-identical)
+    db.schedule_by_last_solve(True)
+    out["cholesky"]["ms_per_step_history_scheduled"] = _time_solves(ctx, db, abi.solving_opts(), reps=5)
+    db.schedule_by_last_solve(False)
     for name, solver in (("cholesky_refined", 1), ("qr_reference_numerics", 2)):
         ms = _time_solves(ctx, db, abi.solving_opts(solver=solver), reps=2)
         res = db.get_results()
@@ -436,6 +441,9 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
         "settled_fraction": settled / 125_000, "gn_iters_per_sec": int(res["accepted"].sum()) / (ms * 1e-3),
         "lm_trials": int(res["trials"].sum()),
     }
+    db.schedule_by_last_solve(True)
+    out["cfg5_share_f32"]["ms_per_step_history_scheduled"] = _time_solves(ctx, db, o32)
+    db.schedule_by_last_solve(False)
     ms64 = _time_solves(ctx, db, abi.solving_opts())
     res = db.get_results()
     out["cfg5_share_f64_same_batch"] = {"systems": 125_000, "dtype": "f64", "ms_per_step": ms64, "lm_trials": int(res["trials"].sum()),

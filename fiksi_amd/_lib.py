@@ -115,6 +115,7 @@ SIGNATURES = [
     ("fx_batch_free", None, [_vp, _vp]),
     ("fx_batch_set_vars", C.c_int, [_vp, _vp, _vp]),
     ("fx_batch_set_params", C.c_int, [_vp, _vp, _vp]),
+    ("fx_batch_schedule_by_last_solve", C.c_int, [_vp, _vp, C.c_int]),
     ("fx_batch_get_vars", C.c_int, [_vp, _vp, _vp]),
     ("fx_batch_get_results", C.c_int, [_vp, _vp, _vp]),
     ("fx_batch_nnz", C.c_uint64, [_vp]),

@@ -325,6 +325,10 @@ class DeviceBatch:
         check(lib.fx_debug_solve_route(self.ctx.handle, self._h, C.byref(o), C.byref(r)), "fx_debug_solve_route")
         return int(r.value)
 
+    def schedule_by_last_solve(self, enable: bool = True):
+        """Later solves start the Systems that took the most LM trials in the last solve first (results unchanged)."""
+        check(lib.fx_batch_schedule_by_last_solve(self.ctx.handle, self._h, 1 if enable else 0), "fx_batch_schedule_by_last_solve")
+
     def eval_residual_jacobian(self, which: int = 0):
         check(lib.fx_eval_residual_jacobian_device(self.ctx.handle, self._h, which), "fx_eval_residual_jacobian_device")
 

@@ -568,6 +568,7 @@ struct fx_dbatch {
     bool comp_walk_built = false;
     std::vector<uint8_t> h_comp_walk;  // per System: 1 = walked on the device
     uint32_t n_units = 0, n_unit_rows = 0, n_unit_vars = 0;  // sizes of the SinglePass block arrays on the device
+    uint32_t* d_order = nullptr;  // fx_batch_schedule_by_last_solve
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -1540,6 +1541,33 @@ int fx_batch_set_params(fx_ctx* ctx, fx_dbatch* db, const double* expr_param) {
     if (db->n_large) std::copy(expr_param, expr_param + db->d.n_exprs, db->h_expr_param.begin());
     FX_HIP(hipMemcpyAsync(db->d.expr_param, expr_param, (size_t)db->d.n_exprs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     FX_HIP(hipStreamSynchronize(ctx->stream));
+    return FX_OK;
+}
+
+int fx_batch_schedule_by_last_solve(fx_ctx* ctx, fx_dbatch* db, int enable) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db) return fail(FX_ERR_INVALID, "batch is NULL");
+    fx::DeviceBatch& d = db->d;
+    if (!enable) {
+        d.order = nullptr;  // (the array stays allocated with the batch)
+        return FX_OK;
+    }
+    const uint32_t n = d.n_systems;
+    std::vector<fx_result> res(n);
+    if (n) FX_HIP(hipMemcpyAsync(res.data(), d.results, (size_t)n * sizeof(fx_result), hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> order(n);
+    for (uint32_t s = 0; s < n; ++s) order[s] = s;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) { return res[a].trials > res[b2].trials; });
+    if (!db->d_order) {
+        rc = dev_alloc_copy(ctx, db, &db->d_order, order.data(), order.size());
+        if (rc) return rc;
+    } else if (n) {
+        FX_HIP(hipMemcpyAsync(db->d_order, order.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    d.order = db->d_order;
     return FX_OK;
 }
 

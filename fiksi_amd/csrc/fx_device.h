@@ -98,6 +98,8 @@ struct DeviceBatch {
     double* sse_unscaled;  // [n_systems] sum r^2 on the solved, unscaled variables
     uint32_t* work_counter;  // [1] next System of the grouped kernel's device-side queue (reset before each launch)
     uint32_t* sys_class;     // [n_systems] or null: first System with the same structure (batches of several sketches)
+    uint32_t* order;         // [n_systems] or null: the System ticket t of the grouped kernel's queue stands for
+                             // (fx_batch_schedule_by_last_solve: last solve's longest Systems first)
     // medium Systems (sys_large == 2)
     uint32_t n_wide, w_max_free, w_max_vars, w_max_rows;
     uint32_t* w_list;         // [n_wide] System ids

@@ -551,7 +551,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             uint32_t nxt;
             for (;;) {
                 uint32_t tk = 0;
-                if (hl == 0) tk = atomicAdd(next_system, 1u);
+                if (hl == 0) {
+                    tk = atomicAdd(next_system, 1u);
+                    if (b.order && tk < b.n_systems) tk = b.order[tk];  // a schedule from an earlier solve of this batch
+                }
                 nxt = (uint32_t)__shfl((int)tk, 0, RS);
                 // large Systems belong to the other paths (a batch of one shared structure has none here)
                 if (nxt >= b.n_systems || b.uniform || !b.sys_large[nxt]) break;

@@ -232,6 +232,12 @@ int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars);
  * resident counterpart of ConstraintHandle::update_parameter (constraints/mod.rs:992-1046): the
  * structure stays, only the targets change (dragging a dimension). */
 int fx_batch_set_params(fx_ctx* ctx, fx_dbatch* db, const double* expr_param);
+/* A resident batch that is solved again and again with nearly the same data (dragging a dimension: fx_batch_set_params +
+ * solve, many times) is as slow as its slowest System plus the time before that System was started. enable != 0:
+ * later solves of this batch hand the Systems out in descending order of the LM trials each took in the LAST solve
+ * (read back here, once), so yesterday's stragglers start first; enable == 0: index order again. Scheduling only:
+ * every System's result is bit-identical either way (Systems are independent). Used by the grouped kernel. */
+int fx_batch_schedule_by_last_solve(fx_ctx* ctx, fx_dbatch* db, int enable);
 /* Copy the current (last solved) values / results back. */
 int fx_batch_get_vars(fx_ctx* ctx, fx_dbatch* db, double* vars);
 int fx_batch_get_results(fx_ctx* ctx, fx_dbatch* db, fx_result* results);

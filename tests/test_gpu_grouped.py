@@ -324,3 +324,30 @@ def test_sketches_past_the_register_held_parts(fiksi, oracle, ctx, routing, buil
         assert same_o.mean() > 0.7
         d = np.abs(r1["sse"] - res_o["sse"])
         assert np.all(d[same_o] <= 1e-9 + 1e-4 * np.abs(res_o["sse"][same_o]))
+
+
+def test_history_schedule_changes_the_order_not_the_results(fiksi, ctx):
+    """fx_batch_schedule_by_last_solve: the Systems that took the most trials last time start first; every result is
+    bit-identical to the index-order solve (f64 and f32, and when the data changes between solves)."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.ring16(20000, inconsistent=True)
+    db = ctx.upload(b)
+    for f32 in (False, True):
+        o = abi.solving_opts(f32=f32)
+        db.schedule_by_last_solve(False)
+        db.system_solve(o)
+        v0, r0 = db.get_vars().copy(), db.get_results().copy()
+        db.schedule_by_last_solve(True)
+        db.system_solve(o)
+        v1, r1 = db.get_vars().copy(), db.get_results().copy()
+        assert np.array_equal(_bits(v0), _bits(v1)) and r0.tobytes() == r1.tobytes()
+    # new targets: the old schedule is only a guess now, the results are still those of a fresh solve
+    p2 = b["expr_param"] * 1.01
+    db.set_params(p2)
+    db.system_solve(abi.solving_opts())
+    v2, r2 = db.get_vars().copy(), db.get_results().copy()
+    db.free()
+    b2 = dict(b, expr_param=p2)
+    v3, r3 = ctx.system_solve_batch(b2)
+    assert np.array_equal(_bits(v2), _bits(v3)) and np.array_equal(r2["trials"], r3["trials"])
