@@ -62,12 +62,15 @@ struct HostPlan {
     std::vector<uint16_t> var_info;
     std::vector<uint16_t> expr_comp;
     std::vector<uint16_t> expr_idx16;
-    std::vector<uint32_t> expr_var0;
     std::vector<uint8_t> expr_tagx;   // tag | 0x80 when a free column repeats inside the row
+};
+
+// What only the row-parallel kernels need (eval_rows_kernel, identity_residual_kernel): built on first use from
+// the compact arrays — a batch that is only ever solved neither computes nor uploads these 19 MB per 100k Systems.
+struct EvalPlan {
+    std::vector<uint32_t> expr_var0;  // var_off of the owning System
     std::vector<uint8_t> row_perm;    // tag-sorted order of each 256-row block
-    std::vector<uint8_t> row_simple;  // all variables of the row free and distinct
-    std::vector<uint8_t> row_sysoff;
-    std::vector<uint32_t> expr_sys;
+    std::vector<uint8_t> row_sysoff;  // owning System minus the block's first System
     std::vector<fx::BlockInfo> blk_info;
 };
 
@@ -168,6 +171,60 @@ void build_csr(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, co
             std::copy(local_cols[t].begin(), local_cols[t].end(), out.jcol.begin() + out.jrow_ptr[expr_off[range_lo[t]]]);
 }
 
+void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, const uint16_t* var_info,
+                     const uint8_t* expr_tagx, const uint16_t* expr_idx16, EvalPlan& out) {
+    const uint32_t ne = n ? expr_off[n] : 0;
+    out.expr_var0.assign(ne, 0);
+    out.row_perm.assign(ne, 0);
+    out.row_sysoff.assign(ne, 0);
+    std::vector<uint32_t> expr_sys(ne, 0);
+    std::vector<uint8_t> row_simple(ne, 0);
+    parallel_ranges(n, ne, [&](uint32_t, uint32_t s_lo, uint32_t s_hi) {
+        for (uint32_t s = s_lo; s < s_hi; ++s) {
+            const uint32_t v0 = var_off[s];
+            for (uint32_t e = expr_off[s]; e < expr_off[s + 1]; ++e) {
+                out.expr_var0[e] = v0;
+                expr_sys[e] = s;
+                uint32_t vars8[8];
+                const int k = fx::expand_vars((int)(expr_tagx[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
+                bool all_free = true, distinct = true;  // "simple": every variable free, none read twice
+                for (int q = 0; q < k; ++q) {
+                    const uint16_t info = var_info[v0 + vars8[q]];
+                    all_free = all_free && (info & fx::VAR_COMP_MASK) != fx::VAR_COMP_NONE && !(info & fx::VAR_FIXED_BIT);
+                    for (int u = q + 1; u < k; ++u) distinct = distinct && vars8[q] != vars8[u];
+                }
+                row_simple[e] = (all_free && distinct) ? 1 : 0;
+            }
+        }
+    });
+    // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
+    const uint32_t nblk = (ne + 255u) / 256u;
+    out.blk_info.assign(nblk, fx::BlockInfo{});
+    parallel_ranges(nblk, ne, [&](uint32_t, uint32_t b_lo, uint32_t b_hi) {
+        for (uint32_t blk = b_lo; blk < b_hi; ++blk) {
+            const uint32_t r0 = blk * 256u;
+            uint32_t nrw = std::min<uint32_t>(256, ne - r0), t = 0;
+            for (int tag = 0; tag < FX_NTAGS; ++tag)
+                for (uint32_t i = 0; i < nrw; ++i)
+                    if ((expr_tagx[r0 + i] & 0x7F) == tag) out.row_perm[r0 + t++] = (uint8_t)i;
+            fx::BlockInfo bi{};
+            bi.sys0 = expr_sys[r0];
+            bool simple = true;
+            for (uint32_t i = 0; i < nrw; ++i) {
+                simple = simple && row_simple[r0 + i];
+                // one byte per row: fits while the block's rows belong to at most 256 consecutive Systems. Systems
+                // without expressions take an index without taking a row, so a block can span more — such a block
+                // is not "simple": its rows then read their System's first variable from expr_var0 instead
+                const uint32_t off = expr_sys[r0 + i] - bi.sys0;
+                simple = simple && off <= 255u;
+                out.row_sysoff[r0 + i] = (uint8_t)(off & 0xFFu);
+            }
+            bi.flags = simple ? 1u : 0u;  // jbase / jcount are filled when the CSR structure is built
+            out.blk_info[blk] = bi;
+        }
+    });
+}
+
 // Checks the batch and builds the plan. Mirrors the data invariants the reference enforces by
 // construction (handles of the same System, indices < variables.len()).
 int analyze(const fx_batch* b, HostPlan* plan) {
@@ -198,12 +255,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     p.var_info.assign(nv, 0);
     p.expr_comp.assign(ne, 0);
     p.expr_idx16.assign(4 * (size_t)ne, 0);
-    p.expr_var0.assign(ne, 0);
     p.expr_tagx.assign(ne, 0);
-    p.row_perm.assign(ne, 0);
-    p.row_simple.assign(ne, 0);
-    p.row_sysoff.assign(ne, 0);
-    p.expr_sys.assign(ne, 0);
 
     struct Partial {
         uint64_t nnz = 0;
@@ -303,7 +355,6 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                 }
                 if (!in_range) break;
                 for (int q = 0; q < 4; ++q) p.expr_idx16[4 * (size_t)e + q] = (uint16_t)(f[q] < nvt ? f[q] : 0);
-                p.expr_var0[e] = v0;
                 p.expr_tagx[e] = (uint8_t)tag;
                 bool dup = false, all_free = true, distinct = true;
                 for (int q = 0; q < k; ++q) {
@@ -314,8 +365,6 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                     }
                 }
                 if (dup) p.expr_tagx[e] |= 0x80;
-                p.row_simple[e] = (all_free && distinct) ? 1 : 0;
-                p.expr_sys[e] = s;
                 uint16_t c = p.expr_comp[e];
                 if (c != fx::VAR_COMP_NONE) {
                     comp_rows[c] += 1;
@@ -464,32 +513,6 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             p.sys_class[s] = eq ? it->second : s;  // (a colliding hash: the System is its own class)
         }
     }
-    // tag-sorted thread -> row assignment inside every block of 256 rows (stable counting sort)
-    const uint32_t nblk = (ne + 255u) / 256u;
-    p.blk_info.assign(nblk, fx::BlockInfo{});
-    parallel_ranges(nblk, ne, [&](uint32_t, uint32_t b_lo, uint32_t b_hi) {
-        for (uint32_t blk = b_lo; blk < b_hi; ++blk) {
-            const uint32_t r0 = blk * 256u;
-            uint32_t nrw = std::min<uint32_t>(256, ne - r0), t = 0;
-            for (int tag = 0; tag < FX_NTAGS; ++tag)
-                for (uint32_t i = 0; i < nrw; ++i)
-                    if ((p.expr_tagx[r0 + i] & 0x7F) == tag) p.row_perm[r0 + t++] = (uint8_t)i;
-            fx::BlockInfo bi{};
-            bi.sys0 = p.expr_sys[r0];
-            bool simple = true;
-            for (uint32_t i = 0; i < nrw; ++i) {
-                simple = simple && p.row_simple[r0 + i];
-                // one byte per row: fits while the block's rows belong to at most 256 consecutive Systems. Systems
-                // without expressions take an index without taking a row, so a block can span more — such a block
-                // is not "simple": its rows then read their System's first variable from expr_var0 instead
-                const uint32_t off = p.expr_sys[r0 + i] - bi.sys0;
-                simple = simple && off <= 255u;
-                p.row_sysoff[r0 + i] = (uint8_t)(off & 0xFFu);
-            }
-            bi.flags = simple ? 1u : 0u;  // jbase / jcount are filled when the CSR structure is built
-            p.blk_info[blk] = bi;
-        }
-    });
     return FX_OK;
 }
 
@@ -603,10 +626,35 @@ int bind(fx_ctx* ctx) {
 }  // namespace
 
 namespace {
+// The arrays of the row-parallel kernels (EvalPlan) and the residual buffer, on first use: the structure is read back
+// from the device's own compact arrays (nothing is kept on the host for batches that are only ever solved).
 int ensure_resid(fx_ctx* ctx, fx_dbatch* db) {
-    if (db->d.resid) return FX_OK;
-    int rc = dev_alloc_copy(ctx, db, &db->d.resid, (const double*)nullptr, db->d.n_exprs);
-    return rc;
+    fx::DeviceBatch& d = db->d;
+    if (d.resid) return FX_OK;
+    const uint32_t n = d.n_systems;
+    std::vector<uint32_t> var_off((size_t)n + 1, 0), expr_off((size_t)n + 1, 0);
+    std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs);
+    std::vector<uint8_t> expr_tag(d.n_exprs);
+    FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (d.n_exprs) {
+        FX_HIP(hipMemcpyAsync(expr_idx.data(), d.expr_idx, expr_idx.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipMemcpyAsync(expr_tag.data(), d.expr_tag, expr_tag.size(), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FX_HIP(hipStreamSynchronize(ctx->stream));
+    EvalPlan ep;
+    build_eval_plan(n, var_off.data(), expr_off.data(), var_info.data(), expr_tag.data(), expr_idx.data(), ep);
+    int rc = dev_alloc_copy(ctx, db, &d.expr_var0, ep.expr_var0.data(), ep.expr_var0.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.row_perm, ep.row_perm.data(), ep.row_perm.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.row_sysoff, ep.row_sysoff.data(), ep.row_sysoff.size());
+    if (!rc) rc = dev_alloc_copy(ctx, db, &d.blk_info, ep.blk_info.data(), ep.blk_info.size());
+    double* resid = nullptr;
+    if (!rc) rc = dev_alloc_copy(ctx, db, &resid, (const double*)nullptr, d.n_exprs);
+    if (rc) return rc;
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors die with this frame
+    d.resid = resid;  // set last: marks the arrays as complete
+    return FX_OK;
 }
 
 // The CSR Jacobian structure of a resident batch, built on first use from the device's own compact
@@ -1416,13 +1464,9 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(vars, (const double*)batch->vars, p.n_vars)
     FX_UP(var_info, p.var_info.data(), p.n_vars)
     FX_UP(expr_tag, p.expr_tagx.data(), p.n_exprs)
-    FX_UP(row_perm, p.row_perm.data(), p.n_exprs)
     FX_UP(expr_comp, p.expr_comp.data(), p.n_exprs)
     FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
     FX_UP(expr_param, batch->expr_param, p.n_exprs)
-    FX_UP(expr_var0, p.expr_var0.data(), p.n_exprs)
-    FX_UP(row_sysoff, p.row_sysoff.data(), p.n_exprs)
-    FX_UP(blk_info, p.blk_info.data(), p.blk_info.size())
     FX_UP(results, (const fx_result*)nullptr, p.n_systems)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
     if (!p.sys_class.empty()) FX_UP(sys_class, p.sys_class.data(), p.n_systems)
