@@ -199,6 +199,10 @@ class Context:
         """grouped: -1 by batch size (default), 0 never, 1 whenever the batch qualifies (fx_ctx_set_routing)."""
         check(lib.fx_ctx_set_routing(self._h, grouped, grouped_min_systems), "fx_ctx_set_routing")
 
+    def set_presort(self, enable: bool = True, min_systems: int = 0):
+        """Most-work-first hand-out of big batches from a scout pass (fx_ctx_set_presort); results unchanged."""
+        check(lib.fx_ctx_set_presort(self._h, 1 if enable else 0, min_systems), "fx_ctx_set_presort")
+
     def synchronize(self):
         check(lib.fx_ctx_synchronize(self._h), "fx_ctx_synchronize")
 

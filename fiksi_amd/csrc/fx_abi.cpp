@@ -532,6 +532,8 @@ struct fx_ctx {
     // routing of batches of small Systems (fx_ctx_set_routing)
     int route_grouped = -1;
     uint32_t grouped_min_systems = 1024u;
+    int presort = 1;                       // fx_ctx_set_presort
+    uint32_t presort_min_systems = 8192u;
     void route(fx::LmParams& p) const {
         p.route_grouped = route_grouped;
         p.grouped_min_systems = grouped_min_systems;
@@ -592,6 +594,11 @@ struct fx_dbatch {
     std::vector<uint8_t> h_comp_walk;  // per System: 1 = walked on the device
     uint32_t n_units = 0, n_unit_rows = 0, n_unit_vars = 0;  // sizes of the SinglePass block arrays on the device
     uint32_t* d_order = nullptr;  // fx_batch_schedule_by_last_solve
+    // longest-first hand-out from a scout pass (fx_presort.hip): keys / ids [2][n], the sort's workspace
+    float* ps_keys = nullptr;
+    uint32_t* ps_ids = nullptr;
+    unsigned char* ps_temp = nullptr;
+    size_t ps_temp_bytes = 0;
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -1099,6 +1106,29 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     return FX_OK;
 }
 
+// launch_solve, with the Systems of a big batch of small Systems handed out longest-first (fx_presort.hip) unless the
+// caller chose a schedule (fx_batch_schedule_by_last_solve) or switched it off (fx_ctx_set_presort)
+int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
+    fx::DeviceBatch& d = db->d;
+    if (ctx->presort && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
+        const uint32_t n = d.n_systems;
+        if (!db->ps_keys) {
+            db->ps_temp_bytes = fx::presort_temp_bytes(n);
+            int rc = dev_alloc_copy(ctx, db, &db->ps_keys, (const float*)nullptr, 2 * (size_t)n);
+            if (!rc) rc = dev_alloc_copy(ctx, db, &db->ps_ids, (const uint32_t*)nullptr, 2 * (size_t)n);
+            if (!rc) rc = dev_alloc_copy(ctx, db, &db->ps_temp, (const unsigned char*)nullptr, db->ps_temp_bytes);
+            if (rc) return rc;
+        }
+        FX_HIP(fx::launch_presort(d, db->ps_keys, db->ps_ids, db->ps_temp, db->ps_temp_bytes, ctx->stream));
+        fx::DeviceBatch dd = d;
+        dd.order = db->ps_ids + n;
+        FX_HIP(fx::launch_solve(dd, p, ctx->stream));
+        return FX_OK;
+    }
+    FX_HIP(fx::launch_solve(d, p, ctx->stream));
+    return FX_OK;
+}
+
 // Decomposer::None on a System too large for LDS but made of components that each fit one wavefront (a
 // sketch of many separate features): the GLOBAL block walker takes the components as its blocks — rows
 // and free variables ascending, snapshot restore after each (quirk Q2) — instead of the host-driven
@@ -1348,6 +1378,13 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
     if (grouped < -1 || grouped > 1) return fail(FX_ERR_INVALID, "grouped must be -1 (by batch size), 0 or 1");
     ctx->route_grouped = grouped;
     if (grouped_min_systems) ctx->grouped_min_systems = grouped_min_systems;
+    return FX_OK;
+}
+
+int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    ctx->presort = enable ? 1 : 0;
+    if (min_systems) ctx->presort_min_systems = min_systems;
     return FX_OK;
 }
 
@@ -1661,7 +1698,8 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         rc = ensure_qr_plans(ctx, db, o.decomposer == 1);
         if (rc) return rc;
     }
-    FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    rc = launch_solve_scheduled(ctx, db, p);
+    if (rc) return rc;
     if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
     return solve_large_systems(ctx, db, p);
 }
@@ -1680,7 +1718,8 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
         rc = ensure_qr_plans(ctx, db, false);
         if (rc) return rc;
     }
-    FX_HIP(fx::launch_solve(db->d, p, ctx->stream));
+    rc = launch_solve_scheduled(ctx, db, p);
+    if (rc) return rc;
     if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
     return solve_large_systems(ctx, db, p);
 }

@@ -351,3 +351,25 @@ def test_history_schedule_changes_the_order_not_the_results(fiksi, ctx):
     b2 = dict(b, expr_param=p2)
     v3, r3 = ctx.system_solve_batch(b2)
     assert np.array_equal(_bits(v2), _bits(v3)) and np.array_equal(r2["trials"], r3["trials"])
+
+
+def test_presort_changes_the_order_not_the_results(fiksi, ctx):
+    """fx_ctx_set_presort: the scout pass + radix sort hand big batches out most-work-first; every System's result is
+    the same bits as in index order (uniform and mixed-structure batches, f64 and f32, SinglePass)."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import random_sketch
+
+    mixed = workloads.concat([workloads.ring16(6000), workloads.concat([random_sketch(s).flatten() for s in range(300)]),
+                              workloads.hinged_triangles(3000, 4), workloads.ring16(3000, inconsistent=True, seed0=9)])
+    for b, kw in ((workloads.ring16(20000), {}), (workloads.ring16(12000, inconsistent=True), {"f32": True}), (mixed, {}),
+                  (workloads.hinged_triangles(9000, 11), {"decomposer": 1})):
+        out = []
+        for on in (False, True):
+            ctx.set_presort(on, 8192)
+            try:
+                out.append(ctx.system_solve_batch(b, abi.solving_opts(**kw)))
+            finally:
+                ctx.set_presort(True, 8192)
+        assert np.array_equal(_bits(out[0][0]), _bits(out[1][0]))
+        assert out[0][1].tobytes() == out[1][1].tobytes()
