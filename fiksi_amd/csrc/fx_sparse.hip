@@ -49,17 +49,64 @@ struct SpRows {                 // expression data of the whole System (device)
     uint32_t net;
 };
 
-// scal[0] = scale, scal[1] = 1/scale. Sequential summation in the reference's order
-// (assemble/mod.rs:32-44) so the scale is bit-identical: one wavefront, 64 values per step.
-__global__ __launch_bounds__(64) void sp_scale_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows,
+// state of a device-controlled LM loop (the kernels that use it come further down)
+struct SpLm {
+    double lambda, sse, sse_t, dn2, sse_start;
+    uint32_t cur, accepted, trials, outer, exit_code, done, need_form, flag;
+};
+__device__ __forceinline__ uint32_t sp_lm_cur(const SpLm* st) { return st->cur; }
+__device__ __forceinline__ bool sp_lm_done(const SpLm* st) { return st->done != 0; }
+struct SpBufs {  // the two generations of the trial vectors
+    double* xs[2];
+    double* r[2];
+    double* j[2];
+};
+// scal[0] = scale, scal[1] = 1/scale. Sequential summation in the reference's order (assemble/mod.rs:32-44: all
+// variables, then the distance parameters, each ascending) so the scale is bit-identical — the sum itself cannot be
+// split, but everything around it can: 256 threads square 4096 values at a time into LDS (+0.0 for expressions without
+// a distance: exact), then ONE thread adds them up in order, sixteen LDS values in flight per step. (The first
+// version added 64 values per step through v_readlane pairs: 0.83 ms for cfg2's 20 000 values; this one ~0.1 ms.)
+__global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows,
                                                       double* __restrict__ scal, int do_scale) {
-    const int lane = threadIdx.x;
-    double scale = 1.0;
-    if (do_scale)
-        scale = system_scale_wave(
-            nvt, rows.net, lane, [&](uint32_t i) { return vars0[i]; }, [&](uint32_t i) { return (int)(rows.tag[i] & 0x7F); },
-            [&](uint32_t i) { return rows.param[i]; });
-    if (lane == 0) {
+    constexpr uint32_t CH = 4096;
+    __shared__ double sq[CH];
+    __shared__ uint32_t cnt_s[256];
+    double sum = 0.0;
+    uint32_t ndist = 0;
+    const uint32_t total = do_scale ? nvt + rows.net : 0u;
+    for (uint32_t base = 0; base < total; base += CH) {
+        const uint32_t n = min(CH, total - base);
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+            const uint32_t g = base + i;
+            double v = 0.0;
+            if (g < nvt) {
+                v = vars0[g];
+            } else {
+                const int tag = rows.tag[g - nvt] & 0x7F;
+                if (tag == 1 || tag == 4) {  // FX_TAG_PPD, FX_TAG_PLD
+                    v = rows.param[g - nvt];
+                    mine += 1;
+                }
+            }
+            sq[i] = v * v;
+        }
+        cnt_s[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t i = 0; i < n; i += 16u) {
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = (i + u < n) ? sq[i + u] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum += t[u];
+            }
+            for (uint32_t i = 0; i < 256u; ++i) ndist += cnt_s[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double scale = do_scale ? ::sqrt(sum / (double)(nvt + ndist)) : 1.0;
         scal[0] = scale;
         scal[1] = 1.0 / scale;
     }
@@ -160,6 +207,42 @@ __global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, co
         for (int t = 0; t < 8; ++t) {
             if ((uint32_t)t < cnt) jvals[base + t] = out[t];
         }
+    }
+}
+
+// the same at the trial point of a device-controlled LM loop: generation cur ^ 1 of the vectors
+__global__ __launch_bounds__(256) void sp_eval_dc_kernel(SpRows rows, SpJac jac, double* xs0, double* xs1, double* r0, double* r1, double* j0,
+                                                         double* j1, const SpLm* __restrict__ st) {
+    if (sp_lm_done(st)) return;
+    const uint32_t t = sp_lm_cur(st) ^ 1u;
+    const double* xs = t ? xs1 : xs0;
+    double* r = t ? r1 : r0;
+    double* jvals = t ? j1 : j0;
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= jac.m) return;
+    uint32_t e = jac.rows[row];
+    int tag = rows.tag[e] & 0x7F;
+    ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars(tag, ff, vars8);
+    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
+    r[row] = eval_expression<double, true>(tag, v, rows.sparam[e], g);
+    uint32_t slots = jac.jslot[row];
+    uint32_t base = jac.jrow_ptr[row];
+    uint32_t cnt = jac.jrow_ptr[row + 1] - base;
+    double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t sl = (slots >> (4 * q)) & 0xFu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out[u] += (sl == (uint32_t)u) ? g[q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if ((uint32_t)u < cnt) jvals[base + u] = out[u];
     }
 }
 
@@ -339,8 +422,12 @@ struct SpRowsOfL {               // L by rows (strictly lower part), for the for
 __global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl,
                                                                const double* __restrict__ a, double lambda,
                                                                double* __restrict__ l, double* __restrict__ b,
-                                                               uint32_t* __restrict__ flag) {
+                                                               uint32_t* __restrict__ flag, const SpLm* __restrict__ st) {
     __shared__ double acc[64];
+    if (st) {  // device-controlled loop: lambda and the stop flag live on the device
+        if (st->done) return;
+        lambda = st->lambda;
+    }
     const int lane = threadIdx.x;
     const uint32_t list = cl.first + blockIdx.x;
     bool bad = false;
@@ -412,7 +499,8 @@ __global__ __launch_bounds__(64) void sp_factor_forward_kernel(SpChol c, SpRowsO
 // K4c: Lt x = y by column gathers, lists walked backwards: x_j = (y_j - sum_{i>j} L_ij x_i) / L_jj
 // reads only ancestors of j — the levels run from the top down. x overwrites y.
 __global__ __launch_bounds__(64) void sp_backward_kernel(SpChol c, ColLists cl, const double* __restrict__ l,
-                                                         double* __restrict__ b) {
+                                                         double* __restrict__ b, const SpLm* __restrict__ st) {
+    if (st && st->done) return;
     const int lane = threadIdx.x;
     const uint32_t list = cl.first + blockIdx.x;
     for (uint32_t q = cl.ptr[list + 1]; q-- > cl.ptr[list];) {
@@ -426,12 +514,154 @@ __global__ __launch_bounds__(64) void sp_backward_kernel(SpChol c, ColLists cl, 
     }
 }
 
+// ---- LM control on the device (lm.rs:108-191). The host used to read three scalars back after every trial and
+// decide; now the decisions are taken by a one-thread kernel on this state, every kernel of a trial looks at it (which
+// buffer is current, lambda, whether anything is left to do), and the host enqueues trials in chunks without waiting —
+// one read-back per chunk instead of a synchronisation per trial.
+__global__ void sp_lm_init_kernel(SpLm* st, fx_lm_opts o) {
+    const double sse = st->sse;  // written by the start point's sum of squares
+    st->sse_start = sse;
+    st->lambda = o.lambda0;
+    st->cur = 0;
+    st->accepted = st->trials = st->outer = 0;
+    st->exit_code = FX_EXIT_MAX_OUTER;
+    st->need_form = 1;
+    st->flag = 0;
+    st->done = 0;
+    if (!(sse == sse) || !(sse < 1.0e300)) {
+        st->exit_code = FX_EXIT_NAN;
+        st->done = 1;
+    } else if (o.max_outer == 0) {
+        st->done = 1;
+    } else if (sse < o.sse_tol) {  // lm.rs:110-112
+        st->exit_code = FX_EXIT_SSE;
+        st->done = 1;
+    } else if (o.max_trials == 0) {
+        st->exit_code = FX_EXIT_TRIAL_CAP;
+        st->done = 1;
+    }
+}
+// after a trial: accept / reject / stop, exactly the host loop this replaces
+__global__ void sp_lm_control_kernel(SpLm* st, fx_lm_opts o) {
+    if (st->done) return;
+    st->trials += 1;
+    bool check_cap = true;
+    if (st->flag) {  // lm.rs:134-137
+        st->lambda *= o.singular_factor;
+        if (!(st->lambda < 1.0e300)) {
+            st->exit_code = FX_EXIT_NAN;
+            st->done = 1;
+        }
+    } else {
+        const double dn2 = st->dn2, sse_t = st->sse_t, sse = st->sse;
+        if (!(dn2 == dn2)) {
+            st->exit_code = FX_EXIT_NAN;
+            st->done = 1;
+            check_cap = false;
+        } else if (dn2 < o.step_tol) {  // lm.rs:139-142
+            st->exit_code = FX_EXIT_STEP;
+            st->done = 1;
+            check_cap = false;
+        } else if (sse_t < sse) {  // accept, lm.rs:151-186
+            double lam = st->lambda * o.accept_factor;
+            if (lam < o.lambda_min) lam = o.lambda_min;
+            st->lambda = lam;
+            st->cur ^= 1u;
+            st->accepted += 1;
+            const double rel = (sse - sse_t) / sse;
+            st->sse = sse_t;
+            if (rel <= o.ftol) {
+                st->exit_code = FX_EXIT_FTOL;
+                st->done = 1;
+                check_cap = false;
+            } else {
+                st->need_form = 1;
+                st->outer += 1;
+                if (st->outer >= o.max_outer) {
+                    st->done = 1;  // exit_code is still FX_EXIT_MAX_OUTER
+                    check_cap = false;
+                } else if (sse_t < o.sse_tol) {
+                    st->exit_code = FX_EXIT_SSE;
+                    st->done = 1;
+                    check_cap = false;
+                }
+            }
+        } else {  // reject, lm.rs:187-190
+            st->lambda *= o.reject_factor;
+            if (!(sse_t == sse_t) && !(st->lambda < 1.0e300)) {
+                st->exit_code = FX_EXIT_NAN;
+                st->done = 1;
+                check_cap = false;
+            }
+        }
+    }
+    if (check_cap && !st->done && st->trials >= o.max_trials) {
+        st->exit_code = FX_EXIT_TRIAL_CAP;
+        st->done = 1;
+    }
+    st->flag = 0;
+}
+__global__ void sp_form_a_dc_kernel(const uint32_t* __restrict__ pair_ptr, const uint32_t* __restrict__ pairs, SpBufs bf, uint32_t nnz_a,
+                                    double* __restrict__ a, const SpLm* __restrict__ st) {
+    if (st->done || !st->need_form) return;
+    const double* jvals = bf.j[st->cur];
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz_a) return;
+    double s = 0.0;
+    for (uint32_t p = pair_ptr[k]; p < pair_ptr[k + 1]; ++p) s += jvals[pairs[2 * p]] * jvals[pairs[2 * p + 1]];
+    a[k] = s;
+}
+__global__ void sp_rhs_dc_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx, const uint32_t* __restrict__ crow,
+                                 SpBufs bf, uint32_t nv, double* __restrict__ b, const SpLm* __restrict__ st) {
+    if (st->done || !st->need_form) return;
+    const double* jvals = bf.j[st->cur];
+    const double* r = bf.r[st->cur];
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nv) return;
+    double s = 0.0;
+    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * -r[crow[p]];
+    b[c] = s;
+}
+// delta <- right-hand side (the factorization kernel solves in place); the formed flag is cleared
+__global__ void sp_begin_dc_kernel(const double* __restrict__ rhs, double* __restrict__ delta, uint32_t nv, SpLm* __restrict__ st) {
+    if (st->done) return;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nv) delta[i] = rhs[i];
+}
+__global__ void sp_formed_dc_kernel(SpLm* st) { st->need_form = 0; }
+__global__ void sp_trial_dc_kernel(const uint32_t* __restrict__ fvar, const uint32_t* __restrict__ perm, uint32_t nv,
+                                   const double* __restrict__ delta, SpBufs bf, const SpLm* __restrict__ st) {
+    if (st->done) return;
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nv) return;
+    const uint32_t v = fvar[perm[k]];
+    bf.xs[st->cur ^ 1u][v] = bf.xs[st->cur][v] + delta[k];
+}
+// out[0] = sum v[i]^2 over the buffer of generation cur ^ sel (fixed-shape tree: deterministic)
+__global__ __launch_bounds__(1024) void sp_sumsq_dc_kernel(const double* v0, const double* v1, uint32_t sel, uint32_t n, double* __restrict__ out,
+                                                           const SpLm* __restrict__ st) {
+    if (st->done) return;
+    const double* v = ((st->cur ^ sel) & 1u) ? v1 : v0;
+    __shared__ double part[1024];
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += v[i] * v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
 // ---- FX_STEP_CHOLESKY_REFINED: one refinement step on the least-squares problem itself (corrected semi-normal
 // equations), as in the fused kernel: t = -r - J delta from the Jacobian rows, (JtJ + lambda I) e = Jt t - lambda delta
 // with the factor at hand, delta += e. All sums in a fixed order.
-__global__ void sp_refine_t_kernel(const uint32_t* __restrict__ jrow_ptr, const uint32_t* __restrict__ jcol,
-                                   const double* __restrict__ jvals, const double* __restrict__ r,
-                                   const double* __restrict__ delta, uint32_t m, double* __restrict__ t) {
+__global__ void sp_refine_t_kernel(const uint32_t* __restrict__ jrow_ptr, const uint32_t* __restrict__ jcol, SpBufs bf,
+                                   const double* __restrict__ delta, uint32_t m, double* __restrict__ t, const SpLm* __restrict__ st) {
+    if (st->done) return;
+    const double* jvals = bf.j[st->cur];
+    const double* r = bf.r[st->cur];
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= m) return;
     double acc = -r[row];
@@ -439,23 +669,27 @@ __global__ void sp_refine_t_kernel(const uint32_t* __restrict__ jrow_ptr, const 
     t[row] = acc;
 }
 __global__ void sp_refine_rhs_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx,
-                                     const uint32_t* __restrict__ crow, const double* __restrict__ jvals,
-                                     const double* __restrict__ t, const double* __restrict__ delta, double lambda, uint32_t nv,
-                                     double* __restrict__ out) {
+                                     const uint32_t* __restrict__ crow, SpBufs bf, const double* __restrict__ t,
+                                     const double* __restrict__ delta, uint32_t nv, double* __restrict__ out, const SpLm* __restrict__ st) {
+    if (st->done) return;
+    const double* jvals = bf.j[st->cur];
+    const double lambda = st->lambda;
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nv) return;
     double s = 0.0;
     for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * t[crow[p]];
     out[c] = s - lambda * delta[c];
 }
-__global__ void sp_add_kernel(const double* __restrict__ e, uint32_t n, double* __restrict__ x) {
+__global__ void sp_add_kernel(const double* __restrict__ e, uint32_t n, double* __restrict__ x, const SpLm* __restrict__ st) {
+    if (st->done) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] += e[i];
 }
 // L y = b with the stored factor (the factorization kernel does this sweep on the fly; the refinement needs it again):
 // row gathers, lists in ascending order, levels bottom up. y overwrites b.
 __global__ __launch_bounds__(64) void sp_forward_kernel(SpChol c, SpRowsOfL lr, ColLists cl, const double* __restrict__ l,
-                                                        double* __restrict__ b) {
+                                                        double* __restrict__ b, const SpLm* __restrict__ st) {
+    if (st && st->done) return;
     const int lane = threadIdx.x;
     const uint32_t list = cl.first + blockIdx.x;
     for (uint32_t q = cl.ptr[list]; q < cl.ptr[list + 1]; ++q) {
@@ -1130,7 +1364,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     double* d_runs = pool.alloc<double>(std::max(net, 1u));
     if (pool.err != hipSuccess) return pool.err;
 
-    hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(64), 0, stream, d_vars0, nvt, rows, d_scal, do_scale);
+    hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(256), 0, stream, d_vars0, nvt, rows, d_scal, do_scale);
     hipLaunchKernelGGL(sp_init_kernel, grid_for(std::max(nvt, net)), dim3(256), 0, stream, d_vars0, nvt, rows, d_scal,
                        d_xs[0], d_xs[1], do_scale);
     hipError_t e = hipMemcpyAsync(d_vars_out, d_vars0, nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
@@ -1382,111 +1616,66 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                 }
             }
         } else {
-        form(0);
-        double lambda = o.lambda0;
-        bool done = false;
-        if (!(sse == sse) || !(sse < 1.0e300)) {
-            exit_code = FX_EXIT_NAN;
-            done = true;
-        }
-        for (uint32_t outer = 0; outer < o.max_outer && !done; ++outer) {
-            if (sse < o.sse_tol) {
-                exit_code = FX_EXIT_SSE;
-                break;
+        // ---- Levenberg-Marquardt (lm.rs:108-191), controlled on the device: the host enqueues trials in chunks and
+        // reads the state back once per chunk
+        SpLm* d_lm = pool.alloc<SpLm>(1);
+        if (pool.err != hipSuccess) return pool.err;
+        SpBufs bf{{d_xs[0], d_xs[1]}, {d_r[0], d_r[1]}, {d_j[0], d_j[1]}};
+        e = hipMemcpyAsync(&d_lm->sse, d_scal + 2, sizeof(double), hipMemcpyDeviceToDevice, stream);  // the start point's SSE
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(sp_lm_init_kernel, dim3(1), dim3(1), 0, stream, d_lm, o);
+        auto enqueue_trial = [&]() {
+            if (P.nnz_a) hipLaunchKernelGGL(sp_form_a_dc_kernel, grid_for(P.nnz_a), dim3(256), 0, stream, d_apair_ptr, d_apairs, bf, P.nnz_a, d_a, d_lm);
+            if (nv) hipLaunchKernelGGL(sp_rhs_dc_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, bf, nv, d_rhs, d_lm);
+            hipLaunchKernelGGL(sp_formed_dc_kernel, dim3(1), dim3(1), 0, stream, d_lm);
+            if (nv) hipLaunchKernelGGL(sp_begin_dc_kernel, grid_for(nv), dim3(256), 0, stream, d_rhs, d_delta, nv, d_lm);
+            for (uint32_t v = 0; v < nlevels; ++v) {
+                ColLists cl = lists;
+                cl.first = P.level_ptr[v];
+                hipLaunchKernelGGL(sp_factor_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream,
+                                   chol, lrows, cl, d_a, 0.0, d_l, d_delta, &d_lm->flag, d_lm);
             }
-            for (;;) {
-                if (trials >= o.max_trials) {
-                    exit_code = FX_EXIT_TRIAL_CAP;
-                    done = true;
-                    break;
-                }
-                trials += 1;
-                const int trial = cur ^ 1;
-                // factor, solve, trial point, trial residuals (+ Jacobian: it becomes J on acceptance)
-                e = hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream);
-                if (e != hipSuccess) return e;
-                e = hipMemcpyAsync(d_delta, d_rhs, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
-                if (e != hipSuccess) return e;
+            for (uint32_t v = nlevels; v-- > 0;) {
+                ColLists cl = lists;
+                cl.first = P.level_ptr[v];
+                hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl, d_l, d_delta, d_lm);
+            }
+            if (refined && nv && m) {
+                hipLaunchKernelGGL(sp_refine_t_kernel, grid_for(m), dim3(256), 0, stream, jac.jrow_ptr, blk->d_jcol, bf, d_delta, m, d_t, d_lm);
+                hipLaunchKernelGGL(sp_refine_rhs_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, bf, d_t, d_delta, nv, d_e, d_lm);
                 for (uint32_t v = 0; v < nlevels; ++v) {
                     ColLists cl = lists;
                     cl.first = P.level_ptr[v];
-                    hipLaunchKernelGGL(sp_factor_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream,
-                                       chol, lrows, cl, d_a, lambda, d_l, d_delta, d_flag);
+                    hipLaunchKernelGGL(sp_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, lrows, cl, d_l, d_e, d_lm);
                 }
                 for (uint32_t v = nlevels; v-- > 0;) {
                     ColLists cl = lists;
                     cl.first = P.level_ptr[v];
-                    hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl,
-                                       d_l, d_delta);
+                    hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl, d_l, d_e, d_lm);
                 }
-                if (refined && nv && m) {
-                    hipLaunchKernelGGL(sp_refine_t_kernel, grid_for(m), dim3(256), 0, stream, jac.jrow_ptr, blk->d_jcol, d_j[cur], d_r[cur], d_delta, m, d_t);
-                    hipLaunchKernelGGL(sp_refine_rhs_kernel, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[cur], d_t, d_delta, lambda, nv, d_e);
-                    for (uint32_t v = 0; v < nlevels; ++v) {
-                        ColLists cl = lists;
-                        cl.first = P.level_ptr[v];
-                        hipLaunchKernelGGL(sp_forward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, lrows, cl, d_l, d_e);
-                    }
-                    for (uint32_t v = nlevels; v-- > 0;) {
-                        ColLists cl = lists;
-                        cl.first = P.level_ptr[v];
-                        hipLaunchKernelGGL(sp_backward_kernel, dim3(P.level_ptr[v + 1] - P.level_ptr[v]), dim3(64), 0, stream, chol, cl, d_l, d_e);
-                    }
-                    hipLaunchKernelGGL(sp_add_kernel, grid_for(nv), dim3(256), 0, stream, d_e, nv, d_delta);
-                }
-                hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_delta, nv, d_scal + 3);
-                if (nv) hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[cur], d_xs[trial]);
-                if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[trial], d_r[trial], d_j[trial]);
-                hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[trial], m, d_scal + 2);
-                uint32_t hflag = 0;
-                e = hipMemcpyAsync(host3, d_scal + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, stream);
-                if (e == hipSuccess) e = hipMemcpyAsync(&hflag, d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(stream);
-                if (e != hipSuccess) return e;
-                const double sse_t = host3[0], dn2 = host3[1];
-                if (hflag) {  // lm.rs:134-137
-                    lambda *= o.singular_factor;
-                    if (!(lambda < 1.0e300)) {
-                        exit_code = FX_EXIT_NAN;
-                        done = true;
-                        break;
-                    }
-                    continue;
-                }
-                if (!(dn2 == dn2)) {
-                    exit_code = FX_EXIT_NAN;
-                    done = true;
-                    break;
-                }
-                if (dn2 < o.step_tol) {  // lm.rs:139-142
-                    exit_code = FX_EXIT_STEP;
-                    done = true;
-                    break;
-                }
-                if (sse_t < sse) {  // accept
-                    lambda *= o.accept_factor;
-                    if (lambda < o.lambda_min) lambda = o.lambda_min;
-                    cur = trial;
-                    accepted += 1;
-                    double rel = (sse - sse_t) / sse;
-                    sse = sse_t;
-                    if (rel <= o.ftol) {
-                        exit_code = FX_EXIT_FTOL;
-                        done = true;
-                        break;
-                    }
-                    form(cur);
-                    break;
-                } else {
-                    lambda *= o.reject_factor;
-                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
-                        exit_code = FX_EXIT_NAN;
-                        done = true;
-                        break;
-                    }
-                }
+                hipLaunchKernelGGL(sp_add_kernel, grid_for(nv), dim3(256), 0, stream, d_e, nv, d_delta, d_lm);
             }
+            hipLaunchKernelGGL(sp_sumsq_dc_kernel, dim3(1), dim3(1024), 0, stream, d_delta, d_delta, 0u, nv, &d_lm->dn2, d_lm);
+            if (nv) hipLaunchKernelGGL(sp_trial_dc_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, bf, d_lm);
+            if (m) hipLaunchKernelGGL(sp_eval_dc_kernel, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[0], d_xs[1], d_r[0], d_r[1], d_j[0], d_j[1], d_lm);
+            hipLaunchKernelGGL(sp_sumsq_dc_kernel, dim3(1), dim3(1024), 0, stream, d_r[0], d_r[1], 1u, m, &d_lm->sse_t, d_lm);
+            hipLaunchKernelGGL(sp_lm_control_kernel, dim3(1), dim3(1), 0, stream, d_lm, o);
+        };
+        SpLm h_lm{};
+        for (uint32_t chunk = 4;; chunk = std::min<uint32_t>(2 * chunk, 16)) {
+            e = hipMemcpyAsync(&h_lm, d_lm, sizeof(SpLm), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            if (h_lm.done) break;
+            for (uint32_t t = 0; t < chunk; ++t) enqueue_trial();
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
         }
+        cur = (int)h_lm.cur;
+        sse = h_lm.sse;
+        accepted = h_lm.accepted;
+        trials = h_lm.trials;
+        exit_code = h_lm.exit_code;
         }  // optimizer
         if (nv) {
             hipLaunchKernelGGL(sp_writeback_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_scal, do_scale, d_vars_out);

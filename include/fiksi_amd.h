@@ -212,7 +212,7 @@ int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
 
 void fx_lm_opts_default(fx_lm_opts* opts);           /* lm.rs:108-189 literals                */
-/* f32 variant: same schedule, ftol 1e-4 and lambda_min 1e-7 (what f32 round-off can resolve). With precision = 32
+/* f32 variant: same schedule, ftol 1e-4, lambda_min 1e-7 and max_outer 40 (what f32 round-off can resolve). With precision = 32
  * ftol also ends a solve on a REJECTED trial whose SSE exceeds the current one by no more than ftol * SSE: that is
  * round-off, not a worse point (the f64 path keeps the reference's rule: only accepted steps test ftol). */
 void fx_lm_opts_default_f32(fx_lm_opts* opts);
