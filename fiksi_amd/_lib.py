@@ -134,6 +134,10 @@ SIGNATURES = [
     ("fx_lm_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
     ("fx_eval_residual_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp]),
     ("fx_constraint_residuals", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
+    ("fx_system_prepare_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp]),
+    ("fx_cluster_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
+    ("fx_pose_transform_points", C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, C.c_uint32]),
+    ("fx_unscale_vars", C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_uint32]),
     ("fx_analyze_batch", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     ("fx_eval_residual_dense_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp, _vp, _vp]),
     ("fx_single_pass_blocks", C.c_int, [C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -162,6 +166,8 @@ SIGNATURES = [
     ("fxs_constraint_valency", C.c_int, [C.c_int]),
     ("fxs_constraint_update_parameter", C.c_int, [_vp, C.c_uint32, C.c_double]),
     ("fxs_components", C.c_int, [_vp, u32p, _vp, _vp]),
+    ("fxs_export_graph", C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("fxs_recursive_plan", C.c_int, [_vp, C.c_uint64, _vp, C.c_uint32, u32p, u32p]),
     ("fxs_flatten", C.c_int, [C.POINTER(_vp), C.c_uint32, C.POINTER(_vp)]),
     ("fxs_flat_batch", C.POINTER(FxBatch), [_vp]),
     ("fxs_flat_free", None, [_vp]),

@@ -29,6 +29,8 @@
 namespace {
 
 thread_local std::string g_last_error;
+// set by fx_cluster_solve_batch while it uploads: the two pose-row tags of fx_expr.h are legal in that batch only
+thread_local bool g_allow_pose = false;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -154,7 +156,7 @@ void build_csr(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, co
             for (uint32_t i = 0; i < net; ++i) {
                 const uint32_t e = e0 + i;
                 uint32_t vars8[8];
-                int k = fx::expand_vars((int)(expr_tag[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
+                int k = fx::expand_vars<true>((int)(expr_tag[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
                 int32_t cols[8];
                 uint32_t slots;
                 int ncols = row_columns(vars8, k, free_rank.data(), cols, &slots);
@@ -186,7 +188,7 @@ void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_o
                 out.expr_var0[e] = v0;
                 expr_sys[e] = s;
                 uint32_t vars8[8];
-                const int k = fx::expand_vars((int)(expr_tagx[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
+                const int k = fx::expand_vars<true>((int)(expr_tagx[e] & 0x7F), expr_idx16 + 4 * (size_t)e, vars8);
                 bool all_free = true, distinct = true;  // "simple": every variable free, none read twice
                 for (int q = 0; q < k; ++q) {
                     const uint16_t info = var_info[v0 + vars8[q]];
@@ -204,7 +206,7 @@ void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_o
         for (uint32_t blk = b_lo; blk < b_hi; ++blk) {
             const uint32_t r0 = blk * 256u;
             uint32_t nrw = std::min<uint32_t>(256, ne - r0), t = 0;
-            for (int tag = 0; tag < FX_NTAGS; ++tag)
+            for (int tag = 0; tag < FX_NTAGS_POSE; ++tag)
                 for (uint32_t i = 0; i < nrw; ++i)
                     if ((expr_tagx[r0 + i] & 0x7F) == tag) out.row_perm[r0 + t++] = (uint8_t)i;
             fx::BlockInfo bi{};
@@ -338,13 +340,13 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             for (uint32_t i = 0; i < net; ++i) {
                 const uint32_t e = e0 + i;
                 const int tag = b->expr_tag[e];
-                if (tag < 0 || tag >= FX_NTAGS) {
+                if (tag < 0 || tag >= (g_allow_pose ? FX_NTAGS_POSE : FX_NTAGS)) {
                     bad(FX_ERR_INVALID, s, "expression %u of system %u: bad tag %d", i, s, (unsigned)tag);
                     break;
                 }
                 const uint32_t* f = b->expr_idx + 4 * (size_t)e;
                 uint32_t vars8[8];
-                int k = fx::expand_vars(tag, f, vars8);
+                int k = fx::expand_vars<true>(tag, f, vars8);
                 bool in_range = true;
                 for (int q = 0; q < k; ++q) {
                     if (vars8[q] >= nvt) {
@@ -905,7 +907,7 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
     std::vector<std::vector<int>> cols(n);
     for (uint32_t r = 0; r < m; ++r) {
         uint32_t vars8[8];
-        const int k = fx::expand_vars((int)(expr_tag[rows[r]] & 0x7F), expr_idx16 + 4 * (size_t)rows[r], vars8);
+        const int k = fx::expand_vars<true>((int)(expr_tag[rows[r]] & 0x7F), expr_idx16 + 4 * (size_t)rows[r], vars8);
         for (int q = 0; q < k; ++q) {
             const int32_t c = vars8[q] < nvt ? colof[vars8[q]] : -1;
             if (c >= 0 && (cols[c].empty() || cols[c].back() != (int)r)) cols[c].push_back((int)r);
@@ -1165,7 +1167,7 @@ int ensure_component_walk(fx_ctx* ctx, fx_dbatch* db) {
             uint16_t c = hb.expr_comp ? hb.expr_comp[e0 + i] : 0;
             if (c == FX_NO_COMPONENT || c >= ncomp) continue;
             rows[c].push_back(i);
-            uint32_t k = (uint32_t)fx::tag_nvars((int)hb.expr_tag[e0 + i]);
+            uint32_t k = (uint32_t)fx::tag_nvars<true>((int)hb.expr_tag[e0 + i]);
             pairs[c] += k * k;
             ents[c] += k;
         }
@@ -1685,7 +1687,10 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     if (o.optimizer == 1 && o.lm.precision == 32)
         return fail(FX_ERR_UNSUPPORTED, "Optimizer::LBfgs runs in f64 only");
 
-    if (o.decomposer > 1) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass)", o.decomposer);
+    if (o.decomposer == 2)
+        return fail(FX_ERR_UNSUPPORTED, "Decomposer::RecursiveAssembly works on a System's elements and constraints: call it through the "
+                                        "builder (fxs_system_solve); a flat batch does not carry them");
+    if (o.decomposer > 2) return fail(FX_ERR_UNSUPPORTED, "unknown decomposer %u (0 = None, 1 = SinglePass, 2 = RecursiveAssembly)", o.decomposer);
     if (o.lm.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", o.lm.solver);
     fx::LmParams p;
     ctx->route(p);
@@ -1852,6 +1857,117 @@ int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_o
 
 int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results) {
     return solve_host(ctx, batch, nullptr, opts, false, results);
+}
+
+// ---- Decomposer::RecursiveAssembly: the device work around the host plan of fx_recursive.h -------------------
+
+int fx_system_prepare_batch(fx_ctx* ctx, const fx_batch* batch, uint32_t perturb, double* out_vars, double* out_params,
+                            double* out_scale) {
+    if (!batch || !out_vars || !out_params || !out_scale) return fail(FX_ERR_INVALID, "bad argument");
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    db->resident = false;
+    auto run = [&]() -> int {
+        if (db->n_large) return fail(FX_ERR_TOO_LARGE, "fx_system_prepare_batch takes Systems of up to %u variables", FX_MAX_SYSTEM_VARS);
+        double *d_vars = nullptr, *d_scale = nullptr, *d_params = nullptr;
+        int r = dev_alloc_copy<double>(ctx, db, &d_vars, nullptr, db->d.n_vars);
+        if (r) return r;
+        r = dev_alloc_copy<double>(ctx, db, &d_params, nullptr, db->d.n_exprs);
+        if (r) return r;
+        r = dev_alloc_copy<double>(ctx, db, &d_scale, nullptr, db->d.n_systems);
+        if (r) return r;
+        FX_HIP(fx::launch_prepare(db->d, 1u | (perturb ? 2u : 0u), d_vars, d_params, d_scale, ctx->stream));
+        if (db->d.n_vars) FX_HIP(hipMemcpyAsync(out_vars, d_vars, (size_t)db->d.n_vars * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (db->d.n_exprs)
+            FX_HIP(hipMemcpyAsync(out_params, d_params, (size_t)db->d.n_exprs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (db->d.n_systems)
+            FX_HIP(hipMemcpyAsync(out_scale, d_scale, (size_t)db->d.n_systems * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        return FX_OK;
+    };
+    rc = run();
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
+int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results) {
+    fx_lm_opts o;
+    if (opts) o = *opts; else fx_lm_opts_default(&o);
+    if (o.precision == 32) return fail(FX_ERR_UNSUPPORTED, "cluster problems are solved in f64");
+    if (o.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", o.solver);
+    fx_dbatch* db = nullptr;
+    g_allow_pose = true;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    g_allow_pose = false;
+    if (rc) return rc;
+    db->resident = false;
+    db->d.has_pose = 1u;
+    if (db->n_large || db->d.n_wide) {
+        fx_batch_free(ctx, db);
+        return fail(FX_ERR_TOO_LARGE, "a cluster problem holds at most %u unknowns, %u rows and %u variables (one wavefront solves it)",
+                    FX_MAX_FREE_VARS, FX_MAX_ROWS, FX_MAX_SYSTEM_VARS);
+    }
+    rc = fx_lm_solve_device(ctx, db, &o);
+    if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
+    if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);
+    fx_batch_free(ctx, db);
+    return rc;
+}
+
+int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses, const uint32_t* pose_of, const uint32_t* var_idx,
+                             uint32_t n_points, double* vars, uint32_t n_vars) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n_points == 0) return FX_OK;
+    if (!poses || !pose_of || !var_idx || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    for (uint32_t i = 0; i < n_points; ++i) {
+        if (pose_of[i] >= n_poses || (uint64_t)var_idx[i] + 1u >= n_vars) return fail(FX_ERR_INVALID, "point %u out of range", i);
+        for (uint32_t j = 0; j < i; ++j)
+            if (var_idx[j] == var_idx[i]) return fail(FX_ERR_INVALID, "point %u is listed twice", i);
+    }
+    fx_dbatch scratch;  // owns the device blocks of this call
+    double *d_poses = nullptr, *d_vars = nullptr;
+    uint32_t *d_of = nullptr, *d_idx = nullptr;
+    auto run = [&]() -> int {
+        int r = dev_alloc_copy<double>(ctx, &scratch, &d_poses, poses, 3 * (size_t)n_poses);
+        if (!r) r = dev_alloc_copy<double>(ctx, &scratch, &d_vars, vars, n_vars);
+        if (!r) r = dev_alloc_copy<uint32_t>(ctx, &scratch, &d_of, pose_of, n_points);
+        if (!r) r = dev_alloc_copy<uint32_t>(ctx, &scratch, &d_idx, var_idx, n_points);
+        if (r) return r;
+        FX_HIP(fx::launch_pose_transform(d_poses, d_of, d_idx, n_points, d_vars, ctx->stream));
+        FX_HIP(hipMemcpyAsync(vars, d_vars, (size_t)n_vars * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        return FX_OK;
+    };
+    rc = run();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& blk : scratch.allocations) ctx->give_back(blk.p, blk.size);
+    return rc;
+}
+
+int fx_unscale_vars(fx_ctx* ctx, double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n == 0) return FX_OK;
+    if (!scaled || !mask || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    fx_dbatch scratch;
+    double *d_scaled = nullptr, *d_vars = nullptr;
+    uint8_t* d_mask = nullptr;
+    auto run = [&]() -> int {
+        int r = dev_alloc_copy<double>(ctx, &scratch, &d_scaled, scaled, n);
+        if (!r) r = dev_alloc_copy<double>(ctx, &scratch, &d_vars, vars, n);
+        if (!r) r = dev_alloc_copy<uint8_t>(ctx, &scratch, &d_mask, mask, n);
+        if (r) return r;
+        FX_HIP(fx::launch_unscale(scale, d_scaled, d_mask, d_vars, n, ctx->stream));
+        FX_HIP(hipMemcpyAsync(vars, d_vars, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        return FX_OK;
+    };
+    rc = run();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& blk : scratch.allocations) ctx->give_back(blk.p, blk.size);
+    return rc;
 }
 
 int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals) {

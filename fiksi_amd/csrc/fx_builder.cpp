@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/fiksi_amd_builder.h"
+#include "fx_recursive.h"
 
 namespace {
 
@@ -27,6 +28,8 @@ struct Element {
 struct Constraint {
     int tag;
     uint32_t expressions_idx;
+    uint8_t n_incident;     // IncidentElements handed to Graph::add_constraint (graph.rs:14-57)
+    uint32_t incident[6];
 };
 
 struct Expr {
@@ -143,6 +146,23 @@ void live_components(const fxs_system* s, std::vector<const Component*>& out) {
         if (c.elements.empty()) continue;
         out.push_back(&c);
     }
+}
+
+// Graph::add_element / add_constraint as lib.rs:403 and constraints/mod.rs:331-880 call them:
+// a Length has 1 degree of freedom, a Point 2, Lines and Circles 0 (they own no variables).
+fx::ra::Graph plan_graph(const fxs_system* s) {
+    fx::ra::Graph g;
+    for (const Element& e : s->elements) g.new_vertex(e.tag == FXS_LENGTH ? 1 : e.tag == FXS_POINT ? 2 : 0);
+    for (const Constraint& c : s->constraints) g.new_edge(valency_of(c.tag), std::vector<uint32_t>(c.incident, c.incident + c.n_incident));
+    return g;
+}
+
+constexpr uint64_t kDefaultPlanBudget = 200000;  // subgraphs the plan search may grow (the reference's search is unbounded)
+
+// element fields an expression names (fx_batch::expr_idx)
+int expr_fields(uint8_t tag) {
+    static const int k[11] = {2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+    return tag < 11 ? k[tag] : 0;
 }
 
 }  // namespace
@@ -288,7 +308,9 @@ int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32
     uint32_t cid = (uint32_t)s->constraints.size();
     merge_components(s, cid, inc, ni);  // graph.rs:235-254
     uint32_t expressions_idx = (uint32_t)s->expressions.size();
-    s->constraints.push_back(Constraint{tag, expressions_idx});
+    Constraint con{tag, expressions_idx, (uint8_t)ni, {0, 0, 0, 0, 0, 0}};
+    for (int q = 0; q < ni; ++q) con.incident[q] = inc[q];
+    s->constraints.push_back(con);
 
     auto push = [&](uint8_t etag, uint32_t i0, uint32_t i1, uint32_t i2, uint32_t i3, double p) {
         Expr x;
@@ -354,6 +376,46 @@ int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* elemen
         if (element_comp) for (uint32_t e : live[c]->elements) element_comp[e] = (uint16_t)c;
         if (constraint_comp) for (uint32_t k : live[c]->constraints) constraint_comp[k] = (uint16_t)c;
     }
+    return FX_OK;
+}
+
+int fxs_export_graph(const fxs_system* s, uint8_t* element_kind, uint32_t* element_idx, uint8_t* constraint_valency,
+                     uint32_t* constraint_expr, uint8_t* constraint_n_incident, uint32_t* constraint_incident) {
+    if (!s) return FX_ERR_INVALID;
+    for (size_t i = 0; i < s->elements.size(); ++i) {
+        if (element_kind) element_kind[i] = (uint8_t)s->elements[i].tag;
+        if (element_idx) element_idx[i] = s->elements[i].a;
+    }
+    for (size_t c = 0; c < s->constraints.size(); ++c) {
+        const Constraint& con = s->constraints[c];
+        if (constraint_valency) constraint_valency[c] = (uint8_t)valency_of(con.tag);
+        if (constraint_expr) constraint_expr[c] = con.expressions_idx;
+        if (constraint_n_incident) constraint_n_incident[c] = con.n_incident;
+        if (constraint_incident)
+            for (int q = 0; q < 6; ++q) constraint_incident[6 * c + q] = con.incident[q];
+    }
+    return FX_OK;
+}
+
+int fxs_recursive_plan(const fxs_system* s, uint64_t budget, uint32_t* out, uint32_t capacity, uint32_t* length, uint32_t* flags) {
+    if (!s || !length) return FX_ERR_INVALID;
+    std::vector<const Component*> live;
+    live_components(s, live);
+    const fx::ra::Graph graph = plan_graph(s);
+    std::vector<uint32_t> words;
+    uint32_t fl = 0;
+    for (const Component* comp : live) {
+        std::vector<uint32_t> els(comp->elements.begin(), comp->elements.end());
+        std::vector<uint32_t> cons(comp->constraints.begin(), comp->constraints.end());
+        const fx::ra::Plan plan = fx::ra::make_plan(graph, els, cons, budget ? budget : kDefaultPlanBudget);
+        fx::ra::serialise(plan, words);
+        fl |= (plan.panicked ? 1u : 0u) | (plan.exhausted ? 2u : 0u);
+        if (fl) break;
+    }
+    *length = (uint32_t)words.size();
+    if (flags) *flags = fl;
+    if (out)
+        for (size_t i = 0; i < words.size() && i < capacity; ++i) out[i] = words[i];
     return FX_OK;
 }
 
@@ -430,8 +492,181 @@ int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) 
     return FX_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// assemble::solve, Decomposer::RecursiveAssembly (assemble/mod.rs:212-277). Host: the plan and the
+// make-up of each cluster problem. Device: scale + perturbation (fx_system_prepare_batch), every
+// cluster solve (fx_cluster_solve_batch), the rigid moves (fx_pose_transform_points), the final
+// un-scaling (fx_unscale_vars) and the closing residual check.
+int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result) {
+    fx_solving_opts o;
+    if (opts) o = *opts; else fx_solving_opts_default(&o);
+    // the arm always runs Levenberg-Marquardt (assemble/mod.rs:224-227 ignores opts.optimizer)
+    fx_result total{};
+    total.exit = FX_EXIT_SSE;
+    if (s->variables.empty()) {
+        if (result) *result = total;
+        return FX_OK;
+    }
+    const fxs_system* one[1] = {s};
+    fxs_flat* f = nullptr;
+    int rc = fxs_flatten(one, 1, &f);
+    if (rc) return rc;
+    struct Guard { fxs_flat* f; ~Guard() { fxs_flat_free(f); } } guard{f};
+
+    const uint32_t nvars = (uint32_t)s->variables.size(), nexprs = (uint32_t)s->expressions.size();
+    std::vector<double> vt(nvars), params(nexprs + 1);
+    double scale = 1.;
+    rc = fx_system_prepare_batch(ctx, &f->batch, o.perturb, vt.data(), params.data(), &scale);
+    if (rc) return rc;
+    total.scale = scale;
+    std::vector<uint8_t> touched(nvars, 0);
+
+    const fx::ra::Graph graph = plan_graph(s);
+    auto is_point = [&](uint32_t e) { return s->elements[e].tag == FXS_POINT; };
+
+    std::vector<const Component*> live;
+    live_components(s, live);
+    std::vector<int32_t> local(nvars, -1);
+    for (const Component* comp : live) {
+        std::vector<uint32_t> els(comp->elements.begin(), comp->elements.end());
+        std::vector<uint32_t> cons(comp->constraints.begin(), comp->constraints.end());
+        const fx::ra::Plan plan = fx::ra::make_plan(graph, els, cons, kDefaultPlanBudget);
+        if (plan.panicked || plan.exhausted) return FX_ERR_UNSUPPORTED;
+
+        for (const fx::ra::Step& step : plan.steps) {
+            const fx::ra::ClusterProblem cp = fx::ra::make_cluster_problem(step, is_point);
+            if (cp.panicked) return FX_ERR_UNSUPPORTED;
+
+            // unknowns: the poses, then the members' variables (assemble/mod.rs:431-474); constants: the points as
+            // solved so far, one pair per pose row pair
+            std::vector<double> x(3 * cp.clusters.size(), 0.);
+            std::vector<uint32_t> global_of;  // unknown -> System variable (poses: none)
+            std::fill(local.begin(), local.end(), -1);
+            for (uint32_t e : cp.members) {
+                const Element& el = s->elements[e];
+                const int n = el.tag == FXS_LENGTH ? 1 : el.tag == FXS_POINT ? 2 : 0;
+                for (int q = 0; q < n; ++q) {
+                    local[el.a + q] = (int32_t)x.size();
+                    x.push_back(vt[el.a + q]);
+                }
+            }
+            const uint32_t n_unknown = (uint32_t)x.size();
+            std::vector<uint8_t> tags;
+            std::vector<uint32_t> idx;
+            std::vector<double> prm;
+            for (size_t ci = 0; ci < cp.clusters.size(); ++ci) {  // pose rows come first (:547-588)
+                for (uint32_t point : cp.clusters[ci].second) {
+                    const uint32_t g = s->elements[point].a;
+                    if (local[g] < 0) return FX_ERR_UNSUPPORTED;
+                    const uint32_t was = (uint32_t)x.size();
+                    x.push_back(vt[g]);
+                    x.push_back(vt[g + 1]);
+                    for (int q = 0; q < 2; ++q) {
+                        tags.push_back((uint8_t)(FX_POSE_COINCIDENCE_X + q));
+                        idx.push_back((uint32_t)(3 * ci));
+                        idx.push_back(was);
+                        idx.push_back((uint32_t)local[g] + (uint32_t)q);
+                        idx.push_back(0);
+                        prm.push_back(0.);
+                    }
+                }
+            }
+            for (uint32_t c : step.constraints) {  // :346-351
+                const Constraint& con = s->constraints[c];
+                for (int q = 0; q < valency_of(con.tag); ++q) {
+                    const Expr& ex = s->expressions[con.expressions_idx + q];
+                    tags.push_back(ex.tag);
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t m = 0;
+                        if (k < expr_fields(ex.tag)) {
+                            if (local[ex.idx[k]] < 0) return FX_ERR_UNSUPPORTED;  // the reference panics (`.unwrap()`, :505-509)
+                            m = (uint32_t)local[ex.idx[k]];
+                        }
+                        idx.push_back(m);
+                    }
+                    prm.push_back(params[con.expressions_idx + q]);
+                }
+            }
+            std::vector<uint8_t> fixed(x.size(), 0);
+            for (size_t i = n_unknown; i < x.size(); ++i) fixed[i] = 1;
+            const uint32_t var_off[2] = {0, (uint32_t)x.size()}, expr_off[2] = {0, (uint32_t)tags.size()};
+            fx_batch b{};
+            b.n_systems = 1;
+            b.var_off = var_off;
+            b.expr_off = expr_off;
+            b.vars = x.data();
+            b.var_fixed = fixed.data();
+            b.expr_tag = tags.data();
+            b.expr_idx = idx.data();
+            b.expr_param = prm.data();
+            fx_result r{};
+            rc = fx_cluster_solve_batch(ctx, &b, &o.lm, &r);
+            if (rc) return rc;
+            total.accepted += r.accepted;
+            total.trials += r.trials;
+            total.exit = r.exit;
+            total.ncomp += 1;
+            total.sse0 += r.sse0;
+            total.sse += r.sse;
+
+            for (uint32_t g = 0; g < nvars; ++g) {  // :228-236
+                if (local[g] >= 0) {
+                    vt[g] = x[(size_t)local[g]];
+                    touched[g] = 1;
+                }
+            }
+            // :238-275 what a moved cluster carries along
+            std::vector<uint32_t> pose_of, point_var;
+            for (size_t ci = 0; ci < cp.clusters.size(); ++ci) {
+                const std::vector<uint32_t>* carried = fx::ra::lookup(step.owned_elements, cp.clusters[ci].first);
+                if (!carried) continue;
+                for (uint32_t e : *carried) {
+                    if (!is_point(e) || std::find(cp.members.begin(), cp.members.end(), e) != cp.members.end()) continue;
+                    pose_of.push_back((uint32_t)ci);
+                    point_var.push_back(s->elements[e].a);
+                    touched[s->elements[e].a] = touched[s->elements[e].a + 1] = 1;
+                }
+            }
+            rc = fx_pose_transform_points(ctx, x.data(), (uint32_t)cp.clusters.size(), pose_of.data(), point_var.data(),
+                                          (uint32_t)pose_of.size(), vt.data(), nvars);
+            if (rc) return rc;
+        }
+    }
+
+    rc = fx_unscale_vars(ctx, scale, vt.data(), touched.data(), s->variables.data(), nvars);
+    if (rc) return rc;
+    // the closing check: sum of squared expression residuals on the solved variables, from the device
+    // (no LM step is taken: max_outer = 0)
+    std::memcpy(f->vars.data(), s->variables.data(), nvars * sizeof(double));
+    fx_lm_opts probe;
+    fx_lm_opts_default(&probe);
+    probe.max_outer = 0;
+    fx_result pr{};
+    rc = fx_lm_solve_batch(ctx, &f->batch, &probe, &pr);
+    if (rc) return rc;
+    total.sse_unscaled = pr.sse_unscaled;
+    if (result) *result = total;
+    return FX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const fx_solving_opts* opts,
                       fx_result* results) {
+    if (opts && opts->decomposer == 2) {  // RecursiveAssembly plans each System from its elements: one after the other
+        if (n && !systems) return FX_ERR_INVALID;
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!systems[k]) return FX_ERR_INVALID;
+            int rc = solve_recursive_assembly(systems[k], ctx, opts, results ? results + k : nullptr);
+            if (rc) return rc;
+        }
+        return FX_OK;
+    }
     fxs_flat* f = nullptr;
     int rc = fxs_flatten(systems, n, &f);
     if (rc) return rc;

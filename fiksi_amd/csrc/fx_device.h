@@ -119,6 +119,9 @@ struct DeviceBatch {
     int16_t* g_colof;         // [total] variable -> free column of the block in flight
     // FX_STEP_QR plans, built on first use (null until then)
     QrPlans qr_none, qr_units;
+    // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
+    // only the pose instantiations of the solve kernel may run it
+    uint32_t has_pose;
 };
 
 struct LmParams {
@@ -148,6 +151,15 @@ hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_
 // scout + sort for the longest-first hand-out of the grouped kernel (fx_presort.hip)
 size_t presort_temp_bytes(uint32_t n);
 hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void* temp, size_t temp_bytes, hipStream_t stream);
+// fx_cluster.hip — the device side of the RecursiveAssembly arm around its cluster solves:
+// scale + LCG perturbation of whole Systems (assemble/mod.rs:58-124) without a solve, one wavefront per System
+// (out_params: the expression parameters as Expression::transform leaves them, expressions.rs:195-211)
+hipError_t launch_prepare(const DeviceBatch& b, uint32_t mode, double* out_vars, double* out_params, double* out_scale, hipStream_t stream);
+// vars[i] = scale * scaled[i] where mask[i] (assemble/mod.rs:234-235, 259-262)
+hipError_t launch_unscale(double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n, hipStream_t stream);
+// Pose2D::transform_point (expressions.rs:1120-1134) of n points in place: vars[idx[i]], vars[idx[i]+1] by pose[3*pose_of[i]..]
+hipError_t launch_pose_transform(const double* poses, const uint32_t* pose_of, const uint32_t* idx, uint32_t n, double* vars,
+                                 hipStream_t stream);
 size_t wide_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes(const DeviceBatch& b);
 size_t solve_lds_bytes_units(const DeviceBatch& b);

@@ -28,11 +28,21 @@
 #define FX_TAG_LLPERP 9
 #define FX_TAG_LCT 10
 #define FX_NTAGS 11
+// Rows of a RecursiveAssembly cluster problem (fiksi/src/assemble/mod.rs:547-588): a point of a solved
+// cluster, moved by the cluster's pose, must land on the point's new position. Internal to the library:
+// only the RecursiveAssembly arm (fx_recursive.h) builds them, only the POSE instantiations evaluate them.
+// Fields: [0] the pose (rotation, tx, ty: three consecutive variables), [1] the point as solved so far
+// (two consecutive fixed variables), [2] the coordinate of the point's new position the row is about.
+#define FX_TAG_POSE_X 11
+#define FX_TAG_POSE_Y 12
+#define FX_NTAGS_POSE 13
 
 namespace fx {
 
 // Number of scalar variables an expression reads (expressions.rs:48-182).
+template <bool POSE = false>
 __host__ __device__ inline int tag_nvars(int tag) {
+    if (POSE && tag >= FX_TAG_POSE_X) return 6;
     switch (tag) {
         case FX_TAG_VVE: return 2;
         case FX_TAG_PPD: return 4;
@@ -49,9 +59,16 @@ __host__ __device__ inline int tag_nvars(int tag) {
 // the scalar variables it reads, in gradient order (expressions.rs:48-182). Points contribute
 // (idx, idx+1); entries beyond the variable count are 0. Written without arrays-in-switch so the
 // result stays in registers.
-template <typename I>
+template <bool POSE = false, typename I>
 __host__ __device__ inline int expand_vars(int tag, const I f[4], uint32_t out[8]) {
     const uint32_t a = f[0], b = f[1], c = f[2], d = f[3];
+    if (POSE && tag >= FX_TAG_POSE_X) {
+        out[0] = a; out[1] = a + 1; out[2] = a + 2;
+        out[3] = b; out[4] = b + 1;
+        out[5] = c;
+        out[6] = 0; out[7] = 0;
+        return 6;
+    }
     const int k = tag_nvars(tag);
     out[0] = a;
     out[1] = (tag == FX_TAG_VVE) ? b : a + 1;  // VariableVariableEquality holds two scalars
@@ -112,8 +129,32 @@ __device__ __forceinline__ T wrap_pi(T a) {
 // gradient arithmetic (residual-only evaluation, expressions.rs:883-961).
 // CR = true: the two angle residuals use the correctly rounded atan2 of fx_atan2.h instead of the device libm's
 // (FX_STEP_QR: every bit of the solve then follows from IEEE arithmetic alone).
-template <typename T, bool WANT_G, bool CR = false>
+// POSE = true adds the two pose rows (Pose2D::transform_point / gradient_chain_rule_point,
+// expressions.rs:1120-1157, as assemble/mod.rs:547-588 uses them); they cost a sincos, so only the
+// cluster-problem instantiations carry them.
+template <typename T, bool WANT_G, bool CR = false, bool POSE = false>
 __device__ __forceinline__ T eval_expression(int tag, const T v[8], T param, T g[8]) {
+    if constexpr (POSE) {
+        if (tag >= FX_TAG_POSE_X) {
+            T sn, cs;
+            if constexpr (sizeof(T) == 8) ::sincos(v[0], &sn, &cs);
+            else ::sincosf(v[0], &sn, &cs);
+            const T pu = v[3], pv = v[4];
+            const T uc = pu * cs, us = pu * sn, vc = pv * cs, vs = pv * sn;
+            const bool is_x = tag == FX_TAG_POSE_X;
+            const T gx = is_x ? T(1) : T(0), gy = is_x ? T(0) : T(1);
+            if (WANT_G) {
+                g[0] = (-us - vc) * gx + (uc - vs) * gy;
+                g[1] = gx;
+                g[2] = gy;
+                g[3] = T(0);
+                g[4] = T(0);
+                g[5] = T(-1);
+            }
+            const T moved = is_x ? (v[1] + uc - vs) : (v[2] + us + vc);
+            return moved - v[5];
+        }
+    }
     switch (tag) {
         case FX_TAG_VVE: {  // expressions.rs:294-300
             if (WANT_G) { g[0] = T(-1); g[1] = T(1); }

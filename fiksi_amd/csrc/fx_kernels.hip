@@ -124,7 +124,7 @@ enum Phase { PH_SETUP = 0, PH_EVAL = 1, PH_FORM = 2, PH_FACTOR = 3, PH_SOLVE = 4
 // everything per block stays in LDS and registers as before.
 // QR = true adds the reference-numerics step (FX_STEP_QR) — an instantiation of its own, so that the register
 // budget of the plain kernel (two wavefronts per SIMD) does not pay for the QR step's register window.
-template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false, bool QR = false>
+template <int N, typename T, bool PROF, bool UNITS, int OPT = 0, bool GLOBAL = false, bool QR = false, bool POSE = false>
 __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmParams& prm, const SolveLayout& L, unsigned char* smem) {
     unsigned long long ph[PH_COUNT] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_last = 0;
@@ -270,7 +270,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
             const ushort4 f4 = ld_idx(i);
             uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
             uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int k = expand_vars(tag, ff, vars8);
+            int k = expand_vars<POSE>(tag, ff, vars8);
             double prm_e = ld_param(i);
             if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
             rtag[pos] = (uint8_t)tag;
@@ -337,7 +337,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                 const ushort4 f4 = ld_idx(i);
                 uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
                 uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                int k = expand_vars(tag, ff, vars8);
+                int k = expand_vars<POSE>(tag, ff, vars8);
                 double prm_e = ld_param(i);
                 if ((prm.mode & 1u) && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
                 rtag[pos] = (uint8_t)tag;
@@ -650,7 +650,7 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                 T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
-                T r = eval_expression<T, true, CR_ATAN2>(rtag[row], v, P[row], g);
+                T r = eval_expression<T, true, CR_ATAN2, POSE>(rtag[row], v, P[row], g);
                 R[buf * mr + row] = r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
@@ -1080,11 +1080,11 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
         const ushort4 f4 = ld_idx(i);
         uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
         uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        expand_vars(tag, ff, vars8);
+        expand_vars<POSE>(tag, ff, vars8);
         double v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = XD[vars8[e]];
-        double r = eval_expression<double, false, CR_ATAN2>(tag, v, ld_param(i), g);
+        double r = eval_expression<double, false, CR_ATAN2, POSE>(tag, v, ld_param(i), g);
         part += r * r;
     }
     double sse_u = wave_sum(part);
@@ -1125,6 +1125,14 @@ template <int N, bool PROF, bool UNITS>
 __global__ __launch_bounds__(64) void lm_solve_qr_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
     lm_solve_body<N, double, PROF, UNITS, 0, false, true>(b, prm, L, smem);
+}
+
+// cluster problems of Decomposer::RecursiveAssembly (fx_recursive.h): the same solve with the two pose rows
+// of fx_expr.h switched on; one build of 64 columns serves every step (a step is a single small problem)
+template <bool QR>
+__global__ __launch_bounds__(64) void lm_solve_pose_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    lm_solve_body<64, double, false, false, 0, false, QR, true>(b, prm, L, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1487,8 +1495,24 @@ static hipError_t launch_solve_t(const DeviceBatch& b, const LmParams& p, hipStr
     }
 }
 
+// Batches holding pose rows (b.has_pose, set by the upload when the RecursiveAssembly arm asks for it)
+static hipError_t launch_solve_pose(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 64u) return hipErrorInvalidValue;
+    const bool qr = p.lm.solver == FX_STEP_QR;
+    if (qr && !b.qr_none.desc) return hipErrorInvalidValue;
+    SolveLayout L = make_layout(64u, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents, qr ? b.qr_none.max_m : 0u,
+                                qr ? b.qr_none.max_h : 0u);
+    if (L.total > 160u * 1024u) return hipErrorInvalidValue;
+    void (*fn)(DeviceBatch, LmParams, SolveLayout) = qr ? &lm_solve_pose_kernel<true> : &lm_solve_pose_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
+    return hipGetLastError();
+}
+
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
+    if (b.has_pose) return launch_solve_pose(b, p, stream);
     if (p.prof && grouped_applies(b, p)) return launch_solve_grouped(b, p, stream);
     if (p.prof) {  // diagnostic build, instantiated for the headline shape only
         uint32_t n = pad_n(b.max_free);

@@ -195,6 +195,32 @@ class System:
     def flatten(self):
         return flatten([self])
 
+    def graph(self):
+        """The System with its geometric graph (graph.rs:98-147): the flat batch arrays of ``flatten()`` plus, per
+        element, ``el_kind`` (0 Length, 1 Point, 2 Line, 3 Circle), ``el_idx`` (first variable) and ``el_comp``, and
+        per constraint ``con_valency``, ``con_expr`` (first expression), ``con_ninc`` / ``con_inc`` (incident
+        primitive elements, 6 slots each) and ``con_comp``."""
+        g = self.flatten()
+        ne, nc = lib.fxs_num_elements(self._h), lib.fxs_num_constraints(self._h)
+        ek = np.zeros(max(ne, 1), dtype=np.uint8); ei = np.zeros(max(ne, 1), dtype=np.uint32)
+        cv = np.zeros(max(nc, 1), dtype=np.uint8); ce = np.zeros(max(nc, 1), dtype=np.uint32)
+        cn = np.zeros(max(nc, 1), dtype=np.uint8); ci = np.zeros(6 * max(nc, 1), dtype=np.uint32)
+        check(lib.fxs_export_graph(self._h, ek.ctypes.data, ei.ctypes.data, cv.ctypes.data, ce.ctypes.data, cn.ctypes.data,
+                                   ci.ctypes.data), "export_graph")
+        _, ec, cc = self.components()
+        g.update(el_kind=ek[:ne], el_idx=ei[:ne], el_comp=ec, con_valency=cv[:nc], con_expr=ce[:nc], con_ninc=cn[:nc],
+                 con_inc=ci[: 6 * nc], con_comp=cc)
+        return g
+
+    def recursive_plan(self, budget: int = 0):
+        """The recombination plan ``Decomposer.RecursiveAssembly`` solves this System by (host only), as the word
+        list of ``fxs_recursive_plan``, and its flags (bit0: the reference would panic, bit1: search budget spent)."""
+        n, fl = C.c_uint32(0), C.c_uint32(0)
+        check(lib.fxs_recursive_plan(self._h, budget, None, 0, C.byref(n), C.byref(fl)), "recursive_plan")
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        check(lib.fxs_recursive_plan(self._h, budget, out.ctypes.data, n.value, C.byref(n), C.byref(fl)), "recursive_plan")
+        return out[: n.value], fl.value
+
 
 def flatten(systems: Sequence[System]):
     """The fx_batch arrays (numpy copies) of a list of Systems."""

@@ -67,7 +67,14 @@ typedef enum fx_tag {
     FX_LINE_LINE_PARALLELISM = 8,
     FX_LINE_LINE_PERPENDICULARITY = 9,
     FX_LINE_CIRCLE_TANGENCY = 10,
-    FX_NUM_TAGS = 11
+    FX_NUM_TAGS = 11,
+    /* Rows of a RecursiveAssembly cluster problem (fiksi/src/assemble/mod.rs:547-588), accepted by
+     * fx_cluster_solve_batch only: a point of an already solved cluster, moved by the cluster's pose
+     * (Pose2D, constraints/expressions.rs:1094-1159), has to land on the point's new position.
+     * expr_idx: {pose (rotation, tx, ty: three consecutive variables), the point as solved so far (x; y is +1;
+     * fixed variables), the x (_X) or y (_Y) variable of the new position, 0}. */
+    FX_POSE_COINCIDENCE_X = 11,
+    FX_POSE_COINCIDENCE_Y = 12
 } fx_tag;
 
 /* One-wavefront limits of the fused solve kernel (one wavefront per System). Systems within them
@@ -154,7 +161,8 @@ typedef struct fx_lm_opts {
  * (solve/lbfgs.rs; f64 only; fx_result.accepted counts its
  * iterations, .trials its residual+Jacobian evaluations); decomposer: 0 = None, 1 = SinglePass (assemble/mod.rs:169-210:
  * maximum matching + strongly connected blocks, solved one after the other); 2 =
- * RecursiveAssembly is reported as FX_ERR_UNSUPPORTED. */
+ * RecursiveAssembly: through the builder only (fxs_system_solve, include/fiksi_amd_builder.h) — its plan needs the
+ * System's elements, which a flat batch does not carry; the batch entry points answer FX_ERR_UNSUPPORTED. */
 typedef struct fx_solving_opts {
     uint32_t optimizer;
     uint32_t decomposer;
@@ -295,6 +303,27 @@ int fx_analyze_batch(fx_ctx* ctx, const fx_batch* batch, uint8_t* dependent);
 /* == calculate_residual of every expression at batch->vars with all variables as given
  * (IdentityVariableMap, constraints/mod.rs:96-109). */
 int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
+
+/* ---- Decomposer::RecursiveAssembly: the device steps of assemble/mod.rs:212-277 ----------------------------
+ * The plan (analyze/graph/recursive_assembly.rs) and the make-up of each cluster problem are host bookkeeping in
+ * the builder; these four calls are everything numeric the arm does. */
+/* What assemble::solve does before any decomposer arm (assemble/mod.rs:58-124): out_vars = variables divided by the
+ * System's scale, free variables of each component nudged by the LCG (perturb != 0); out_params = expression
+ * parameters after Expression::transform (distances divided by the scale); out_scale[s] = the scale. Systems of up to
+ * FX_MAX_SYSTEM_VARS variables. */
+int fx_system_prepare_batch(fx_ctx* ctx, const fx_batch* batch, uint32_t perturb, double* out_vars, double* out_params,
+                            double* out_scale);
+/* fx_lm_solve_batch for cluster problems: the batch may hold FX_POSE_COINCIDENCE_X / _Y rows. f64, Levenberg-Marquardt
+ * (lm.rs:21-193, as the arm calls it, assemble/mod.rs:224-227), any fx_step_solver; each problem within the one-wavefront
+ * limits (FX_MAX_FREE_VARS unknowns, FX_MAX_ROWS rows). */
+int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
+/* Pose2D::transform_point (expressions.rs:1120-1134) in place on points (vars[var_idx[i]], vars[var_idx[i] + 1]) with
+ * pose poses[3 * pose_of[i] ..] = (rotation, tx, ty): the points a moved cluster carries along (assemble/mod.rs:238-275). */
+int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses, const uint32_t* pose_of, const uint32_t* var_idx,
+                             uint32_t n_points, double* vars, uint32_t n_vars);
+/* vars[i] = scale * scaled[i] where mask[i] != 0 (assemble/mod.rs:234-235, 259-262); other entries keep their bits. */
+int fx_unscale_vars(fx_ctx* ctx, double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n);
+
 /* == find_strongly_connected_expressions per connected component (analyze/graph/equations.rs:186-221),
  * the structural plan Decomposer::SinglePass solves by: the blocks of System `system` in solve order.
  * Host-only (no device needed). block_comp[k] = component of block k; its expressions are

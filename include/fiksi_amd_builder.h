@@ -76,6 +76,23 @@ int fxs_constraint_update_parameter(fxs_system* s, uint32_t constraint, double v
  * component id per element (FX_NO_COMPONENT if none) and per constraint. */
 int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* element_comp, uint16_t* constraint_comp);
 
+/* The geometric graph as the reference keeps it (graph.rs:98-147, lib.rs:123-137): per element its
+ * EncodedElement kind and first variable (Length: idx; Point: idx of x; Line: point1_idx; Circle: center_idx),
+ * per constraint its valency, first expression and the incident primitive elements handed to
+ * Graph::add_constraint (6 slots each, constraint_n_incident used). Any output pointer may be NULL. */
+int fxs_export_graph(const fxs_system* s, uint8_t* element_kind, uint32_t* element_idx, uint8_t* constraint_valency,
+                     uint32_t* constraint_expr, uint8_t* constraint_n_incident, uint32_t* constraint_incident);
+
+/* The recombination plan Decomposer::RecursiveAssembly solves the System by (analyze/graph/recursive_assembly.rs:164-480),
+ * one plan per live component, concatenated. Words: n_steps, then per step |constraints| ids.. |elements| ids..
+ * |free_elements| ids.., then the step's three tables (on_frontiers: element -> clusters; owned_elements: cluster ->
+ * elements; frontier_elements: cluster -> elements) each as |entries| (key |list| ids..).. in ascending key order.
+ * The reference walks randomly seeded hash sets; this plan walks them in ascending id order (fx_recursive.h).
+ * budget: subgraphs the search may grow per call (0 = default). flags: bit0 the reference would panic on this
+ * System, bit1 budget exhausted (the reference's search would not finish in reasonable time either).
+ * Host only. `out` may be NULL to ask for *length. */
+int fxs_recursive_plan(const fxs_system* s, uint64_t budget, uint32_t* out, uint32_t capacity, uint32_t* length, uint32_t* flags);
+
 /* Flat view of n Systems as one fx_batch (arrays owned by the returned object). */
 typedef struct fxs_flat fxs_flat;
 int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out);
@@ -84,7 +101,10 @@ void fxs_flat_free(fxs_flat* f);
 /* Copy solved variables of a flat batch back into the Systems it was built from. */
 int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n);
 
-/* System::solve for one System / many independent Systems on the device behind `ctx`. */
+/* System::solve for one System / many independent Systems on the device behind `ctx`.
+ * opts->decomposer == 2 (RecursiveAssembly): planned here on the host, each step's cluster problem solved on the
+ * device (fx_cluster_solve_batch); fx_result counts are summed over the steps, ncomp = steps solved.
+ * FX_ERR_UNSUPPORTED where the reference would panic or its plan search would not finish (fxs_recursive_plan flags). */
 int fxs_system_solve(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result);
 int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const fx_solving_opts* opts,
                       fx_result* results);

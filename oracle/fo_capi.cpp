@@ -13,6 +13,7 @@
 #include "fo_expressions.hpp"
 #include "fo_lm.hpp"
 #include "fo_qr.hpp"
+#include "fo_recursive.hpp"
 #include "fo_singlepass.hpp"
 #include "fo_rand.hpp"
 #include "fo_sparse.hpp"
@@ -344,6 +345,86 @@ int fo_solve_batch(uint32_t n_systems, const uint32_t* var_off, const uint32_t* 
         std::memcpy(vars + var_off[s], sys.variables.data(), sys.variables.size() * sizeof(double));
         if (results) results[s] = res;
     });
+    return 0;
+}
+
+// Pose2D::transform_point and gradient_chain_rule_point with the inner gradients [1,0] and [0,1]
+// (expressions.rs:1120-1157, as assemble/mod.rs:547-575 calls them). out: x, y, dx[3], dy[3].
+void fo_pose_rows(const double* pose3, double u, double v, double* out8) {
+    Pose2D pose = Pose2D::from_array(pose3);
+    pose.transform_point(u, v, out8[0], out8[1]);
+    pose.gradient_chain_rule_point(u, v, 1., 0., out8 + 2);
+    pose.gradient_chain_rule_point(u, v, 0., 1., out8 + 5);
+}
+
+// assemble::solve with Decomposer::RecursiveAssembly (assemble/mod.rs:212-277) on ONE System given with its
+// elements and constraints (fo_recursive.hpp). el_kind: 0 Length, 1 Point, 2 Line, 3 Circle; el_idx: variable
+// index of a Length / a Point's x. con_inc holds 6 slots per constraint (con_ninc used). el_comp / con_comp:
+// live component of each element / constraint in iteration order, 0xFFFF = none.
+// plan_out receives the concatenated serialised plans (fo::serialise_plan) of the components; step_results one
+// entry per solved cluster problem. flags: bit0 the reference would panic, bit1 search budget exhausted.
+int fo_solve_recursive(uint32_t nvars, double* vars, const uint8_t* var_fixed, uint32_t nexprs, const uint8_t* expr_tag,
+                       const uint32_t* expr_idx, const double* expr_param, uint32_t nel, const uint8_t* el_kind,
+                       const uint32_t* el_idx, const uint16_t* el_comp, uint32_t ncon, const uint8_t* con_valency,
+                       const uint32_t* con_expr, const uint8_t* con_ninc, const uint32_t* con_inc, const uint16_t* con_comp,
+                       int perturb, int ordering, uint32_t trial_cap, uint64_t budget, uint32_t* plan_out, uint32_t plan_cap,
+                       uint32_t* plan_len, fo_result* step_results, uint32_t step_cap, uint32_t* n_steps, uint32_t* flags) {
+    GeoSystem g;
+    g.variables.assign(vars, vars + nvars);
+    g.fixed.assign(var_fixed, var_fixed + nvars);
+    g.expressions.resize(nexprs);
+    for (uint32_t e = 0; e < nexprs; ++e) {
+        g.expressions[e].tag = expr_tag[e];
+        for (int k = 0; k < 4; ++k) g.expressions[e].idx[k] = expr_idx[4 * static_cast<size_t>(e) + k];
+        g.expressions[e].param = expr_param[e];
+    }
+    uint32_t ncomp = 0;
+    g.elements.resize(nel);
+    for (uint32_t i = 0; i < nel; ++i) {
+        g.elements[i] = GeoElementInfo{el_kind[i], el_idx[i]};
+        if (el_comp[i] != NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, el_comp[i] + 1u);
+    }
+    g.constraints.resize(ncon);
+    for (uint32_t c = 0; c < ncon; ++c) {
+        g.constraints[c].valency = con_valency[c];
+        g.constraints[c].expressions_idx = con_expr[c];
+        g.constraints[c].incident_elements.assign(con_inc + 6 * static_cast<size_t>(c), con_inc + 6 * static_cast<size_t>(c) + con_ninc[c]);
+        if (con_comp[c] != NO_COMPONENT) ncomp = std::max<uint32_t>(ncomp, con_comp[c] + 1u);
+    }
+    g.components.resize(ncomp);
+    for (uint32_t i = 0; i < nel; ++i)
+        if (el_comp[i] != NO_COMPONENT) g.components[el_comp[i]].elements.push_back(i);
+    for (uint32_t c = 0; c < ncon; ++c)
+        if (con_comp[c] != NO_COMPONENT) g.components[con_comp[c]].constraints.push_back(c);
+
+    RecursiveStats st = solve_recursive_assembly(g, perturb != 0, ordering ? QrOrdering::Colamd : QrOrdering::Natural, trial_cap,
+                                                 budget ? static_cast<size_t>(budget) : 200000);
+    std::memcpy(vars, g.variables.data(), nvars * sizeof(double));
+    uint32_t len = 0;
+    for (const std::vector<uint32_t>& p : st.plans) {
+        for (uint32_t w : p) {
+            if (plan_out && len < plan_cap) plan_out[len] = w;
+            ++len;
+        }
+    }
+    if (plan_len) *plan_len = len;
+    uint32_t ns = 0;
+    for (const LmStats& c : st.steps) {
+        if (step_results && ns < step_cap) {
+            fo_result r{};
+            r.accepted = c.accepted;
+            r.trials = c.trials;
+            r.exit = c.exit;
+            r.ncomp = 1;
+            r.scale = st.scale;
+            r.sse0 = c.sse_initial;
+            r.sse = c.sse_final;
+            step_results[ns] = r;
+        }
+        ++ns;
+    }
+    if (n_steps) *n_steps = ns;
+    if (flags) *flags = (st.panicked ? 1u : 0u) | (st.exhausted ? 2u : 0u);
     return 0;
 }
 

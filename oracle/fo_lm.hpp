@@ -88,7 +88,10 @@ inline double norm_squared(const double* v, size_t n) {  // lm.rs:195-197 (seque
 // lm.rs:21-193. `ordering` is Colamd in the reference (lm.rs:103); Natural is offered for tests.
 // `trial_cap` bounds the reference's unbounded inner loop (0 = uncapped, as in the reference).
 // If `first_delta` is non-null it receives the first successfully solved delta (ncols values).
-inline LmStats levenberg_marquardt(const Subsystem& problem, double* variables,
+// `Problem` (solve/mod.rs:29-49): num_variables, num_residuals, calculate_residuals,
+// calculate_residuals_and_sparse_jacobian — Subsystem above, or the cluster problem of fo_recursive.hpp.
+template <class Problem>
+inline LmStats levenberg_marquardt(const Problem& problem, double* variables,
                                    QrOrdering ordering = QrOrdering::Colamd, uint32_t trial_cap = 0,
                                    double* first_delta = nullptr) {
     LmStats stats;

@@ -337,3 +337,41 @@ def eval_dense_batch(b):
         blk = jac[int(off[s]):int(off[s + 1])]
         out.append(blk.reshape(m, -1) if m and len(blk) else blk.reshape(m, 0))
     return r, out
+
+
+def solve_recursive(g, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, budget: int = 0):
+    """assemble::solve with Decomposer::RecursiveAssembly on ONE System (fo_recursive.hpp).
+
+    ``g``: the System with its geometric graph — ``vars, var_fixed, expr_tag, expr_idx, expr_param`` (flat batch of one
+    System), ``el_kind, el_idx, el_comp`` per element and ``con_valency, con_expr, con_ninc, con_inc, con_comp`` per
+    constraint (``fiksi_amd.System.graph()`` produces it). Returns (solved variables, serialised plan words,
+    per-step results, flags: bit0 the reference would panic, bit1 search budget exhausted)."""
+    vars_out = np.ascontiguousarray(g["vars"], dtype=np.float64).copy()
+    nv, ne = len(vars_out), len(g["expr_tag"])
+    nel, ncon = len(g["el_kind"]), len(g["con_valency"])
+    cap = 1 << 20
+    plan = np.zeros(cap, dtype=np.uint32)
+    plan_len = C.c_uint32(0)
+    steps = np.zeros(4096, dtype=RESULT_DTYPE)
+    n_steps = C.c_uint32(0)
+    flags = C.c_uint32(0)
+    a = lambda k, dt: np.ascontiguousarray(g[k], dtype=dt)
+    keep = [a("var_fixed", np.uint8), a("expr_tag", np.uint8), a("expr_idx", np.uint32), a("expr_param", np.float64),
+            a("el_kind", np.uint8), a("el_idx", np.uint32), a("el_comp", np.uint16), a("con_valency", np.uint8),
+            a("con_expr", np.uint32), a("con_ninc", np.uint8), a("con_inc", np.uint32), a("con_comp", np.uint16)]
+    lib().fo_solve_recursive(C.c_uint32(nv), _p(vars_out), _p(keep[0]), C.c_uint32(ne), _p(keep[1]), _p(keep[2]), _p(keep[3]),
+                             C.c_uint32(nel), _p(keep[4]), _p(keep[5]), _p(keep[6]), C.c_uint32(ncon), _p(keep[7]), _p(keep[8]),
+                             _p(keep[9]), _p(keep[10]), _p(keep[11]), C.c_int(1 if perturb else 0),
+                             C.c_int(1 if ordering == "colamd" else 0), C.c_uint32(trial_cap), C.c_uint64(budget), _p(plan),
+                             C.c_uint32(cap), C.byref(plan_len), _p(steps), C.c_uint32(len(steps)), C.byref(n_steps), C.byref(flags))
+    assert plan_len.value <= cap and n_steps.value <= len(steps)
+    return vars_out, plan[: plan_len.value].copy(), steps[: n_steps.value].copy(), int(flags.value)
+
+
+def pose_rows(pose, point):
+    """Pose2D::transform_point and the two gradient_chain_rule_point rows ([1,0] and [0,1]) at ``pose`` =
+    (rotation, tx, ty) for ``point`` = (u, v). Returns (x, y, gradient of x[3], gradient of y[3])."""
+    pose = np.ascontiguousarray(pose, dtype=np.float64)
+    out = np.zeros(8, dtype=np.float64)
+    lib().fo_pose_rows(_p(pose), C.c_double(point[0]), C.c_double(point[1]), _p(out))
+    return out[0], out[1], out[2:5].copy(), out[5:8].copy()
