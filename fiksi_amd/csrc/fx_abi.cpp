@@ -1230,13 +1230,15 @@ bool wide_kernel_applies(const fx::LmParams& p) {
 
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (!db->n_large) return FX_OK;
-    if (wide_kernel_applies(p) && db->d.n_wide) {
+    // cluster problems with pose rows: only the one-wavefront pose build and the sparse path evaluate those
+    const bool pose = db->d.has_pose != 0;
+    if (!pose && wide_kernel_applies(p) && db->d.n_wide) {
         hipError_t e = fx::launch_solve_wide(db->d, p, ctx->stream);
         if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
     }
     const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
     // Decomposer::None, f64 LM: large Systems made of small components are walked on the device
-    const bool comp_walk = wide_kernel_applies(p);
+    const bool comp_walk = !pose && wide_kernel_applies(p);
     if (comp_walk) {
         int rc = ensure_component_walk(ctx, db);
         if (rc) return rc;
@@ -1250,7 +1252,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     std::vector<uint32_t> todo;
     for (uint32_t s = 0; s < db->d.n_systems; ++s) {
         if (!db->h_sys_large[s]) continue;
-        if (db->h_sys_large[s] == 2 && wide_kernel_applies(p)) continue;  // done by the wide kernel
+        if (db->h_sys_large[s] == 2 && !pose && wide_kernel_applies(p)) continue;  // done by the wide kernel
         if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
         if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
         todo.push_back(s);
@@ -1869,7 +1871,6 @@ int fx_system_prepare_batch(fx_ctx* ctx, const fx_batch* batch, uint32_t perturb
     if (rc) return rc;
     db->resident = false;
     auto run = [&]() -> int {
-        if (db->n_large) return fail(FX_ERR_TOO_LARGE, "fx_system_prepare_batch takes Systems of up to %u variables", FX_MAX_SYSTEM_VARS);
         double *d_vars = nullptr, *d_scale = nullptr, *d_params = nullptr;
         int r = dev_alloc_copy<double>(ctx, db, &d_vars, nullptr, db->d.n_vars);
         if (r) return r;
@@ -1903,11 +1904,6 @@ int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts*
     if (rc) return rc;
     db->resident = false;
     db->d.has_pose = 1u;
-    if (db->n_large || db->d.n_wide) {
-        fx_batch_free(ctx, db);
-        return fail(FX_ERR_TOO_LARGE, "a cluster problem holds at most %u unknowns, %u rows and %u variables (one wavefront solves it)",
-                    FX_MAX_FREE_VARS, FX_MAX_ROWS, FX_MAX_SYSTEM_VARS);
-    }
     rc = fx_lm_solve_device(ctx, db, &o);
     if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
     if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);

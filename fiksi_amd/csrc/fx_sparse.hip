@@ -47,6 +47,7 @@ struct SpRows {                 // expression data of the whole System (device)
     const double* param;        // [net] unscaled
     double* sparam;             // [net] scaled (distance parameters * 1/scale)
     uint32_t net;
+    uint32_t has_pose;          // the System holds pose rows (cluster problems): the POSE builds of the row kernels run it
 };
 
 // state of a device-controlled LM loop (the kernels that use it come further down)
@@ -174,7 +175,7 @@ struct SpJac {                   // J of one component (device)
 };
 
 // K1/K2 for one component: thread per row (subsystem.rs:93-166).
-template <bool WANT_J>
+template <bool WANT_J, bool POSE = false>
 __global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, const double* __restrict__ xs,
                                                       double* __restrict__ r, double* __restrict__ jvals) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,11 +185,11 @@ __global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, co
     ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
     uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
     uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars(tag, ff, vars8);
+    expand_vars<POSE>(tag, ff, vars8);
     double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
-    r[row] = eval_expression<double, WANT_J>(tag, v, rows.sparam[e], g);
+    r[row] = eval_expression<double, WANT_J, false, POSE>(tag, v, rows.sparam[e], g);
     if (WANT_J) {
         uint32_t slots = jac.jslot[row];
         uint32_t base = jac.jrow_ptr[row];
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, co
 }
 
 // the same at the trial point of a device-controlled LM loop: generation cur ^ 1 of the vectors
+template <bool POSE = false>
 __global__ __launch_bounds__(256) void sp_eval_dc_kernel(SpRows rows, SpJac jac, double* xs0, double* xs1, double* r0, double* r1, double* j0,
                                                          double* j1, const SpLm* __restrict__ st) {
     if (sp_lm_done(st)) return;
@@ -225,11 +227,11 @@ __global__ __launch_bounds__(256) void sp_eval_dc_kernel(SpRows rows, SpJac jac,
     ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
     uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
     uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars(tag, ff, vars8);
+    expand_vars<POSE>(tag, ff, vars8);
     double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
-    r[row] = eval_expression<double, true>(tag, v, rows.sparam[e], g);
+    r[row] = eval_expression<double, true, false, POSE>(tag, v, rows.sparam[e], g);
     uint32_t slots = jac.jslot[row];
     uint32_t base = jac.jrow_ptr[row];
     uint32_t cnt = jac.jrow_ptr[row + 1] - base;
@@ -728,6 +730,7 @@ __global__ void sp_writeback_kernel(const uint32_t* __restrict__ fvar, uint32_t 
 }
 
 // residual of every expression on unscaled variables (constraints/mod.rs:96-109)
+template <bool POSE = false>
 __global__ void sp_identity_residual_kernel(SpRows rows, const double* __restrict__ x, double* __restrict__ out) {
     uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows.net) return;
@@ -735,11 +738,11 @@ __global__ void sp_identity_residual_kernel(SpRows rows, const double* __restric
     ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
     uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
     uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars(tag, ff, vars8);
+    expand_vars<POSE>(tag, ff, vars8);
     double v[8], g[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = x[vars8[q]];
-    out[e] = eval_expression<double, false>(tag, v, rows.param[e], g);
+    out[e] = eval_expression<double, false, false, POSE>(tag, v, rows.param[e], g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1023,7 +1026,7 @@ void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint32_t>& 
     for (uint32_t r = 0; r < P.m; ++r) {
         uint32_t e = e0 + rows[r];
         uint32_t vars8[8];
-        int k = expand_vars((int)b->expr_tag[e], b->expr_idx + 4 * (size_t)e, vars8);
+        int k = expand_vars<true>((int)b->expr_tag[e], b->expr_idx + 4 * (size_t)e, vars8);
         auto& rc = rowcols[r];
         for (int q = 0; q < k; ++q) {
             int32_t c = colof[vars8[q]];
@@ -1356,11 +1359,13 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     rows.param = pool.up(params);
     rows.sparam = pool.alloc<double>(net);
     rows.net = net;
+    rows.has_pose = 0;
+    for (uint8_t t : tags)
+        if ((t & 0x7F) >= FX_TAG_POSE_X) rows.has_pose = 1;
     double* d_vars0 = pool.up(vars0);
     double* d_xs[2] = {pool.alloc<double>(nvt), pool.alloc<double>(nvt)};
     double* d_snap = pool.alloc<double>(nvt);  // pre-solve snapshot (quirk Q2)
     double* d_scal = pool.alloc<double>(8);       // scale, 1/scale, sse, dn2, sse_unscaled
-    uint32_t* d_flag = pool.alloc<uint32_t>(2);
     double* d_runs = pool.alloc<double>(std::max(net, 1u));
     if (pool.err != hipSuccess) return pool.err;
 
@@ -1520,9 +1525,9 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         auto eval = [&](int buf, bool want_j, double* sse_out) -> hipError_t {
             if (m) {
                 if (want_j)
-                    hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
+                    hipLaunchKernelGGL((rows.has_pose ? sp_eval_kernel<true, true> : sp_eval_kernel<true, false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
                 else
-                    hipLaunchKernelGGL(sp_eval_kernel<false>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
+                    hipLaunchKernelGGL((rows.has_pose ? sp_eval_kernel<false, true> : sp_eval_kernel<false, false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
             }
             hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[buf], m, d_scal + 2);
             hipError_t er = hipMemcpyAsync(sse_out, d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream);
@@ -1582,7 +1587,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
                             hipLaunchKernelGGL(sp_scaled_copy_kernel, grid_for(nv), dim3(256), 0, stream, d_dir, step, nv, d_delta);
                             hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[0], d_xs[1]);
                         }
-                        if (m) hipLaunchKernelGGL(sp_eval_kernel<true>, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[1], d_r[1], d_j[1]);
+                        if (m) hipLaunchKernelGGL((rows.has_pose ? sp_eval_kernel<true, true> : sp_eval_kernel<true, false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[1], d_r[1], d_j[1]);
                         hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[1], m, d_scal + 5);
                         gradient(1);
                         hipLaunchKernelGGL(sp_dot_kernel, dim3(1), dim3(1024), 0, stream, d_grad, d_dir, nv, d_scal + 6);
@@ -1657,7 +1662,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
             }
             hipLaunchKernelGGL(sp_sumsq_dc_kernel, dim3(1), dim3(1024), 0, stream, d_delta, d_delta, 0u, nv, &d_lm->dn2, d_lm);
             if (nv) hipLaunchKernelGGL(sp_trial_dc_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, bf, d_lm);
-            if (m) hipLaunchKernelGGL(sp_eval_dc_kernel, grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[0], d_xs[1], d_r[0], d_r[1], d_j[0], d_j[1], d_lm);
+            if (m) hipLaunchKernelGGL((rows.has_pose ? sp_eval_dc_kernel<true> : sp_eval_dc_kernel<false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[0], d_xs[1], d_r[0], d_r[1], d_j[0], d_j[1], d_lm);
             hipLaunchKernelGGL(sp_sumsq_dc_kernel, dim3(1), dim3(1024), 0, stream, d_r[0], d_r[1], 1u, m, &d_lm->sse_t, d_lm);
             hipLaunchKernelGGL(sp_lm_control_kernel, dim3(1), dim3(1), 0, stream, d_lm, o);
         };
@@ -1724,7 +1729,7 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
     }
 
     // ---- post-solve check on the unscaled variables
-    if (net) hipLaunchKernelGGL(sp_identity_residual_kernel, grid_for(net), dim3(256), 0, stream, rows, d_vars_out, d_runs);
+    if (net) hipLaunchKernelGGL((rows.has_pose ? sp_identity_residual_kernel<true> : sp_identity_residual_kernel<false>), grid_for(net), dim3(256), 0, stream, rows, d_vars_out, d_runs);
     hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_runs, net, d_scal + 4);
     e = hipMemcpyAsync(host3, d_scal, sizeof(double), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(host3 + 1, d_scal + 4, sizeof(double), hipMemcpyDeviceToHost, stream);

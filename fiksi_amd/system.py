@@ -160,10 +160,14 @@ class System:
         return [ConstraintHandle(self.id, i, lib.fxs_constraint_tag_of(self._h, i)) for i in range(n)]
 
     # -- lib.rs:464-466
-    def solve(self, opts: SolvingOptions = SolvingOptions.DEFAULT, ctx: Optional[abi.Context] = None):
+    def solve(self, opts: SolvingOptions = SolvingOptions.DEFAULT, ctx: Optional[abi.Context] = None, **lm_kw):
+        """``lm_kw``: fields of ``fx_lm_opts`` to set beside the reference's three options (e.g. ``solver=2`` for
+        the reference-numerics step FX_STEP_QR)."""
         ctx = ctx or default_context()
         res = FxResult()
         o = opts._to_abi()
+        for k, v in lm_kw.items():
+            setattr(o.lm, k, v)
         check(lib.fxs_system_solve(self._h, ctx.handle, C.byref(o), C.byref(res)), "System::solve")
         self.last_result = {f[0]: getattr(res, f[0]) for f in FxResult._fields_}
 

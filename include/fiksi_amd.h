@@ -309,13 +309,13 @@ int fx_constraint_residuals(fx_ctx* ctx, const fx_batch* batch, double* r);
  * the builder; these four calls are everything numeric the arm does. */
 /* What assemble::solve does before any decomposer arm (assemble/mod.rs:58-124): out_vars = variables divided by the
  * System's scale, free variables of each component nudged by the LCG (perturb != 0); out_params = expression
- * parameters after Expression::transform (distances divided by the scale); out_scale[s] = the scale. Systems of up to
- * FX_MAX_SYSTEM_VARS variables. */
+ * parameters after Expression::transform (distances divided by the scale); out_scale[s] = the scale. */
 int fx_system_prepare_batch(fx_ctx* ctx, const fx_batch* batch, uint32_t perturb, double* out_vars, double* out_params,
                             double* out_scale);
 /* fx_lm_solve_batch for cluster problems: the batch may hold FX_POSE_COINCIDENCE_X / _Y rows. f64, Levenberg-Marquardt
- * (lm.rs:21-193, as the arm calls it, assemble/mod.rs:224-227), any fx_step_solver; each problem within the one-wavefront
- * limits (FX_MAX_FREE_VARS unknowns, FX_MAX_ROWS rows). */
+ * (lm.rs:21-193, as the arm calls it, assemble/mod.rs:224-227), any fx_step_solver. Problems within the one-wavefront
+ * limits (FX_MAX_FREE_VARS unknowns, FX_MAX_ROWS rows, FX_MAX_SYSTEM_VARS variables) run on the fused kernel, larger ones on
+ * the sparse path (where FX_STEP_QR means FX_STEP_CHOLESKY_REFINED, as everywhere). */
 int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
 /* Pose2D::transform_point (expressions.rs:1120-1134) in place on points (vars[var_idx[i]], vars[var_idx[i] + 1]) with
  * pose poses[3 * pose_of[i] ..] = (rotation, tx, ty): the points a moved cluster carries along (assemble/mod.rs:238-275). */

@@ -368,7 +368,8 @@ int fo_solve_recursive(uint32_t nvars, double* vars, const uint8_t* var_fixed, u
                        const uint32_t* el_idx, const uint16_t* el_comp, uint32_t ncon, const uint8_t* con_valency,
                        const uint32_t* con_expr, const uint8_t* con_ninc, const uint32_t* con_inc, const uint16_t* con_comp,
                        int perturb, int ordering, uint32_t trial_cap, uint64_t budget, uint32_t* plan_out, uint32_t plan_cap,
-                       uint32_t* plan_len, fo_result* step_results, uint32_t step_cap, uint32_t* n_steps, uint32_t* flags) {
+                       uint32_t* plan_len, fo_result* step_results, uint32_t step_cap, uint32_t* n_steps, uint32_t* flags,
+                       uint32_t* step_sizes /* 2 per step: unknowns, rows; may be NULL */) {
     GeoSystem g;
     g.variables.assign(vars, vars + nvars);
     g.fixed.assign(var_fixed, var_fixed + nvars);
@@ -420,6 +421,10 @@ int fo_solve_recursive(uint32_t nvars, double* vars, const uint8_t* var_fixed, u
             r.sse0 = c.sse_initial;
             r.sse = c.sse_final;
             step_results[ns] = r;
+            if (step_sizes) {
+                step_sizes[2 * ns] = st.sizes[ns].first;
+                step_sizes[2 * ns + 1] = st.sizes[ns].second;
+            }
         }
         ++ns;
     }

@@ -588,6 +588,7 @@ struct RecursiveStats {
     double scale = 0.;
     bool panicked = false, exhausted = false;
     std::vector<LmStats> steps;                 // one per solved step, components in order
+    std::vector<std::pair<uint32_t, uint32_t>> sizes;  // (unknowns, rows) of each step's cluster problem
     std::vector<std::vector<uint32_t>> plans;   // serialised plan per component
 };
 
@@ -667,6 +668,7 @@ inline RecursiveStats solve_recursive_assembly(GeoSystem& s, bool perturb, QrOrd
                     }
             }
             ClusteredProblem problem{cs};
+            out.sizes.emplace_back(problem.num_variables(), problem.num_residuals());
             out.steps.push_back(levenberg_marquardt(problem, x.data(), ordering, trial_cap));
 
             for (const auto& kv : cs.variable_mapping) {  // :228-236

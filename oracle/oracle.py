@@ -339,13 +339,14 @@ def eval_dense_batch(b):
     return r, out
 
 
-def solve_recursive(g, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, budget: int = 0):
+def solve_recursive(g, perturb: bool = True, ordering: str = "colamd", trial_cap: int = 0, budget: int = 0, sizes=None):
     """assemble::solve with Decomposer::RecursiveAssembly on ONE System (fo_recursive.hpp).
 
     ``g``: the System with its geometric graph — ``vars, var_fixed, expr_tag, expr_idx, expr_param`` (flat batch of one
     System), ``el_kind, el_idx, el_comp`` per element and ``con_valency, con_expr, con_ninc, con_inc, con_comp`` per
     constraint (``fiksi_amd.System.graph()`` produces it). Returns (solved variables, serialised plan words,
-    per-step results, flags: bit0 the reference would panic, bit1 search budget exhausted)."""
+    per-step results, flags: bit0 the reference would panic, bit1 search budget exhausted). ``sizes`` (optional list)
+    receives (unknowns, rows) of every step's cluster problem."""
     vars_out = np.ascontiguousarray(g["vars"], dtype=np.float64).copy()
     nv, ne = len(vars_out), len(g["expr_tag"])
     nel, ncon = len(g["el_kind"]), len(g["con_valency"])
@@ -353,6 +354,7 @@ def solve_recursive(g, perturb: bool = True, ordering: str = "colamd", trial_cap
     plan = np.zeros(cap, dtype=np.uint32)
     plan_len = C.c_uint32(0)
     steps = np.zeros(4096, dtype=RESULT_DTYPE)
+    step_sizes = np.zeros(2 * 4096, dtype=np.uint32)
     n_steps = C.c_uint32(0)
     flags = C.c_uint32(0)
     a = lambda k, dt: np.ascontiguousarray(g[k], dtype=dt)
@@ -363,8 +365,11 @@ def solve_recursive(g, perturb: bool = True, ordering: str = "colamd", trial_cap
                              C.c_uint32(nel), _p(keep[4]), _p(keep[5]), _p(keep[6]), C.c_uint32(ncon), _p(keep[7]), _p(keep[8]),
                              _p(keep[9]), _p(keep[10]), _p(keep[11]), C.c_int(1 if perturb else 0),
                              C.c_int(1 if ordering == "colamd" else 0), C.c_uint32(trial_cap), C.c_uint64(budget), _p(plan),
-                             C.c_uint32(cap), C.byref(plan_len), _p(steps), C.c_uint32(len(steps)), C.byref(n_steps), C.byref(flags))
+                             C.c_uint32(cap), C.byref(plan_len), _p(steps), C.c_uint32(len(steps)), C.byref(n_steps), C.byref(flags),
+                             _p(step_sizes))
     assert plan_len.value <= cap and n_steps.value <= len(steps)
+    if sizes is not None:
+        sizes.extend((int(step_sizes[2 * i]), int(step_sizes[2 * i + 1])) for i in range(n_steps.value))
     return vars_out, plan[: plan_len.value].copy(), steps[: n_steps.value].copy(), int(flags.value)
 
 

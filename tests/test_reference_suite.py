@@ -1,7 +1,7 @@
 """The reference's own end-to-end solver tests (fiksi/src/tests/{basic,triangles,singular,fixed,
 magnitude}.rs and the bench spot-check), written against the drop-in mirror API and run on the GPU:
 same sketches, same thresholds. Each test also solves the identical System with the CPU oracle and
-compares. Decomposer::SinglePass / RecursiveAssembly arms of those tests are out of scope."""
+compares. triangles.rs:10-14 runs its sketch under all three decomposers; so does test_single_triangle."""
 import math
 
 import numpy as np
@@ -143,8 +143,8 @@ def test_two_connected_components(F, oracle):  # basic.rs:152-170
 
 # ---- triangles.rs --------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass"])
-def test_single_triangle(F, oracle, decomposer):  # triangles.rs:9-37, both arms
+@pytest.mark.parametrize("decomposer", ["NONE", "SinglePass", "RecursiveAssembly"])
+def test_single_triangle(F, oracle, decomposer):  # triangles.rs:9-37, all three arms
     s = F.System()
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
@@ -163,8 +163,8 @@ def test_unimplemented_options_are_reported_unsupported(F):
     p0 = F.elements.Point.create(s, 0., 0.)
     p1 = F.elements.Point.create(s, 1., 0.5)
     F.constraints.PointPointDistance.create(s, p0, p1, 1.)
-    with pytest.raises(FiksiError) as e:
-        s.solve(F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly))
+    with pytest.raises(FiksiError) as e:  # RecursiveAssembly plans from elements: builder API only, not a flat batch
+        F.default_context().system_solve_batch(s.flatten(), F.abi.solving_opts(decomposer=2))
     assert e.value.code == -6
     with pytest.raises(FiksiError) as e:  # L-BFGS is f64 only
         F.default_context().system_solve_batch(s.flatten(), F.abi.solving_opts(optimizer=1, f32=True))
