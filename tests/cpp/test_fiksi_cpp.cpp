@@ -132,11 +132,26 @@ int main(int argc, char** argv) {
         CHECK(an.overconstrained.size() == 1 && an.overconstrained[0].tag == FXS_POINT_POINT_DISTANCE);
     }
 
-    // unsupported arms are errors, not silent fallbacks
+    // triangles.rs:10-37 runs its triangle under Decomposer::RecursiveAssembly too
+    {
+        System w;
+        auto q0 = elements::create_point(w, 0., 0.);
+        auto q1 = elements::create_point(w, 1., 0.5);
+        auto q2 = elements::create_point(w, 2., 1.);
+        constraints::create_point_point_distance(w, q0, q1, 1.);
+        constraints::create_point_point_distance(w, q0, q2, 1.);
+        constraints::create_point_point_distance(w, q1, q2, 1.);
+        SolvingOptions o;
+        o.decomposer = Decomposer::RecursiveAssembly;
+        w.solve(o);
+        CHECK(rms(w.constraint_residuals()) < RESIDUAL_THRESHOLD);
+    }
+
+    // unsupported options are errors, not silent fallbacks
     threw = false;
     try {
         SolvingOptions o;
-        o.decomposer = Decomposer::RecursiveAssembly;
+        o.decomposer = static_cast<Decomposer>(7);
         u.solve(o);
     } catch (const Error& e) {
         threw = e.code == FX_ERR_UNSUPPORTED;
