@@ -14,6 +14,10 @@
 // order here; that is one of the orders the reference can take. Everything that is ordered in the
 // reference (Vecs, the IndexMap of clusters, BTreeSets of a component) keeps its order.
 //
+// Pinned by the reference's Pose2D finite-difference test (expressions.rs:1470-1509) and by the threshold of its
+// triangle test (tests/triangles.rs:10-37), both in tests/test_recursive_assembly.py. PLAN PARITY UNPINNED: the
+// reference holds no known-answer vector for a plan (its plans are not reproducible between two of its own runs).
+//
 // Where the reference would panic (an `unwrap` on bookkeeping that is not there) `panicked` is set
 // and the plan ends; where its exhaustive search would not finish, `exhausted` is set.
 #pragma once
