@@ -1,5 +1,5 @@
-"""The library's host-side logic (batch analysis, Jacobian structure, SinglePass decomposition, QR planning with its
-COLAMD, the System builder — ~3 000 lines of index arithmetic) under AddressSanitizer + UndefinedBehaviorSanitizer:
+"""The library's host-side logic (batch analysis, Jacobian structure, SinglePass decomposition, the RecursiveAssembly
+plan, QR planning with its COLAMD, the System builder — ~3 000 lines of index arithmetic) under AddressSanitizer + UndefinedBehaviorSanitizer:
 `make -C fiksi_amd/csrc asan` compiles fx_abi.cpp / fx_builder.cpp with g++ against stubs of the HIP runtime
 (fx_hip_shim.h: every device entry point answers FX_ERR_NO_DEVICE), and the CPU tests of those parts run against that
 library in a child process with the sanitizer runtimes preloaded. GPU AddressSanitizer is not available on the pool;
@@ -27,7 +27,8 @@ def test_host_logic_under_asan_and_ubsan():
         pre.append(path)
     env = dict(os.environ, LD_PRELOAD=" ".join(pre), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
                FIKSI_AMD_LIBRARY=lib, FIKSI_AMD_HIP_RUNTIME="system")
-    tests = ["tests/test_host.py", "tests/test_single_pass.py", "tests/test_qr_plan.py", "tests/test_reference_suite.py"]
+    tests = ["tests/test_host.py", "tests/test_single_pass.py", "tests/test_qr_plan.py", "tests/test_recursive_assembly.py",
+             "tests/test_reference_suite.py"]
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + tests, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=1500)
     out = p.stdout + p.stderr
