@@ -203,6 +203,10 @@ class Context:
         """Most-work-first hand-out of big batches from a scout pass (fx_ctx_set_presort); results unchanged."""
         check(lib.fx_ctx_set_presort(self._h, 1 if enable else 0, min_systems), "fx_ctx_set_presort")
 
+    def set_hold_passes(self, passes: int = 2):
+        """Grouped kernel: passes a finished row waits for a second one (fx_ctx_set_hold_passes); results unchanged."""
+        check(lib.fx_ctx_set_hold_passes(self._h, passes), "fx_ctx_set_hold_passes")
+
     def synchronize(self):
         check(lib.fx_ctx_synchronize(self._h), "fx_ctx_synchronize")
 

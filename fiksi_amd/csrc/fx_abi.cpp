@@ -535,10 +535,12 @@ struct fx_ctx {
     int route_grouped = -1;
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
+    uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
     uint32_t presort_min_systems = 8192u;
     void route(fx::LmParams& p) const {
         p.route_grouped = route_grouped;
         p.grouped_min_systems = grouped_min_systems;
+        p.hold_passes = hold_passes;
     }
     static constexpr size_t MAX_CACHED_BYTES = size_t(4) << 30;  // beyond this, released blocks go back to the driver
 
@@ -1382,6 +1384,12 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
     if (grouped < -1 || grouped > 1) return fail(FX_ERR_INVALID, "grouped must be -1 (by batch size), 0 or 1");
     ctx->route_grouped = grouped;
     if (grouped_min_systems) ctx->grouped_min_systems = grouped_min_systems;
+    return FX_OK;
+}
+
+int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    ctx->hold_passes = passes;
     return FX_OK;
 }
 

@@ -132,6 +132,7 @@ struct LmParams {
     // 1 = whenever the batch qualifies; the size from which a batch takes it
     int route_grouped = -1;
     uint32_t grouped_min_systems = 1024u;
+    uint32_t hold_passes = 2u;  // grouped kernel: passes a finished row waits for a second one before its set-up blocks (fx_ctx_set_hold_passes)
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

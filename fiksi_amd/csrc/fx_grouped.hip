@@ -356,6 +356,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     double lambda = 0.0;
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
     bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
+    uint32_t held = 0;   // passes this row has waited, done, for company (see FINISH)
     // The product list of a component does not change between its assemblies: the 32-column f64 build (one wavefront
     // per SIMD, registers to spare) keeps each lane's first PWR / PER list words in registers, which takes the list
     // read — one of three dependent LDS round trips per batch of products — out of every assembly.
@@ -1044,8 +1045,24 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
         }
 
+        // A row that is done waits up to prm.hold_passes passes for a second row of the wavefront to get done, so that the
+        // two go through FINISH / CLOSE / NEXT / COMP side by side: those blocks cost the wavefront the same whether one
+        // row or four execute them, and a row alone in them stalls the other three (scheduling).
+        bool finish_now = phase == GP_FINISH;
+        if (!UNITS && prm.hold_passes) {
+            const int n_done = __popcll(__ballot(phase == GP_FINISH)) / RS;
+            const bool any_running = __ballot(phase == GP_RUN) != 0ull;
+            if (phase == GP_FINISH) {
+                if (n_done >= 2 || !any_running || held >= prm.hold_passes) {
+                    held = 0;
+                } else {
+                    held += 1;
+                    finish_now = false;
+                }
+            }
+        }
         // ================= FINISH: K6 write back scale * x for the free variables (assemble/mod.rs:161-166) ===
-        if (phase == GP_FINISH) {
+        if (finish_now) {
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 if ((uint32_t)(hl + RS * q) < nfree) {

@@ -373,3 +373,25 @@ def test_presort_changes_the_order_not_the_results(fiksi, ctx):
                 ctx.set_presort(True, 8192)
         assert np.array_equal(_bits(out[0][0]), _bits(out[1][0]))
         assert out[0][1].tobytes() == out[1][1].tobytes()
+
+
+def test_holding_a_finished_row_changes_the_order_not_the_results(fiksi, ctx):
+    """fx_ctx_set_hold_passes: a row that is done waits a few passes for a second one before the hand-over blocks;
+    every System's result is the same bits with 0, 2 and 5 passes (uniform, mixed and multi-component batches, f32)."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import random_sketch
+
+    mixed = workloads.concat([workloads.ring16(3000), workloads.concat([random_sketch(s).flatten() for s in range(300)]),
+                              workloads.hinged_triangles(2000, 4)])
+    for b, kw in ((workloads.ring16(12000), {}), (workloads.ring16(9000, inconsistent=True), {"f32": True}), (mixed, {})):
+        out = []
+        for passes in (0, 2, 5):
+            ctx.set_hold_passes(passes)
+            try:
+                out.append(ctx.system_solve_batch(b, abi.solving_opts(**kw)))
+            finally:
+                ctx.set_hold_passes(2)
+        for other in out[1:]:
+            assert np.array_equal(_bits(out[0][0]), _bits(other[0]))
+            assert out[0][1].tobytes() == other[1].tobytes()
