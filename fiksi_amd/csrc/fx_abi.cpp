@@ -536,6 +536,18 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
+    // Page-locked staging for small one-shot solves (System::solve on one sketch): first half carries the packed upload,
+    // second half the read-back — both copies are then truly asynchronous and the call waits on the stream once.
+    unsigned char* pinned = nullptr;
+    static constexpr size_t PINNED_HALF = size_t(128) << 10;
+    bool pinned_busy = false;  // an upload from the first half may still be in flight
+    bool ensure_pinned() {
+        if (pinned) return true;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 2 * PINNED_HALF, 0) != hipSuccess) return false;
+        pinned = static_cast<unsigned char*>(p);
+        return true;
+    }
     uint32_t presort_min_systems = 8192u;
     void route(fx::LmParams& p) const {
         p.route_grouped = route_grouped;
@@ -603,6 +615,9 @@ struct fx_dbatch {
     uint32_t* ps_ids = nullptr;
     unsigned char* ps_temp = nullptr;
     size_t ps_temp_bytes = 0;
+    unsigned char* packed_base = nullptr;  // small batches: the one block all arrays live in
+    size_t packed_bytes = 0;
+    bool upload_pending = false;           // ... and its copy from the context's page-locked staging was not waited for
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -1286,6 +1301,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     // idle, so a few host threads, each with its own stream, run them side by side (Systems are
     // independent; every result depends only on its own System, so the schedule does not show).
     const uint32_t nt = (uint32_t)std::min<size_t>(todo.size(), 8);
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // the workers use their own streams: everything queued on ours (upload, kernels) first
     std::atomic<uint32_t> next{0};
     std::vector<hipError_t> err(nt, hipSuccess);
     std::vector<uint32_t> err_sys(nt, 0);
@@ -1376,6 +1392,7 @@ void fx_ctx_destroy(fx_ctx* ctx) {
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     ctx->drop_cache();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 
@@ -1535,18 +1552,33 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
             return fail(e1 == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", packed, hipGetErrorString(e1));
         }
         db->allocations.push_back({base, packed});
-        stage.assign(packed, 0);
+        db->packed_base = base;
+        db->packed_bytes = packed;
+        unsigned char* st = nullptr;
+        if (packed <= fx_ctx::PINNED_HALF && ctx->ensure_pinned()) {
+            if (ctx->pinned_busy) {  // an earlier upload may still be reading the staging area
+                (void)hipStreamSynchronize(ctx->stream);
+                ctx->pinned_busy = false;
+            }
+            st = ctx->pinned;
+            memset(st, 0, packed);
+            db->upload_pending = true;
+        } else {
+            stage.assign(packed, 0);
+            st = stage.data();
+        }
         size_t at = 0;
         for (const Req& r : reqs) {
-            if (r.src && r.bytes) memcpy(stage.data() + at, r.src, r.bytes);
+            if (r.src && r.bytes) memcpy(st + at, r.src, r.bytes);
             *r.dst = base + at;
             at += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
         }
-        e1 = hipMemcpyAsync(base, stage.data(), packed, hipMemcpyHostToDevice, ctx->stream);
+        e1 = hipMemcpyAsync(base, st, packed, hipMemcpyHostToDevice, ctx->stream);
         if (e1 != hipSuccess) {
             fx_batch_free(ctx, db);
             return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e1));
         }
+        if (db->upload_pending) ctx->pinned_busy = true;
     } else {
         for (const Req& r : reqs) {
             unsigned char* dptr = nullptr;
@@ -1566,11 +1598,14 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     // evaluation entry points: they are built on first use (ensure_csr / ensure_resid), so a plain
     // solve neither computes nor uploads them.
 #undef FX_UP
-    // the host plan lives on this stack frame: finish the copies before returning
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        fx_batch_free(ctx, db);
-        return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    // the host plan lives on this stack frame: finish the copies before returning (a small batch went through the
+    // context's page-locked staging area, which outlives the call: its copy is left in flight)
+    if (!db->upload_pending) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            fx_batch_free(ctx, db);
+            return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+        }
     }
     if (p.n_large) {
         const uint32_t nv = p.n_vars, ne = p.n_exprs, n = p.n_systems;
@@ -1605,11 +1640,12 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     return FX_OK;
 }
 
-void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) {
+static void free_batch(fx_ctx* ctx, fx_dbatch* db, bool stream_idle) {
     if (!db) return;
-    if (ctx) {
+    if (ctx && !stream_idle) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        ctx->pinned_busy = false;
     }
     for (auto& kv : db->sparse_plans) fx::sparse_cache_free(kv.second);
     for (auto& blk : db->allocations) {
@@ -1618,6 +1654,8 @@ void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) {
     }
     delete db;
 }
+
+void fx_batch_free(fx_ctx* ctx, fx_dbatch* db) { free_batch(ctx, db, false); }
 
 int fx_batch_set_vars(fx_ctx* ctx, fx_dbatch* db, const double* vars) {
     int rc = bind(ctx);
@@ -1855,6 +1893,28 @@ static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts*
     if (rc) return rc;
     db->resident = false;  // solved once and freed: no point in keeping plans
     rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
+    // a small batch sits in one block: solved variables and results come back in ONE copy through the page-locked
+    // staging area, and the call waits on the stream once
+    if (!rc && batch->n_systems && db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
+        const unsigned char* lo = reinterpret_cast<const unsigned char*>(db->d.vars);
+        const unsigned char* hi = reinterpret_cast<const unsigned char*>(db->d.results + db->d.n_systems);
+        if (lo >= db->packed_base && hi <= db->packed_base + db->packed_bytes && lo < hi) {
+            unsigned char* back = ctx->pinned + fx_ctx::PINNED_HALF;
+            auto run = [&]() -> int {
+                FX_HIP(hipMemcpyAsync(back, lo, (size_t)(hi - lo), hipMemcpyDeviceToHost, ctx->stream));
+                FX_HIP(hipStreamSynchronize(ctx->stream));
+                return FX_OK;
+            };
+            rc = run();
+            ctx->pinned_busy = false;
+            if (!rc) {
+                memcpy(batch->vars, back, (size_t)db->d.n_vars * sizeof(double));
+                if (results) memcpy(results, back + (reinterpret_cast<const unsigned char*>(db->d.results) - lo), (size_t)db->d.n_systems * sizeof(fx_result));
+            }
+            free_batch(ctx, db, /*stream_idle=*/rc == FX_OK);
+            return rc;
+        }
+    }
     if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
     if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);
     fx_batch_free(ctx, db);

@@ -27,6 +27,8 @@ inline hipError_t hipSetDevice(int) { return hipErrorNoDevice; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t*, int) { return hipErrorNoDevice; }
 inline hipError_t hipMalloc(void** p, size_t) { *p = nullptr; return hipErrorNoDevice; }
 inline hipError_t hipFree(void*) { return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t, unsigned) { *p = nullptr; return hipErrorNoDevice; }
+inline hipError_t hipHostFree(void*) { return hipSuccess; }
 inline hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind) { return hipErrorNoDevice; }
 inline hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t) { return hipErrorNoDevice; }
 inline hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t) { return hipErrorNoDevice; }
