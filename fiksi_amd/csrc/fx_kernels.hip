@@ -12,6 +12,7 @@
 // Compiled with -ffp-contract=off: products and sums stay separate exactly as in the reference;
 // fused multiply-adds are written explicitly (fma) where the algorithm is ours (Cholesky).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 #include "fx_device.h"
@@ -1449,8 +1450,17 @@ static hipError_t launch_solve_n(const DeviceBatch& b, const LmParams& p, const 
     if constexpr (QR && N <= 32) fn = &lm_solve_qr_kernel_w2<N, PROF, UNITS>;
     else if constexpr (QR) fn = &lm_solve_qr_kernel<N, PROF, UNITS>;
     else fn = &lm_solve_kernel<N, T, PROF, UNITS, OPT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
-    if (e != hipSuccess) return e;
+    // the attribute is raised once per instantiation and device (a call per launch costs a single small solve a few
+    // microseconds of its ~50): 160 KB is what any layout may ask for
+    static std::atomic<uint32_t> raised_on{0};  // bit d: done on device d
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (!(raised_on.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised_on.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL(fn, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
 }
