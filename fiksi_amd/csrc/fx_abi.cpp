@@ -1240,9 +1240,11 @@ int ensure_component_walk(fx_ctx* ctx, fx_dbatch* db) {
 }
 
 // Systems beyond the one-wavefront limits: host-driven LM with device numerics (fx_sparse.hip).
-// the wide kernel covers f64 Levenberg-Marquardt without a decomposer
+// the wide kernel covers Levenberg-Marquardt without a decomposer. Every path for Systems beyond the one-wavefront
+// limits computes in f64 (the sparse path always did): a request for f32 compute keeps its options (ftol, max_outer)
+// and gets the f64 device kernels here rather than the host-driven loop.
 bool wide_kernel_applies(const fx::LmParams& p) {
-    return !(p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS)) && p.lm.precision != 32;
+    return !(p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS));
 }
 
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
@@ -1253,7 +1255,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         hipError_t e = fx::launch_solve_wide(db->d, p, ctx->stream);
         if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
     }
-    const bool device_units = (p.mode & fx::MODE_UNITS) && p.lm.precision != 32 && !(p.mode & fx::MODE_LBFGS);
+    const bool device_units = (p.mode & fx::MODE_UNITS) && !(p.mode & fx::MODE_LBFGS);
     // Decomposer::None, f64 LM: large Systems made of small components are walked on the device
     const bool comp_walk = !pose && wide_kernel_applies(p);
     if (comp_walk) {

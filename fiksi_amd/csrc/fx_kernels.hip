@@ -1542,7 +1542,11 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
         return units ? launch_solve_t<double, true, 1>(b, p, stream) : launch_solve_t<double, false, 1>(b, p, stream);
     }
     if (units) {
-        if (p.lm.precision == 32) return grouped_applies(b, p) ? launch_solve_grouped(b, p, stream) : launch_solve_t<float, true, 0>(b, p, stream);
+        if (p.lm.precision == 32) {
+            hipError_t e = grouped_applies(b, p) ? launch_solve_grouped(b, p, stream) : launch_solve_t<float, true, 0>(b, p, stream);
+            if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);  // Systems beyond one wavefront: the f64 walker
+            return e;
+        }
         hipError_t e = grouped_applies(b, p) ? launch_solve_grouped(b, p, stream) : launch_solve_t<double, true, 0>(b, p, stream);
         if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);
         return e;

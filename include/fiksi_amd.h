@@ -154,7 +154,9 @@ typedef struct fx_lm_opts {
     uint32_t max_trials;  /* 4096    (reference: unbounded) total LM trials    */
     uint32_t solver;      /* fx_step_solver                                                     */
     uint32_t precision;   /* 0 or 64: f64 (the reference's arithmetic); 32: f32 compute (cfg5) —
-                             HBM arrays stay f64, scale + perturbation stay f64                    */
+                             HBM arrays stay f64, scale + perturbation stay f64. Applies to Systems
+                             within the one-wavefront limits; larger ones are computed in f64 on
+                             their own device paths with the same options                         */
 } fx_lm_opts;
 
 /* SolvingOptions (fiksi/src/lib.rs:205-237). optimizer: 0 = LevenbergMarquardt, 1 = LBfgs

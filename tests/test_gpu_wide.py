@@ -107,3 +107,26 @@ def test_wide_kernel_l2_entry_point_and_limits(fiksi, oracle, ctx):
     v2_o, res2_o = oracle.solve_batch(big, mode=3)
     assert res2["accepted"][0] == res2_o["accepted"][0]
     assert np.max(np.abs(v2 - v2_o)) < 1e-7
+
+
+def test_f32_requests_on_medium_and_large_systems_take_the_f64_device_kernels(fiksi, ctx):
+    """Every path beyond the one-wavefront limits computes in f64. A request for f32 compute (`precision = 32`, with its
+    ftol / max_outer) therefore gives, on Systems of 65 ... 128 free variables (wide kernel) and on large Systems cut into
+    small blocks by SinglePass (the walker), exactly the bits of the same options with `precision = 64` — and no longer
+    goes through the host-driven loop of the sparse path (20 000 sketches of 66 variables: seconds -> milliseconds)."""
+    import time
+
+    from fiksi_amd import abi, workloads
+
+    b = workloads.hinged_triangles(400, 16)  # 66 variables each
+    for decomposer in (0, 1):
+        o32 = abi.solving_opts(f32=True, decomposer=decomposer)
+        o64 = abi.solving_opts(f32=True, decomposer=decomposer)
+        o64.lm.precision = 64
+        t0 = time.perf_counter()
+        v32, r32 = ctx.system_solve_batch(b, o32)
+        dt = time.perf_counter() - t0
+        v64, r64 = ctx.system_solve_batch(b, o64)
+        assert np.array_equal(v32.view(np.uint64), v64.view(np.uint64)) and r32.tobytes() == r64.tobytes()
+        assert np.all(r32["sse_unscaled"] < 1e-4)
+        assert dt < 0.5, dt  # the host-driven path took ~1 ms per System
