@@ -1534,11 +1534,6 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
             if (er == hipSuccess) er = hipStreamSynchronize(stream);
             return er;
         };
-        auto form = [&](int buf) {
-            if (P.nnz_a) hipLaunchKernelGGL(sp_form_a_kernel, grid_for(P.nnz_a), dim3(256), 0, stream, d_apair_ptr, d_apairs, d_j[buf], P.nnz_a, d_a);
-            if (nv) hipLaunchKernelGGL(sp_rhs_kernel<true>, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf], d_r[buf], nv, d_rhs);
-        };
-
         int cur = 0;
         double sse = 0.0;
         e = eval(0, true, &sse);
