@@ -27,6 +27,8 @@ python3 tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/${TAG}_pmc_sq.json 100000 > /de
 echo "[collect] cfg2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg2 -- python3 tools/cfg2.py 5000 > $OUT/cfg2.log 2>&1
 cp $(find $OUT/cfg2 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_cfg2_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/cfg2_sq -- python3 tools/cfg2.py 5000 > $OUT/cfg2_sq.log 2>&1
+python3 tools/pmc_sq_summary.py $OUT/cfg2_sq $OUT/${TAG}_cfg2_pmc_sq.json 1 "tools/cfg2.py 5000" > /dev/null
 echo "[collect] plain bench line"
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 tail -c 400 $OUT/${TAG}_bench.json
