@@ -83,7 +83,7 @@ class FxLmOpts(C.Structure):
 
 class FxSolvingOpts(C.Structure):
     _fields_ = [
-        ("optimizer", C.c_uint32), ("decomposer", C.c_uint32), ("perturb", C.c_uint32), ("reserved", C.c_uint32),
+        ("optimizer", C.c_uint32), ("decomposer", C.c_uint32), ("perturb", C.c_uint32), ("plan_budget", C.c_uint32),
         ("lm", FxLmOpts),
     ]
 

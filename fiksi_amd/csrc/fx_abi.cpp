@@ -1466,7 +1466,7 @@ void fx_solving_opts_default(fx_solving_opts* o) {
     o->optimizer = 0;
     o->decomposer = 0;
     o->perturb = 1;
-    o->reserved = 0;
+    o->plan_budget = 0;
     fx_lm_opts_default(&o->lm);
 }
 

@@ -533,7 +533,7 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
     for (const Component* comp : live) {
         std::vector<uint32_t> els(comp->elements.begin(), comp->elements.end());
         std::vector<uint32_t> cons(comp->constraints.begin(), comp->constraints.end());
-        const fx::ra::Plan plan = fx::ra::make_plan(graph, els, cons, kDefaultPlanBudget);
+        const fx::ra::Plan plan = fx::ra::make_plan(graph, els, cons, o.plan_budget ? (uint64_t)o.plan_budget * 1000u : kDefaultPlanBudget);
         if (plan.panicked || plan.exhausted) return FX_ERR_UNSUPPORTED;
 
         for (const fx::ra::Step& step : plan.steps) {

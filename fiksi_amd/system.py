@@ -39,11 +39,13 @@ class SolvingOptions:  # lib.rs:205-237
     optimizer: Optimizer = Optimizer.LevenbergMarquardt
     decomposer: Decomposer = Decomposer.NONE
     perturb: bool = True
+    plan_budget: int = 0  # not in the reference: thousands of subgraphs RecursiveAssembly's plan search may grow (0 = default)
 
     def _to_abi(self):
         o = abi.solving_opts(perturb=self.perturb)
         o.optimizer = self.optimizer.value
         o.decomposer = self.decomposer.value
+        o.plan_budget = self.plan_budget
         return o
 
 

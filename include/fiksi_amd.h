@@ -169,7 +169,8 @@ typedef struct fx_solving_opts {
     uint32_t optimizer;
     uint32_t decomposer;
     uint32_t perturb;  /* 1 = LCG perturbation, seed 42 (assemble/mod.rs:47,113-124) */
-    uint32_t reserved;
+    uint32_t plan_budget; /* RecursiveAssembly only: subgraphs its plan search may grow, in thousands (0 = 200, the
+                             default; the reference's search is unbounded). Otherwise ignored — leave it 0.   */
     fx_lm_opts lm;
 } fx_solving_opts;
 

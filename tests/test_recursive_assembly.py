@@ -243,3 +243,68 @@ def test_pose_transform_and_prepare_match_oracle(fiksi, ctx, oracle):
     v3, r3 = ctx.system_solve_batch(b)
     assert np.array_equal(r2["accepted"], r3["accepted"]) and np.array_equal(r2["trials"], r3["trials"])
     assert np.array_equal(r2["sse0"], r3["sse0"]) and np.array_equal(r2["sse"], r3["sse"])
+
+
+@pytest.mark.gpu
+def test_device_arm_edge_cases(fiksi, ctx, oracle):
+    """Empty System, elements without constraints, two components, fixed elements (the arm does not know them, as in the
+    reference), a sketch the reference would panic on, and a plan search cut short by its budget."""
+    from fiksi_amd._lib import FiksiError
+
+    F = fiksi
+    RA = F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly)
+    s = F.System()
+    s.solve(RA, ctx)  # nothing to do
+    assert s.last_result["ncomp"] == 0
+    P, D = F.elements.Point.create, F.constraints.PointPointDistance.create
+    s = F.System(); a = P(s, 0.25, 0.5); b = P(s, 1.5, 2.5)
+    s.solve(RA, ctx)  # no constraint: no component, variables keep their bits
+    assert a.get_value(s) == (0.25, 0.5) and b.get_value(s) == (1.5, 2.5) and s.last_result["ncomp"] == 0
+
+    # two components (two triangles far apart) + an unconstrained point
+    s = F.System()
+    pts = [P(s, 0, 0), P(s, 1, .5), P(s, 2, 1), P(s, 10, 10), P(s, 11, 10.5), P(s, 12, 11), P(s, -5., 7.)]
+    for o in (0, 3):
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            D(s, pts[o + i], pts[o + j], 1.)
+    g = s.graph()
+    v_o, plan, steps, fl = oracle.solve_recursive(g, trial_cap=TRIAL_CAP, budget=BUDGET)
+    s.solve(RA, ctx, solver=2)
+    assert fl == 0 and s.last_result["ncomp"] == len(steps) == 6
+    assert np.max(np.abs(s.flatten()["vars"] - v_o)) < 1e-12
+    assert pts[6].get_value(s) == (-5., 7.)
+    assert rms(s.constraint_residuals(ctx)) < RESIDUAL_THRESHOLD
+
+    # a fixed point is just another unknown to this arm (assemble/mod.rs:434-474 maps every variable of a step)
+    s = F.System(); p = [P(s, 0., 0.), P(s, 1., .5), P(s, 2., 1.)]
+    p[1].fix(s)
+    for i, j in ((0, 1), (0, 2), (1, 2)):
+        D(s, p[i], p[j], 1.)
+    v_o, plan, steps, fl = oracle.solve_recursive(s.graph(), trial_cap=TRIAL_CAP, budget=BUDGET)
+    s.solve(RA, ctx, solver=2)
+    assert np.max(np.abs(s.flatten()["vars"] - v_o)) < 1e-12
+    assert p[1].get_value(s) != (1., .5)  # moved, as in the reference's arm
+
+    # a closed ring of six points with chords: the reference's bookkeeping panics on it (`flags` bit 0)
+    import math
+    s = F.System(); n = 6
+    q = [P(s, math.cos(2 * math.pi * i / n) + 0.01 * i, math.sin(2 * math.pi * i / n)) for i in range(n)]
+    for i in range(n):
+        D(s, q[i], q[(i + 1) % n], 1.)
+    for i in range(0, n, 2):
+        D(s, q[i], q[(i + 2) % n], 1.7)
+    before = s.flatten()["vars"].copy()
+    assert s.recursive_plan()[1] & 1
+    with pytest.raises(FiksiError) as e:
+        s.solve(RA, ctx)
+    assert e.value.code == -6 and np.array_equal(s.flatten()["vars"], before)
+
+    # budget: a sketch whose plan needs more grown subgraphs than allowed is refused, and solved when allowed
+    seed = next(k for k in range(200) if random_sketch(k).recursive_plan(2000)[1] == 2 and random_sketch(k).recursive_plan(0)[1] == 0)
+    s = random_sketch(seed)
+    before = s.flatten()["vars"].copy()
+    with pytest.raises(FiksiError) as e:
+        s.solve(F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly, plan_budget=2), ctx)
+    assert e.value.code == -6 and np.array_equal(s.flatten()["vars"], before)
+    s.solve(RA, ctx)
+    assert s.last_result["ncomp"] > 0
