@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (nb == 0u) break;
                 load_block(a, base, nb);
                 __syncthreads();
-                ok = chol_factor<64, double>(a, invd, lane) && ok;
+                ok = chol_factor<64, double>(a, invd, lane, (int)nb) && ok;  // the padding of a short second block is skipped
                 // row `lane` of L and d back into the triangle
                 if ((uint32_t)lane < nb) {
                     const uint32_t c = base + (uint32_t)lane;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     for (uint32_t k = 0; k < 64u; ++k) t = fma(-Lm[rb + k], DEL[k], t);
                 }
                 reload_factor(a, invd, 64u, n2);
-                const double x2 = chol_solve<64, double>(a, invd, t, lane);
+                const double x2 = chol_solve<64, double>(a, invd, t, lane, (int)n2);
                 __syncthreads();
                 if ((uint32_t)lane < n2) DEL[64 + lane] = x2;
                 __syncthreads();
