@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="the headline + roofline only (no side workloads)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="systems in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host threads of the sparse path for batches of several large Systems (0 = library default 8; the "
+                         "profiled runs of tools/collect_profiles.sh use 1: rocprofv3 --kernel-trace crashes under concurrent launches)")
     return ap.parse_args()
 
 
@@ -130,6 +133,8 @@ def main() -> int:
         n_sys = args.systems
         batch = workloads.ring16(n_sys, seed0=distributed.rank_seed(1000, rank, n_sys))
     ctx = fiksi_amd.Context(local_rank)
+    if args.host_threads:
+        ctx.set_host_threads(args.host_threads)
     db = ctx.upload(batch)
     opts = abi.solving_opts()  # SolvingOptions::DEFAULT + the reference LM constants
 

@@ -536,6 +536,7 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
+    uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: workers of the sparse path when a batch holds several large Systems
     // Page-locked staging for small one-shot solves (System::solve on one sketch): first half carries the packed upload,
     // second half the read-back — both copies are then truly asynchronous and the call waits on the stream once.
     unsigned char* pinned = nullptr;
@@ -1292,7 +1293,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         return e;
     };
-    if (todo.size() <= 1) {
+    if (todo.size() <= 1 || ctx->host_threads <= 1u) {
         for (size_t k = 0; k < todo.size(); ++k) {
             hipError_t e = solve_one(todo[k], ctx->stream, plans[k]);
             if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", todo[k], hipGetErrorString(e));
@@ -1302,7 +1303,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     // Several large Systems: each one is a host-driven loop of small launches that leaves the GPU mostly
     // idle, so a few host threads, each with its own stream, run them side by side (Systems are
     // independent; every result depends only on its own System, so the schedule does not show).
-    const uint32_t nt = (uint32_t)std::min<size_t>(todo.size(), 8);
+    const uint32_t nt = (uint32_t)std::min<size_t>(todo.size(), std::max(1u, ctx->host_threads));
     FX_HIP(hipStreamSynchronize(ctx->stream));  // the workers use their own streams: everything queued on ours (upload, kernels) first
     std::atomic<uint32_t> next{0};
     std::vector<hipError_t> err(nt, hipSuccess);
@@ -1409,6 +1410,12 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes) {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
     ctx->hold_passes = passes;
+    return FX_OK;
+}
+
+int fx_ctx_set_host_threads(fx_ctx* ctx, uint32_t threads) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    ctx->host_threads = threads ? std::min(threads, 64u) : 8u;
     return FX_OK;
 }
 

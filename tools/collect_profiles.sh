@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 echo "[collect] bench under rocprofv3 --stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --host-threads 1 > $OUT/bench_under_rocprof.log 2>&1
 cp $(find $OUT/bench -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_bench_kernel_stats.csv
 echo "[collect] HBM counters, 100k and 500k Systems"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/solve_once.py 100000 2 > $OUT/pmc_fetch.log 2>&1
