@@ -50,17 +50,19 @@ __device__ __forceinline__ T chol_solve(const T (&a)[N], T invd, T rhs, int lane
     T acc = rhs;
 #pragma unroll
     for (int k = 0; k < N; ++k) {  // forward: L y = b, y_k = acc_k / d_k
-        if (k >= nb) break;
-        T yk = bcast(acc * invd, k);
-        if (lane > k) acc = fma(-a[k], yk, acc);
+        if (k < nb) {
+            T yk = bcast(acc * invd, k);
+            if (lane > k) acc = fma(-a[k], yk, acc);
+        }
     }
     // acc_k = y_k d_k. backward: x_k = (y_k d_k - sum_{i>k} (L_ik d_k) x_i) / d_k^2
     T invd2 = invd * invd;
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        if (i >= nb) continue;
-        T xi = bcast(acc * invd2, i);
-        if (lane < i) acc = fma(-a[i], xi, acc);
+        if (i < nb) {
+            T xi = bcast(acc * invd2, i);
+            if (lane < i) acc = fma(-a[i], xi, acc);
+        }
     }
     return acc * invd2;
 }
@@ -72,9 +74,10 @@ __device__ __forceinline__ T chol_forward(const T (&a)[N], T invd, T rhs, int la
     T acc = rhs;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        if (k >= nb) break;
-        T yk = bcast(acc * invd, k);
-        if (lane > k) acc = fma(-a[k], yk, acc);
+        if (k < nb) {
+            T yk = bcast(acc * invd, k);
+            if (lane > k) acc = fma(-a[k], yk, acc);
+        }
     }
     return acc * invd;
 }
@@ -85,9 +88,10 @@ __device__ __forceinline__ T chol_backward(const T (&a)[N], T invd, T y, int lan
     T invd2 = invd * invd;
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
-        if (i >= nb) continue;
-        T xi = bcast(acc * invd2, i);
-        if (lane < i) acc = fma(-a[i], xi, acc);
+        if (i < nb) {
+            T xi = bcast(acc * invd2, i);
+            if (lane < i) acc = fma(-a[i], xi, acc);
+        }
     }
     return acc * invd2;
 }
