@@ -1047,9 +1047,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 
         // A row that is done waits up to prm.hold_passes passes for a second row of the wavefront to get done, so that the
         // two go through FINISH / CLOSE / NEXT / COMP side by side: those blocks cost the wavefront the same whether one
-        // row or four execute them, and a row alone in them stalls the other three (scheduling).
+        // row or four execute them, and a row alone in them stalls the other three (scheduling). SinglePass
+        // blocks wait the same way (a block's FINISH / COMP are the hand-over there).
         bool finish_now = phase == GP_FINISH;
-        if (!UNITS && prm.hold_passes) {
+        if (prm.hold_passes) {
             const int n_done = __popcll(__ballot(phase == GP_FINISH)) / RS;
             const bool any_running = __ballot(phase == GP_RUN) != 0ull;
             if (phase == GP_FINISH) {

@@ -219,7 +219,7 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);
  * as its slowest System plus the time before that System was started (~0.1 ms per 100 000 Systems; enable = 0 turns it
  * off). Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
-/* Grouped kernel: a row of a wavefront that has finished its System waits up to `passes` trial passes (default 2) for a
+/* Grouped kernel: a row of a wavefront that has finished its System (SinglePass: its block) waits up to `passes` trial passes (default 2) for a
  * second row to finish, so that the two take their next Systems side by side — the hand-over blocks cost the wavefront
  * the same for one row as for four. 0: never wait. Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);

@@ -377,14 +377,16 @@ def test_presort_changes_the_order_not_the_results(fiksi, ctx):
 
 def test_holding_a_finished_row_changes_the_order_not_the_results(fiksi, ctx):
     """fx_ctx_set_hold_passes: a row that is done waits a few passes for a second one before the hand-over blocks;
-    every System's result is the same bits with 0, 2 and 5 passes (uniform, mixed and multi-component batches, f32)."""
+    every System's result is the same bits with 0, 2 and 5 passes (uniform, mixed and multi-component batches, f32,
+    SinglePass blocks)."""
     from fiksi_amd import abi, workloads
 
     from helpers import random_sketch
 
     mixed = workloads.concat([workloads.ring16(3000), workloads.concat([random_sketch(s).flatten() for s in range(300)]),
                               workloads.hinged_triangles(2000, 4)])
-    for b, kw in ((workloads.ring16(12000), {}), (workloads.ring16(9000, inconsistent=True), {"f32": True}), (mixed, {})):
+    for b, kw in ((workloads.ring16(12000), {}), (workloads.ring16(9000, inconsistent=True), {"f32": True}), (mixed, {}),
+                  (workloads.hinged_triangles(6000, 11), {"decomposer": 1}), (workloads.ring16(6000), {"decomposer": 1})):
         out = []
         for passes in (0, 2, 5):
             ctx.set_hold_passes(passes)
