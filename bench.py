@@ -258,6 +258,7 @@ def main() -> int:
             out["other_workloads"] = other_workloads(ctx, abi, workloads, np, n_sys)
             out["reference_bench_group"] = reference_bench_group(ctx, abi, workloads, np)
             out["host_path"] = host_path(ctx, batch, np)
+            out["decomposers_single_triangle"] = decomposers_single_triangle(ctx)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)
         print(json.dumps(out), flush=True)
@@ -389,6 +390,34 @@ def reference_bench_group(ctx, abi, workloads, np):
                           "converged_fraction": conv / n_batch, "triangles_per_sec": conv * n_tri / (ms * 1e-3)}
         db.free()
         out[f"hinged_triangles_{n_tri}"] = entry
+    return out
+
+
+def decomposers_single_triangle(ctx):
+    """The reference's `single_triangle` test (fiksi/src/tests/triangles.rs:10-37) as a latency figure: one System::solve
+    through the builder under each Decomposer; RMS of the constraint residuals as the test asserts it (< 1e-4)."""
+    import time as _t
+
+    import fiksi_amd as F
+
+    out = {}
+    for dec in (F.Decomposer.NONE, F.Decomposer.SinglePass, F.Decomposer.RecursiveAssembly):
+        s = F.System()
+        pts = [F.elements.Point.create(s, x, y) for x, y in ((0., 0.), (1., .5), (2., 1.))]
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            F.constraints.PointPointDistance.create(s, pts[i], pts[j], 1.)
+        opts = F.SolvingOptions(decomposer=dec)
+        s.solve(opts, ctx)
+        dt, reps = 0.0, 10
+        for _ in range(reps):
+            for h, (x, y) in zip(pts, ((0., 0.), (1., .5), (2., 1.))):
+                h.update_value(s, x, y)
+            t0 = _t.perf_counter()
+            s.solve(opts, ctx)
+            dt += _t.perf_counter() - t0
+        r = s.constraint_residuals(ctx)
+        out[dec.name] = {"solve_ms": dt / reps * 1e3, "rms_residual": float((r * r).mean() ** 0.5),
+                         "device_solves": int(s.last_result["ncomp"])}
     return out
 
 
