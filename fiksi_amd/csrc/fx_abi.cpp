@@ -737,6 +737,24 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs);
     std::vector<uint8_t> expr_tag(d.n_exprs), sys_large(n);
     std::vector<uint16_t> sys_ncomp(n);
+    if (db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
+        // a small batch is one block on the device: one copy of it (page-locked, second half of the staging area) instead
+        // of seven small ones — the structure arrays are then taken from that image
+        unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
+        FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->pinned_busy = false;
+        auto grab = [&](void* dst, const void* dev, size_t bytes) {
+            if (bytes) memcpy(dst, img + (reinterpret_cast<const unsigned char*>(dev) - db->packed_base), bytes);
+        };
+        grab(var_off.data(), d.var_off, var_off.size() * 4);
+        grab(expr_off.data(), d.expr_off, expr_off.size() * 4);
+        grab(var_info.data(), d.var_info, var_info.size() * 2);
+        grab(expr_idx.data(), d.expr_idx, expr_idx.size() * 2);
+        grab(expr_tag.data(), d.expr_tag, expr_tag.size());
+        grab(sys_large.data(), d.sys_large, n);
+        grab(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2);
+    } else {
     FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -749,6 +767,7 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
         FX_HIP(hipMemcpyAsync(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
     }
     FX_HIP(hipStreamSynchronize(ctx->stream));
+    }
 
     std::vector<uint32_t> sys_unit_off((size_t)n + 1, 0);
     std::vector<fx::UnitDesc> desc;
