@@ -992,6 +992,26 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     std::vector<uint32_t> sys_unit_off, unit_rows;
     std::vector<fx::UnitDesc> unit_desc;
     std::vector<uint16_t> unit_vars;
+    if (d.sys_class && !units) sys_class.resize(n);
+    if (db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
+        // a small batch is one block on the device: its image in one page-locked copy instead of nine small ones
+        unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
+        FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->pinned_busy = false;
+        auto grab = [&](void* dst, const void* dev, size_t bytes) {
+            if (bytes) memcpy(dst, img + (reinterpret_cast<const unsigned char*>(dev) - db->packed_base), bytes);
+        };
+        grab(var_off.data(), d.var_off, var_off.size() * 4);
+        grab(expr_off.data(), d.expr_off, expr_off.size() * 4);
+        grab(var_info.data(), d.var_info, var_info.size() * 2);
+        grab(expr_idx.data(), d.expr_idx, expr_idx.size() * 2);
+        grab(expr_tag.data(), d.expr_tag, expr_tag.size());
+        grab(expr_comp.data(), d.expr_comp, expr_comp.size() * 2);
+        grab(sys_large.data(), d.sys_large, n);
+        grab(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2);
+        if (!sys_class.empty()) grab(sys_class.data(), d.sys_class, (size_t)n * 4);
+    } else {
     FX_HIP(hipMemcpyAsync(var_off.data(), d.var_off, var_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     FX_HIP(hipMemcpyAsync(expr_off.data(), d.expr_off, expr_off.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (d.n_vars) FX_HIP(hipMemcpyAsync(var_info.data(), d.var_info, var_info.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1003,10 +1023,8 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     if (n) {
         FX_HIP(hipMemcpyAsync(sys_large.data(), d.sys_large, n, hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipMemcpyAsync(sys_ncomp.data(), d.sys_ncomp, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream));
-        if (d.sys_class && !units) {
-            sys_class.resize(n);
-            FX_HIP(hipMemcpyAsync(sys_class.data(), d.sys_class, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        if (!sys_class.empty()) FX_HIP(hipMemcpyAsync(sys_class.data(), d.sys_class, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     }
     if (units) {
         if (!d.sys_unit_off) return fail(FX_ERR_INVALID, "internal: SinglePass blocks are not built yet");
@@ -1914,15 +1932,10 @@ int fx_timer_end(fx_ctx* ctx, float* milliseconds) {
 
 // ---- host-buffer entry points ---------------------------------------------------------------
 
-static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
-                      bool system_level, fx_result* results) {
-    fx_dbatch* db = nullptr;
-    int rc = fx_batch_upload(ctx, batch, &db);
-    if (rc) return rc;
-    db->resident = false;  // solved once and freed: no point in keeping plans
-    rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
-    // a small batch sits in one block: solved variables and results come back in ONE copy through the page-locked
-    // staging area, and the call waits on the stream once
+// After a one-shot solve: solved variables and results back to the caller, then the batch is freed. A small batch sits in
+// one block on the device: both come back in ONE copy through the page-locked staging area and the call waits on the
+// stream once.
+static int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch, fx_result* results, int rc) {
     if (!rc && batch->n_systems && db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
         const unsigned char* lo = reinterpret_cast<const unsigned char*>(db->d.vars);
         const unsigned char* hi = reinterpret_cast<const unsigned char*>(db->d.results + db->d.n_systems);
@@ -1947,6 +1960,16 @@ static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts*
     if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);
     fx_batch_free(ctx, db);
     return rc;
+}
+
+static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
+                      bool system_level, fx_result* results) {
+    fx_dbatch* db = nullptr;
+    int rc = fx_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    db->resident = false;  // solved once and freed: no point in keeping plans
+    rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
+    return read_back_and_free(ctx, db, batch, results, rc);
 }
 
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results) {
@@ -2001,10 +2024,7 @@ int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts*
     db->resident = false;
     db->d.has_pose = 1u;
     rc = fx_lm_solve_device(ctx, db, &o);
-    if (!rc && batch->n_systems) rc = fx_batch_get_vars(ctx, db, batch->vars);
-    if (!rc && results && batch->n_systems) rc = fx_batch_get_results(ctx, db, results);
-    fx_batch_free(ctx, db);
-    return rc;
+    return read_back_and_free(ctx, db, batch, results, rc);
 }
 
 int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses, const uint32_t* pose_of, const uint32_t* var_idx,
