@@ -542,6 +542,39 @@ struct fx_ctx {
     unsigned char* pinned = nullptr;
     static constexpr size_t PINNED_HALF = size_t(128) << 10;
     bool pinned_busy = false;  // an upload from the first half may still be in flight
+    // Plans of the sparse path for one-shot calls (System::solve on a large sketch, again and again while it is dragged):
+    // keyed by the System's structure and the solve mode, a handful kept, least recently used dropped. Values never
+    // enter a plan, so a hit only skips the host planning and the upload of its index arrays.
+    struct PlanEntry {
+        std::vector<unsigned char> key;
+        fx::SparsePlanCache* plan;
+        uint64_t used;
+    };
+    std::vector<PlanEntry> plan_cache;
+    uint64_t plan_clock = 0;
+    static constexpr size_t MAX_PLANS = 8;
+    fx::SparsePlanCache* plan_for(std::vector<unsigned char>&& key, bool* fresh) {
+        for (PlanEntry& e : plan_cache)
+            if (e.key == key) {
+                e.used = ++plan_clock;
+                *fresh = false;
+                return e.plan;
+            }
+        if (plan_cache.size() >= MAX_PLANS) {
+            size_t old = 0;
+            for (size_t i = 1; i < plan_cache.size(); ++i)
+                if (plan_cache[i].used < plan_cache[old].used) old = i;
+            fx::sparse_cache_free(plan_cache[old].plan);
+            plan_cache.erase(plan_cache.begin() + (long)old);
+        }
+        plan_cache.push_back({std::move(key), fx::sparse_cache_new(), ++plan_clock});
+        *fresh = true;
+        return plan_cache.back().plan;
+    }
+    void drop_plans() {
+        for (PlanEntry& e : plan_cache) fx::sparse_cache_free(e.plan);
+        plan_cache.clear();
+    }
     bool ensure_pinned() {
         if (pinned) return true;
         void* p = nullptr;
@@ -1316,13 +1349,39 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     }
     // plan caches are created here, on the calling thread (the map is not touched by the workers)
     std::vector<fx::SparsePlanCache*> plans(todo.size(), nullptr);
-    if (db->resident)
+    if (db->resident) {
         for (size_t k = 0; k < todo.size(); ++k) {
             const uint64_t key = 2ull * todo[k] + ((p.mode & fx::MODE_UNITS) ? 1u : 0u);
             auto it = db->sparse_plans.find(key);
             if (it == db->sparse_plans.end()) it = db->sparse_plans.emplace(key, fx::sparse_cache_new()).first;
             plans[k] = it->second;
         }
+    } else if (!pose) {  // (cluster problems of RecursiveAssembly differ from step to step: nothing to keep)
+        // one-shot call: the context keeps the plans of the structures it has seen (fx_ctx::plan_for). A plan that is
+        // being filled belongs to one System of this call; a finished one is read-only and may serve all that share it.
+        const fx_batch& hb = db->h_batch;
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const uint32_t s = todo[k];
+            const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0, e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
+            std::vector<unsigned char> key;
+            auto put = [&](const void* ptr, size_t bytes) {
+                const unsigned char* c = static_cast<const unsigned char*>(ptr);
+                key.insert(key.end(), c, c + bytes);
+            };
+            const uint32_t head[4] = {p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS), p.lm.solver, nvt, net};
+            put(head, sizeof(head));
+            put(hb.var_fixed + v0, nvt);
+            put(hb.expr_tag + e0, net);
+            put(hb.expr_idx + 4 * (size_t)e0, 4 * (size_t)net * sizeof(uint32_t));
+            if (hb.var_comp) put(hb.var_comp + v0, nvt * sizeof(uint16_t));
+            if (hb.expr_comp) put(hb.expr_comp + e0, net * sizeof(uint16_t));
+            bool fresh = false;
+            fx::SparsePlanCache* plan = ctx->plan_for(std::move(key), &fresh);
+            bool taken = false;  // (an unfinished plan goes to the first System that asks for it in this call)
+            for (size_t j = 0; j < k; ++j) taken = taken || plans[j] == plan;
+            plans[k] = (fx::sparse_cache_ready(plan) || !taken) ? plan : nullptr;
+        }
+    }
     auto solve_one = [&](uint32_t s, hipStream_t stream, fx::SparsePlanCache* plan) -> hipError_t {
         fx_result res{};
         hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, stream, db->d.vars + db->h_var_off[s], &res, plan);
@@ -1431,6 +1490,7 @@ void fx_ctx_destroy(fx_ctx* ctx) {
     }
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    ctx->drop_plans();
     ctx->drop_cache();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;

@@ -28,6 +28,7 @@ size_t analyze_lds_bytes(uint32_t, uint32_t) { return 0; }
 hipError_t launch_analyze(const DeviceBatch&, const double*, uint32_t, uint32_t, uint8_t*, hipStream_t) { return hipErrorNoDevice; }
 SparsePlanCache* sparse_cache_new() { return nullptr; }
 void sparse_cache_free(SparsePlanCache*) {}
+bool sparse_cache_ready(const SparsePlanCache*) { return false; }
 hipError_t sparse_solve_system(const fx_batch*, uint32_t, const LmParams&, hipStream_t, double*, fx_result*, SparsePlanCache*) {
     return hipErrorNoDevice;
 }

@@ -17,6 +17,7 @@ namespace fx {
 struct SparsePlanCache;
 SparsePlanCache* sparse_cache_new();
 void sparse_cache_free(SparsePlanCache* c);
+bool sparse_cache_ready(const SparsePlanCache* c);  // filled by a completed solve: later solves only read it
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
                                double* d_vars_out, fx_result* result, SparsePlanCache* cache);
 

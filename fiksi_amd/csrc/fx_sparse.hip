@@ -1004,6 +1004,7 @@ struct SparsePlanCache {
 };
 SparsePlanCache* sparse_cache_new() { return new SparsePlanCache(); }
 void sparse_cache_free(SparsePlanCache* c) { delete c; }
+bool sparse_cache_ready(const SparsePlanCache* c) { return c && c->ready; }
 
 namespace {
 
@@ -1331,10 +1332,8 @@ hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& pr
         cache->units.clear();
         cache->blocks.clear();
     }
-    if (cache && !cache->pool) {
-        cache->pool.reset(new Pool(&cache->arena));
-        cache->pool->stream = stream;
-    }
+    if (cache && !cache->pool) cache->pool.reset(new Pool(&cache->arena));
+    if (cache && !reuse) cache->pool->stream = stream;  // the index arrays go up on the filling call's stream
     size_t comp_at = 0, block_at = 0;
     const bool single_pass = (prm.mode & MODE_UNITS) != 0;
     const bool lbfgs = (prm.mode & MODE_LBFGS) != 0;

@@ -262,3 +262,39 @@ def test_k1_with_hundreds_of_constraint_free_systems_between_rows(fiksi, oracle,
     v, res = ctx.system_solve_batch(b)
     v_o, res_o = oracle.solve_batch(b, mode=3)
     assert np.array_equal(res["accepted"], res_o["accepted"]) and np.array_equal(res["ncomp"], res_o["ncomp"])
+
+
+def test_one_shot_calls_reuse_the_plan_of_a_structure_seen_before(fiksi, ctx):
+    """fx_system_solve_batch on a large sketch, again and again (System::solve while a sketch is dragged): the context
+    keeps the sparse path's plan per structure and solve mode (eight of them, least recently used dropped). Same bits as
+    the first call and as a resident batch; new values, a changed structure and more structures than the cache holds all
+    go through."""
+    from fiksi_amd import abi
+
+    from helpers import random_big_sketch
+
+    flats = [random_big_sketch(9000 + k, 140 + 7 * k).flatten() for k in range(10)]  # ten structures > eight cached plans
+    first = []
+    for f in flats:
+        first.append(ctx.system_solve_batch(f))
+    for round_ in range(2):
+        for k, f in enumerate(flats):
+            v, r = ctx.system_solve_batch(f)
+            assert np.array_equal(v.view(np.uint64), first[k][0].view(np.uint64)) and r.tobytes() == first[k][1].tobytes()
+    # resident batch of the same sketch: the same bits
+    db = ctx.upload(flats[3])
+    db.system_solve()
+    assert np.array_equal(db.get_vars().view(np.uint64), first[3][0].view(np.uint64))
+    db.free()
+    # same structure, other values: the cached plan serves it
+    g = dict(flats[5])
+    g["vars"] = g["vars"] * 1.25 + 0.5
+    v1, r1 = ctx.system_solve_batch(g)
+    db = ctx.upload(g)
+    db.system_solve()
+    assert np.array_equal(db.get_vars().view(np.uint64), v1.view(np.uint64))
+    db.free()
+    # another solve mode on a cached structure gets its own plan
+    v2, r2 = ctx.system_solve_batch(flats[5], abi.solving_opts(solver=1))
+    v3, r3 = ctx.system_solve_batch(flats[5], abi.solving_opts(solver=1))
+    assert np.array_equal(v2.view(np.uint64), v3.view(np.uint64)) and r2.tobytes() == r3.tobytes()
