@@ -296,8 +296,8 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
 /* == assemble::solve: batch->vars in: unscaled values, out: solved values. results may be NULL.
  * Systems beyond the one-wavefront kernels need a plan (ordering, symbolic factorisation, gather lists): the context keeps
  * the plans of the last eight structures + solve modes these one-shot entry points have seen, so that System::solve on the
- * same large sketch with new values pays for it once (device memory of a plan: about 5 KB per variable; all freed by
- * fx_ctx_destroy). */
+ * same large sketch with new values pays for it once (a plan's index arrays stay in device memory until it is dropped;
+ * fx_ctx_destroy frees them all). */
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results);
 /* == levenberg_marquardt(Subsystem): values used as given (already scaled/perturbed). */
 int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
