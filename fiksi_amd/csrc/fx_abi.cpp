@@ -610,6 +610,10 @@ struct fx_ctx {
             drop_cache();
             err = hipMalloc(&p, bytes);
         }
+        if (err == hipErrorOutOfMemory && !plan_cache.empty()) {  // ... then the kept plans of one-shot calls
+            drop_plans();
+            err = hipMalloc(&p, bytes);
+        }
         return err == hipSuccess ? p : nullptr;
     }
     void give_back(void* p, size_t bytes) {
