@@ -553,22 +553,23 @@ struct fx_ctx {
     std::vector<PlanEntry> plan_cache;
     uint64_t plan_clock = 0;
     static constexpr size_t MAX_PLANS = 8;
-    fx::SparsePlanCache* plan_for(std::vector<unsigned char>&& key, bool* fresh) {
+    // `call_clock` = plan_clock when the calling solve began: entries used since then belong to it and stay. When all
+    // MAX_PLANS entries are this call's, the structure gets no cached plan (nullptr: the solve plans for itself).
+    fx::SparsePlanCache* plan_for(std::vector<unsigned char>&& key, uint64_t call_clock) {
         for (PlanEntry& e : plan_cache)
             if (e.key == key) {
                 e.used = ++plan_clock;
-                *fresh = false;
                 return e.plan;
             }
         if (plan_cache.size() >= MAX_PLANS) {
-            size_t old = 0;
-            for (size_t i = 1; i < plan_cache.size(); ++i)
-                if (plan_cache[i].used < plan_cache[old].used) old = i;
+            size_t old = plan_cache.size();
+            for (size_t i = 0; i < plan_cache.size(); ++i)
+                if (plan_cache[i].used <= call_clock && (old == plan_cache.size() || plan_cache[i].used < plan_cache[old].used)) old = i;
+            if (old == plan_cache.size()) return nullptr;
             fx::sparse_cache_free(plan_cache[old].plan);
             plan_cache.erase(plan_cache.begin() + (long)old);
         }
         plan_cache.push_back({std::move(key), fx::sparse_cache_new(), ++plan_clock});
-        *fresh = true;
         return plan_cache.back().plan;
     }
     void drop_plans() {
@@ -639,8 +640,12 @@ struct fx_dbatch {
     std::vector<double> h_vars, h_expr_param;
     std::vector<uint8_t> h_var_fixed, h_expr_tag, h_sys_large;
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
-    // sparse-path plans of large Systems, key = 2 * system + (SinglePass ? 1 : 0)
-    std::map<uint64_t, fx::SparsePlanCache*> sparse_plans;
+    // sparse-path plans of the batch's large Systems, one per structure and decomposer mode (hash -> candidates)
+    struct ResidentPlan {
+        std::vector<unsigned char> key;
+        fx::SparsePlanCache* plan;
+    };
+    std::multimap<uint64_t, ResidentPlan> sparse_plans;
     // Decomposer::None on large Systems made of small components: the component walk (a DeviceBatch
     // whose unit arrays list whole components), built on first use
     fx::DeviceBatch comp_walk{};
@@ -1351,39 +1356,91 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
         todo.push_back(s);
     }
-    // plan caches are created here, on the calling thread (the map is not touched by the workers)
-    std::vector<fx::SparsePlanCache*> plans(todo.size(), nullptr);
-    if (db->resident) {
-        for (size_t k = 0; k < todo.size(); ++k) {
-            const uint64_t key = 2ull * todo[k] + ((p.mode & fx::MODE_UNITS) ? 1u : 0u);
-            auto it = db->sparse_plans.find(key);
-            if (it == db->sparse_plans.end()) it = db->sparse_plans.emplace(key, fx::sparse_cache_new()).first;
-            plans[k] = it->second;
+    if (todo.empty()) return FX_OK;
+    // ---- Systems of one STRUCTURE (fixed flags, tags, fields, components) share a plan and are solved together
+    const fx_batch& hb = db->h_batch;
+    auto structure_key = [&](uint32_t s) {
+        const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0, e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
+        std::vector<unsigned char> key;
+        auto put = [&](const void* ptr, size_t bytes) {
+            const unsigned char* c = static_cast<const unsigned char*>(ptr);
+            key.insert(key.end(), c, c + bytes);
+        };
+        const uint32_t head[4] = {p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS), 0u, nvt, net};
+        put(head, sizeof(head));
+        put(hb.var_fixed + v0, nvt);
+        put(hb.expr_tag + e0, net);
+        put(hb.expr_idx + 4 * (size_t)e0, 4 * (size_t)net * sizeof(uint32_t));
+        if (hb.var_comp) put(hb.var_comp + v0, nvt * sizeof(uint16_t));
+        if (hb.expr_comp) put(hb.expr_comp + e0, net * sizeof(uint16_t));
+        return key;
+    };
+    // groups in order of their first System; a 64-bit hash finds the candidates, the bytes decide
+    struct Group {
+        std::vector<unsigned char> key;
+        std::vector<uint32_t> systems;
+    };
+    std::vector<Group> groups;
+    {
+        std::map<uint64_t, std::vector<size_t>> by_hash;
+        for (uint32_t s : todo) {
+            std::vector<unsigned char> key = structure_key(s);
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
+            std::vector<size_t>& cand = by_hash[h];
+            size_t g = groups.size();
+            for (size_t i : cand)
+                if (groups[i].key == key) g = i;
+            if (g == groups.size()) {
+                cand.push_back(g);
+                groups.push_back({std::move(key), {}});
+            }
+            groups[g].systems.push_back(s);
         }
-    } else if (!pose) {  // (cluster problems of RecursiveAssembly differ from step to step: nothing to keep)
-        // one-shot call: the context keeps the plans of the structures it has seen (fx_ctx::plan_for). A plan that is
-        // being filled belongs to one System of this call; a finished one is read-only and may serve all that share it.
-        const fx_batch& hb = db->h_batch;
+    }
+    // plans: a resident batch keeps its own (per structure and decomposer mode); one-shot calls share the context's
+    // (fx_ctx::plan_for — entries this call has touched are never evicted under it). Cluster problems of
+    // RecursiveAssembly differ from step to step: nothing to keep.
+    const uint64_t call_clock = ctx->plan_clock;
+    std::vector<fx::SparsePlanCache*> group_plan(groups.size(), nullptr);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        if (db->resident) {
+            uint64_t h = (p.mode & fx::MODE_UNITS) ? 0x9E3779B97F4A7C15ull : 0ull;
+            for (unsigned char c : groups[g].key) h = (h ^ c) * 1099511628211ull;
+            auto range = db->sparse_plans.equal_range(h);
+            fx_dbatch::ResidentPlan* found = nullptr;
+            for (auto it = range.first; it != range.second; ++it)
+                if (it->second.key == groups[g].key) found = &it->second;
+            if (!found) found = &db->sparse_plans.emplace(h, fx_dbatch::ResidentPlan{groups[g].key, fx::sparse_cache_new()})->second;
+            group_plan[g] = found->plan;
+        } else if (!pose) {
+            group_plan[g] = ctx->plan_for(std::vector<unsigned char>(groups[g].key), call_clock);
+        }
+    }
+    if (!(p.mode & fx::MODE_LBFGS)) {
+        // Levenberg-Marquardt: every launch covers a whole group, control flow on the device (fx_sparse_team.h)
+        for (size_t g = 0; g < groups.size(); ++g) {
+            hipError_t e = fx::sparse_solve_group(&hb, db->d, groups[g].systems.data(), (uint32_t)groups[g].systems.size(), p, ctx->stream,
+                                                  group_plan[g]);
+            if (e != hipSuccess)
+                return fail(FX_ERR_HIP, "sparse path failed on the group of system %u: %s", groups[g].systems[0], hipGetErrorString(e));
+        }
+        return FX_OK;
+    }
+    // ---- Optimizer::LBfgs: one host-driven loop per System (the line search's decisions are taken on the host).
+    // A plan that is being filled belongs to one System of this call; a finished one is read-only and may serve all
+    // that share it.
+    std::vector<fx::SparsePlanCache*> plans(todo.size(), nullptr);
+    {
+        std::map<uint32_t, size_t> group_of;
+        for (size_t g = 0; g < groups.size(); ++g)
+            for (uint32_t s : groups[g].systems) group_of[s] = g;
+        std::vector<uint8_t> taken(groups.size(), 0);
         for (size_t k = 0; k < todo.size(); ++k) {
-            const uint32_t s = todo[k];
-            const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0, e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
-            std::vector<unsigned char> key;
-            auto put = [&](const void* ptr, size_t bytes) {
-                const unsigned char* c = static_cast<const unsigned char*>(ptr);
-                key.insert(key.end(), c, c + bytes);
-            };
-            const uint32_t head[4] = {p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS), p.lm.solver, nvt, net};
-            put(head, sizeof(head));
-            put(hb.var_fixed + v0, nvt);
-            put(hb.expr_tag + e0, net);
-            put(hb.expr_idx + 4 * (size_t)e0, 4 * (size_t)net * sizeof(uint32_t));
-            if (hb.var_comp) put(hb.var_comp + v0, nvt * sizeof(uint16_t));
-            if (hb.expr_comp) put(hb.expr_comp + e0, net * sizeof(uint16_t));
-            bool fresh = false;
-            fx::SparsePlanCache* plan = ctx->plan_for(std::move(key), &fresh);
-            bool taken = false;  // (an unfinished plan goes to the first System that asks for it in this call)
-            for (size_t j = 0; j < k; ++j) taken = taken || plans[j] == plan;
-            plans[k] = (fx::sparse_cache_ready(plan) || !taken) ? plan : nullptr;
+            const size_t g = group_of[todo[k]];
+            fx::SparsePlanCache* plan = group_plan[g];
+            plans[k] = (plan && (fx::sparse_cache_ready(plan) || !taken[g])) ? plan : nullptr;
+            taken[g] = 1;
         }
     }
     auto solve_one = [&](uint32_t s, hipStream_t stream, fx::SparsePlanCache* plan) -> hipError_t {
@@ -1757,7 +1814,7 @@ static void free_batch(fx_ctx* ctx, fx_dbatch* db, bool stream_idle) {
         (void)hipStreamSynchronize(ctx->stream);
         ctx->pinned_busy = false;
     }
-    for (auto& kv : db->sparse_plans) fx::sparse_cache_free(kv.second);
+    for (auto& kv : db->sparse_plans) fx::sparse_cache_free(kv.second.plan);
     for (auto& blk : db->allocations) {
         if (ctx) ctx->give_back(blk.p, blk.size);  // the stream is idle: the blocks can be handed out again
         else (void)hipFree(blk.p);

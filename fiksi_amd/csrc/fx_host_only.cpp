@@ -32,4 +32,7 @@ bool sparse_cache_ready(const SparsePlanCache*) { return false; }
 hipError_t sparse_solve_system(const fx_batch*, uint32_t, const LmParams&, hipStream_t, double*, fx_result*, SparsePlanCache*) {
     return hipErrorNoDevice;
 }
+hipError_t sparse_solve_group(const fx_batch*, const DeviceBatch&, const uint32_t*, uint32_t, const LmParams&, hipStream_t, SparsePlanCache*) {
+    return hipErrorNoDevice;
+}
 }  // namespace fx

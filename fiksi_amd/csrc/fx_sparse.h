@@ -18,6 +18,12 @@ struct SparsePlanCache;
 SparsePlanCache* sparse_cache_new();
 void sparse_cache_free(SparsePlanCache* c);
 bool sparse_cache_ready(const SparsePlanCache* c);  // filled by a completed solve: later solves only read it
+// Levenberg-Marquardt for Systems systems[0 .. n) of the host batch `b`, which all have the structure of the first one
+// (fixed flags, tags, fields, components): one plan, every launch covers the whole group, results and solved variables
+// go straight to the resident batch `d` (d.vars, d.results). Synchronises `stream` before it returns.
+hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uint32_t* systems, uint32_t n, const LmParams& prm,
+                              hipStream_t stream, SparsePlanCache* cache);
+// Optimizer::LBfgs, one System:
 hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
                                double* d_vars_out, fx_result* result, SparsePlanCache* cache);
 

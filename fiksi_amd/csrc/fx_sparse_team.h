@@ -1,0 +1,793 @@
+// Workgroup ("team") kernels of the large-component path — included by fx_sparse.hip inside its anonymous namespace,
+// after the structures and helpers they use (SpRows, SpJac, SpChol, SpRowsOfL, SpLm, lds_add_f64, wave_sum64, ...).
+//
+// Round 2 ran one host loop of tiny launches per large System: a level of the elimination tree per launch, ~30 launches
+// per LM trial, each bound by its own launch latency (hinged triangles x 64: 1.6 k Systems/s, slower than one CPU core).
+// Here the unit of work is a WORKGROUP of 16 wavefronts that owns a piece of the elimination tree (a "segment",
+// fx_sparse_plan.h: TeamSchedule): its lists are walked by its wavefronts, a workgroup barrier ends a level, and what
+// one wavefront stores the others read through the CU's own L1 — no launch boundary, no device-wide barrier.
+//   * Systems whose factor is one segment (up to a few thousand columns): sp_lm_team_kernel — ONE launch runs the
+//     whole Levenberg-Marquardt loop (lm.rs:108-191) of a block for every System of a batch that shares the structure,
+//     one workgroup per System, control flow included; the host does not look at it until the end.
+//   * larger Systems (cfg2): the tree is cut into parts (one workgroup each, side by side) and a top (one workgroup):
+//     spt_* kernels, five launches per trial instead of thirty, LM control in the last block of the evaluation kernel.
+
+constexpr int TEAM_THREADS = 1024;
+constexpr int TEAM_NWAVES = TEAM_THREADS / 64;
+static_assert(TEAM_NWAVES == (int)sparse_plan::TEAM_WAVES, "the schedules are built for this many wavefronts");
+
+struct ColDesc {  // one column, as a wavefront meets it on its way through a list
+    uint32_t j;             // the column
+    uint32_t beg, end;      // its entries in L (the first one is the diagonal)
+    uint32_t rbeg, rend;    // row j of L (strictly lower part)
+    uint32_t pbeg, pend0;   // the products of its first 64 entries
+    uint32_t pad;
+};
+
+struct SpTeamSched {
+    const uint32_t* seg_lev;
+    const uint32_t* lev_list;
+    const uint32_t* list_ptr;
+    const uint32_t* list_cols;
+    const ColDesc* cdesc;       // [nv] in the order of list_cols
+    uint32_t nparts;
+};
+constexpr uint32_t FORM_LONG = 32;  // gather lists of A / of the right-hand side beyond this are summed by a wavefront
+
+struct SpBlock {  // structure of one block, shared by the Systems of a group
+    SpJac jac;
+    const uint32_t *fvar, *perm, *apair_ptr, *apairs, *cptr, *cidx, *crow, *jcol;
+    SpChol chol;
+    SpRowsOfL lrows;
+    SpTeamSched sched;
+    const uint32_t* along;   // entries of A, then columns of the right-hand side, whose gather lists are long
+    uint32_t n_along, n_clong;
+    uint32_t m, nv, nnz_a, nnz_l;
+};
+
+// Value arrays of the group's first System; System s of the group lives `s * stride` doubles further in every one.
+struct SpVals {
+    double *xs0, *xs1, *snap, *r0, *r1, *j0, *j1, *a, *l, *rhs, *delta, *t, *e, *scal;
+    size_t stride;
+    __device__ __forceinline__ void shift(uint32_t s) {
+        const size_t o = (size_t)s * stride;
+        xs0 += o; xs1 += o; snap += o; r0 += o; r1 += o; j0 += o; j1 += o; a += o; l += o;
+        rhs += o; delta += o; t += o; e += o; scal += o;
+    }
+};
+
+struct SpAccum {  // what a System's blocks add up to (fx_result)
+    uint32_t accepted, trials, exit_code, ncomp;
+    double sse0, sse;
+};
+
+constexpr uint32_t TEAM_REFINED = 1, TEAM_SINGLE_PASS = 2, TEAM_SCALE = 4;
+constexpr uint32_t TEAM_PARTS_MAX_GROUP = 8;  // from this many Systems of a structure on, each one keeps to its own workgroup
+
+// what one wavefront stored (global memory), its other lanes may load next: the stores have left (vmcnt) before any
+// later load issues. Same CU, same L1 — nothing more is needed inside a workgroup.
+__device__ __forceinline__ void wave_sync_mem() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// the same for LDS: a wavefront's LDS instructions execute in order, only the compiler has to keep them so — and the
+// index loads of the next column stay in flight (no vmcnt wait)
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool LDSV>
+__device__ __forceinline__ void vals_sync() {
+    if (LDSV) wave_sync_lds();
+    else wave_sync_mem();
+}
+
+__device__ __forceinline__ double bcast_first(double s) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(s));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
+    return __hiloint2double(hi, lo);
+}
+
+// The columns of a list, bottom-up: numeric Cholesky (left-looking by gather lists) with the forward sweep L y = b
+// riding along — once column j is factored, row j of L is complete, so y_j follows at once. FACTOR = false: the forward
+// sweep alone with the stored factor (the refined step needs it again). LDSV: l and b live in LDS.
+// A column is a chain of dependent steps (operands -> products -> pivot -> division -> the next column's operands),
+// so everything that does NOT depend on values is taken off it: the column's description is one 32-byte record in list
+// order (a scalar load), and the index words of the first 64 products / row entries / A entries of column t + 1 are
+// loaded while column t computes. 64 entries at a time (almost every column has fewer): all their products in one
+// flat, lane-strided sweep — they are contiguous, lpair_ptr is a prefix over the entries — summed per entry with LDS
+// atomics. `acc`: 64 doubles of LDS owned by the wavefront. Returns false when a pivot is not positive and finite.
+template <bool LDSV, bool FACTOR>
+__device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& lr, const ColDesc* __restrict__ cd, uint32_t t0, uint32_t t1,
+                                             const double* __restrict__ a, double lambda, double* l, double* b, double* acc, int lane) {
+    bool ok = true;
+    if (t0 >= t1) return ok;
+    const uint2* __restrict__ lpairs2 = reinterpret_cast<const uint2*>(c.lpairs);
+    ColDesc nd = cd[t0];
+    uint2 npr = make_uint2(0u, 0u);
+    uint32_t npk = 0, nri = 0, nrc = 0;
+    double nav = 0.0;
+    auto fetch = [&](const ColDesc& d) {
+        if (FACTOR) {
+            const uint32_t p = d.pbeg + lane;
+            if (p < d.pend0) {
+                npr = lpairs2[p];
+                npk = c.lpair_k[p];
+            }
+            const uint32_t k = d.beg + lane;
+            if (k < d.end) {
+                const int32_t ai = c.l2a[k];
+                nav = ai >= 0 ? a[ai] : 0.0;
+            }
+        }
+        const uint32_t r = d.rbeg + lane;
+        if (r < d.rend) {
+            nri = lr.ridx[r];
+            nrc = lr.rcol[r];
+        }
+    };
+    fetch(nd);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const ColDesc d = nd;
+        const uint2 pr = npr;
+        const uint32_t pk = npk, ri = nri, rc = nrc;
+        const double av = nav;
+        if (t + 1 < t1) {
+            nd = cd[t + 1];
+            fetch(nd);
+        }
+        double part = 0.0;  // forward-sweep gather for row j (all of its columns are final already)
+        {
+            uint32_t r = d.rbeg + lane;
+            if (r < d.rend) part = l[ri] * b[rc];
+            for (r += 64; r < d.rend; r += 64) part = fma(l[lr.ridx[r]], b[lr.rcol[r]], part);
+        }
+        double dg = 0.0;
+        if (FACTOR) {
+            for (uint32_t base = d.beg; base < d.end; base += 64) {
+                const bool first = base == d.beg;
+                const uint32_t k = base + lane, cend = min(base + 64u, d.end);
+                double s = 0.0;
+                if (k < cend) {
+                    if (first) {
+                        s = av;
+                    } else {
+                        const int32_t ai = c.l2a[k];
+                        s = ai >= 0 ? a[ai] : 0.0;
+                    }
+                    if (k == d.beg) s += lambda;
+                }
+                const uint32_t pb = first ? d.pbeg : c.lpair_ptr[base], pe = first ? d.pend0 : c.lpair_ptr[cend];
+                if (pe > pb) {  // (wave-uniform) leaves of the tree have no products at all
+                    acc[lane] = 0.0;
+                    uint32_t p = pb + lane;
+                    if (first) {
+                        if (p < pe) lds_add_f64(&acc[pk - base], -l[pr.x] * l[pr.y]);
+                        p += 64;
+                    }
+                    for (; p < pe; p += 64) {
+                        const uint2 q2 = lpairs2[p];
+                        lds_add_f64(&acc[c.lpair_k[p] - base], -l[q2.x] * l[q2.y]);
+                    }
+                    wave_sync_lds();
+                    if (k < cend) s += acc[lane];
+                }
+                if (first) {
+                    const double piv = bcast_first(s);
+                    ok = ok && (piv > 0.0) && (piv < 1.0e300);
+                    dg = ::sqrt(piv);
+                }
+                if (k < cend) l[k] = (k == d.beg) ? dg : s / dg;
+            }
+        } else {
+            dg = l[d.beg];
+        }
+        part = wave_sum64(part);
+        if (lane == 0) b[d.j] = (b[d.j] - part) / dg;
+        vals_sync<LDSV>();  // the next column of this list may read what this one stored
+    }
+    return ok;
+}
+
+// Lt x = y, the columns of a list top-down: x_j = (y_j - sum_{i>j} L_ij x_i) / L_jj reads only ancestors of j
+template <bool LDSV>
+__device__ __forceinline__ void team_walk_down(const SpChol& c, const ColDesc* __restrict__ cd, uint32_t t0, uint32_t t1, const double* l,
+                                               double* b, int lane) {
+    if (t0 >= t1) return;
+    ColDesc nd = cd[t1 - 1];
+    uint32_t nrow = 0;
+    auto fetch = [&](const ColDesc& d) {
+        const uint32_t k = d.beg + 1 + lane;
+        if (k < d.end) nrow = c.lrow[k];
+    };
+    fetch(nd);
+    for (uint32_t t = t1; t-- > t0;) {
+        const ColDesc d = nd;
+        const uint32_t row = nrow;
+        if (t > t0) {
+            nd = cd[t - 1];
+            fetch(nd);
+        }
+        double part = 0.0;
+        uint32_t k = d.beg + 1 + lane;
+        if (k < d.end) part = l[k] * b[row];
+        for (k += 64; k < d.end; k += 64) part = fma(l[k], b[c.lrow[k]], part);
+        part = wave_sum64(part);
+        if (lane == 0) b[d.j] = (b[d.j] - part) / l[d.beg];
+        vals_sync<LDSV>();
+    }
+}
+
+// A segment's factorization + forward sweep by the calling workgroup: levels bottom-up, a barrier after each.
+// Returns (to every thread of a wavefront) whether its pivots were fine.
+template <bool LDSV, bool FACTOR>
+__device__ __forceinline__ bool team_factor_forward(const SpChol& c, const SpRowsOfL& lr, const SpTeamSched& sc, uint32_t seg,
+                                                    const double* __restrict__ a, double lambda, double* l, double* b, double* s_acc) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    bool ok = true;
+    for (uint32_t q = sc.seg_lev[seg]; q < sc.seg_lev[seg + 1]; ++q) {
+        for (uint32_t list = sc.lev_list[q] + wave; list < sc.lev_list[q + 1]; list += TEAM_NWAVES)
+            ok = team_walk_up<LDSV, FACTOR>(c, lr, sc.cdesc, sc.list_ptr[list], sc.list_ptr[list + 1], a, lambda, l, b, s_acc + wave * 64, lane) && ok;
+        __syncthreads();
+    }
+    return ok;
+}
+
+template <bool LDSV>
+__device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched& sc, uint32_t seg, const double* l, double* b) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (uint32_t q = sc.seg_lev[seg + 1]; q-- > sc.seg_lev[seg];) {
+        for (uint32_t list = sc.lev_list[q] + wave; list < sc.lev_list[q + 1]; list += TEAM_NWAVES)
+            team_walk_down<LDSV>(c, sc.cdesc, sc.list_ptr[list], sc.list_ptr[list + 1], l, b, lane);
+        __syncthreads();
+    }
+}
+
+// K3 for the calling workgroup's share (first, step over the items): A = JtJ (lower triangle, permuted order) and
+// -Jt r by deterministic gathers, one thread per entry; the few entries whose gather lists are long (the diagonal of a
+// point every constraint hangs on: one product per constraint) are summed by a wavefront each, a fixed butterfly.
+// The right-hand side goes to `rhs` (kept: a rejected trial solves with it again) and to `vec`, the vector the solves overwrite.
+__device__ __forceinline__ void team_form(const SpBlock& B, const double* jc, const double* rc, double* a, double* rhs, double* vec,
+                                          uint32_t first, uint32_t step, uint32_t wave_first, uint32_t wave_step) {
+    for (uint32_t k = first; k < B.nnz_a; k += step) {
+        const uint32_t pb = B.apair_ptr[k], pe = B.apair_ptr[k + 1];
+        if (pe - pb > FORM_LONG) continue;
+        double s = 0.0;
+        for (uint32_t p = pb; p < pe; ++p) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
+        a[k] = s;
+    }
+    for (uint32_t c = first; c < B.nv; c += step) {
+        const uint32_t pb = B.cptr[c], pe = B.cptr[c + 1];
+        if (pe - pb > FORM_LONG) continue;
+        double s = 0.0;
+        for (uint32_t p = pb; p < pe; ++p) s += jc[B.cidx[p]] * -rc[B.crow[p]];
+        rhs[c] = s;
+        vec[c] = s;
+    }
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = wave_first; i < B.n_along + B.n_clong; i += wave_step) {
+        double s = 0.0;
+        if (i < B.n_along) {
+            const uint32_t k = B.along[i];
+            for (uint32_t p = B.apair_ptr[k] + lane; p < B.apair_ptr[k + 1]; p += 64) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
+            s = wave_sum64(s);
+            if (lane == 0) a[k] = s;
+        } else {
+            const uint32_t c = B.along[i];
+            for (uint32_t p = B.cptr[c] + lane; p < B.cptr[c + 1]; p += 64) s += jc[B.cidx[p]] * -rc[B.crow[p]];
+            s = wave_sum64(s);
+            if (lane == 0) {
+                rhs[c] = s;
+                vec[c] = s;
+            }
+        }
+    }
+}
+
+// sum v[i]^2 with the shape of sp_sumsq_kernel (1024 strided partial sums, then a binary tree): same bits
+__device__ __forceinline__ double team_sumsq(const double* v, uint32_t n, double* s_red) {
+    double s = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += TEAM_THREADS) s += v[i] * v[i];
+    return block_sum_1024(s, s_red);
+}
+
+// K1 / K2 for one row of a block (subsystem.rs:93-166), the body of sp_eval_kernel
+template <bool POSE>
+__device__ __forceinline__ void team_eval_row(const SpRows& rows, const double* sparam, const SpJac& jac, uint32_t row, const double* xs,
+                                              double* r, double* jvals) {
+    const uint32_t e = jac.rows[row];
+    const int tag = rows.tag[e] & 0x7F;
+    const ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+    const uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    expand_vars<POSE>(tag, ff, vars8);
+    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
+    r[row] = eval_expression<double, true, false, POSE>(tag, v, sparam[e], g);
+    const uint32_t slots = jac.jslot[row];
+    const uint32_t base = jac.jrow_ptr[row];
+    const uint32_t cnt = jac.jrow_ptr[row + 1] - base;
+    double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t sl = (slots >> (4 * q)) & 0xFu;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) out[u] += (sl == (uint32_t)u) ? g[q] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if ((uint32_t)u < cnt) jvals[base + u] = out[u];
+}
+
+// lm.rs:108-112 on a state in registers
+__device__ __forceinline__ void lm_state_init(SpLm& st, double sse, const fx_lm_opts& o) {
+    st.sse = st.sse_start = sse;
+    st.sse_t = st.dn2 = 0.0;
+    st.lambda = o.lambda0;
+    st.cur = 0;
+    st.accepted = st.trials = st.outer = 0;
+    st.exit_code = FX_EXIT_MAX_OUTER;
+    st.need_form = 1;
+    st.flag = 0;
+    st.done = 0;
+    if (!(sse == sse) || !(sse < 1.0e300)) {
+        st.exit_code = FX_EXIT_NAN;
+        st.done = 1;
+    } else if (o.max_outer == 0) {
+        st.done = 1;
+    } else if (sse < o.sse_tol) {  // lm.rs:110-112
+        st.exit_code = FX_EXIT_SSE;
+        st.done = 1;
+    } else if (o.max_trials == 0) {
+        st.exit_code = FX_EXIT_TRIAL_CAP;
+        st.done = 1;
+    }
+}
+
+// after a trial: accept / reject / stop (lm.rs:134-191) — sp_lm_control_kernel's decisions; need_form tells whether
+// the next trial starts from a new point
+__device__ __forceinline__ void lm_state_control(SpLm& st, const fx_lm_opts& o) {
+    st.trials += 1;
+    st.need_form = 0;
+    bool check_cap = true;
+    if (st.flag) {  // lm.rs:134-137
+        st.lambda *= o.singular_factor;
+        if (!(st.lambda < 1.0e300)) {
+            st.exit_code = FX_EXIT_NAN;
+            st.done = 1;
+        }
+    } else {
+        const double dn2 = st.dn2, sse_t = st.sse_t, sse = st.sse;
+        if (!(dn2 == dn2)) {
+            st.exit_code = FX_EXIT_NAN;
+            st.done = 1;
+            check_cap = false;
+        } else if (dn2 < o.step_tol) {  // lm.rs:139-142
+            st.exit_code = FX_EXIT_STEP;
+            st.done = 1;
+            check_cap = false;
+        } else if (sse_t < sse) {  // accept, lm.rs:151-186
+            double lam = st.lambda * o.accept_factor;
+            if (lam < o.lambda_min) lam = o.lambda_min;
+            st.lambda = lam;
+            st.cur ^= 1u;
+            st.accepted += 1;
+            const double rel = (sse - sse_t) / sse;
+            st.sse = sse_t;
+            if (rel <= o.ftol) {
+                st.exit_code = FX_EXIT_FTOL;
+                st.done = 1;
+                check_cap = false;
+            } else {
+                st.need_form = 1;
+                st.outer += 1;
+                if (st.outer >= o.max_outer) {
+                    st.done = 1;  // exit_code is still FX_EXIT_MAX_OUTER
+                    check_cap = false;
+                } else if (sse_t < o.sse_tol) {
+                    st.exit_code = FX_EXIT_SSE;
+                    st.done = 1;
+                    check_cap = false;
+                }
+            }
+        } else {  // reject, lm.rs:187-190
+            st.lambda *= o.reject_factor;
+            if (!(sse_t == sse_t) && !(st.lambda < 1.0e300)) {
+                st.exit_code = FX_EXIT_NAN;
+                st.done = 1;
+                check_cap = false;
+            }
+        }
+    }
+    if (check_cap && !st.done && st.trials >= o.max_trials) {
+        st.exit_code = FX_EXIT_TRIAL_CAP;
+        st.done = 1;
+    }
+    st.flag = 0;
+}
+
+// what ends a block (assemble/mod.rs:161-166, :201-207): solved values out, working vectors ready for the next block
+__device__ __forceinline__ void team_block_epilogue(const SpBlock& B, const SpVals& V, uint32_t cur, uint32_t flags, double* vars_out,
+                                                    uint32_t first, uint32_t step) {
+    const double* xc = cur ? V.xs1 : V.xs0;
+    double* xo = cur ? V.xs0 : V.xs1;
+    const double scale = V.scal[0];
+    for (uint32_t k = first; k < B.nv; k += step) {
+        const uint32_t vi = B.fvar[k];
+        const double x = xc[vi];
+        vars_out[vi] = (flags & TEAM_SCALE) ? scale * x : x;
+        if (flags & TEAM_SINGLE_PASS) {
+            xo[vi] = x;  // later blocks see this one (:201-207)
+        } else {         // later components see the pre-solve snapshot (quirk Q2)
+            const double sn = V.snap[vi];
+            V.xs0[vi] = sn;
+            V.xs1[vi] = sn;
+        }
+    }
+}
+
+// ---- the whole LM loop of one block, one workgroup per System ------------------------------------------------------
+// LDSV: the factor and the solves' vectors live in LDS (dynamic: lds_l doubles of L, then two vectors of lds_v) — every
+// step of a column's dependent chain is then an LDS round trip instead of an L2 one. The host picks it when they fit.
+template <bool POSE, bool LDSV>
+__global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum,
+                                                                   fx_lm_opts o, uint32_t flags, double* __restrict__ vars_base,
+                                                                   const uint64_t* __restrict__ out_off, uint32_t lds_l, uint32_t lds_v,
+                                                                   unsigned long long* prof) {
+    // prof (diagnostics, FIKSI_AMD_TEAM_PROF=1; else null): workgroup 0 adds up the 100 MHz ticks of its phases
+    const bool stamp = prof && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long t_prev = stamp ? wall_clock64() : 0ull;
+    auto mark = [&](int slot) {
+        if (stamp) {
+            const unsigned long long now = wall_clock64();
+            prof[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
+    extern __shared__ double s_dyn[];
+    __shared__ double s_acc[TEAM_NWAVES * 64];
+    __shared__ double s_red[TEAM_THREADS];
+    __shared__ uint32_t s_bad;
+    const uint32_t sys = blockIdx.x, tid = threadIdx.x;
+    V.shift(sys);
+    const double* sparam = rows.sparam + (size_t)sys * V.stride;
+    const uint32_t m = B.m, nv = B.nv;
+    double* const fl = LDSV ? s_dyn : V.l;                      // the factor
+    double* const dvec = LDSV ? s_dyn + lds_l : V.delta;        // right-hand side -> step
+    double* const evec = LDSV ? s_dyn + lds_l + lds_v : V.e;    // the refinement's
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, V.xs0, V.r0, V.j0);
+    __syncthreads();
+    SpLm st;
+    lm_state_init(st, team_sumsq(V.r0, m, s_red), o);
+    mark(0);
+    while (!st.done) {
+        const double* jc = st.cur ? V.j1 : V.j0;
+        const double* rc = st.cur ? V.r1 : V.r0;
+        if (st.need_form) {
+            team_form(B, jc, rc, V.a, V.rhs, dvec, tid, TEAM_THREADS, wave, TEAM_NWAVES);
+        } else {
+            for (uint32_t c = tid; c < nv; c += TEAM_THREADS) dvec[c] = V.rhs[c];
+        }
+        if (tid == 0) s_bad = 0;
+        __syncthreads();
+        mark(1);
+        const bool ok = team_factor_forward<LDSV, true>(B.chol, B.lrows, B.sched, 0, V.a, st.lambda, fl, dvec, s_acc);
+        if (!ok && (tid & 63) == 0) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        st.flag = s_bad;
+        __syncthreads();  // (s_bad is cleared again at the top of the next trial)
+        mark(2);
+        if (!st.flag) {
+            team_backward<LDSV>(B.chol, B.sched, 0, fl, dvec);
+            mark(3);
+            if (flags & TEAM_REFINED) {  // corrected semi-normal equations, as sp_refine_*: t = -r - J delta, (A + lambda I) e = Jt t - lambda delta
+                for (uint32_t row = tid; row < m; row += TEAM_THREADS) {
+                    double acc = -rc[row];
+                    for (uint32_t p = B.jac.jrow_ptr[row]; p < B.jac.jrow_ptr[row + 1]; ++p) acc -= jc[p] * dvec[B.jcol[p]];
+                    V.t[row] = acc;
+                }
+                __syncthreads();
+                for (uint32_t c = tid; c < nv; c += TEAM_THREADS) {
+                    double s = 0.0;
+                    for (uint32_t p = B.cptr[c]; p < B.cptr[c + 1]; ++p) s += jc[B.cidx[p]] * V.t[B.crow[p]];
+                    evec[c] = s - st.lambda * dvec[c];
+                }
+                __syncthreads();
+                team_factor_forward<LDSV, false>(B.chol, B.lrows, B.sched, 0, V.a, 0.0, fl, evec, s_acc);
+                team_backward<LDSV>(B.chol, B.sched, 0, fl, evec);
+                for (uint32_t c = tid; c < nv; c += TEAM_THREADS) dvec[c] += evec[c];
+                __syncthreads();
+                mark(4);
+            }
+            st.dn2 = team_sumsq(dvec, nv, s_red);
+            const double* xc = st.cur ? V.xs1 : V.xs0;
+            double* xt = st.cur ? V.xs0 : V.xs1;
+            for (uint32_t k = tid; k < nv; k += TEAM_THREADS) {
+                const uint32_t v = B.fvar[B.perm[k]];
+                xt[v] = xc[v] + dvec[k];
+            }
+            __syncthreads();
+            double* rt = st.cur ? V.r0 : V.r1;
+            double* jt = st.cur ? V.j0 : V.j1;
+            for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, xt, rt, jt);
+            __syncthreads();
+            st.sse_t = team_sumsq(rt, m, s_red);
+            mark(5);
+        }
+        lm_state_control(st, o);
+    }
+    team_block_epilogue(B, V, st.cur, flags, vars_base + out_off[sys], tid, TEAM_THREADS);
+    mark(6);
+    if (stamp) prof[7] += st.trials;
+    if (tid == 0) {
+        SpAccum& ac = accum[sys];
+        ac.accepted += st.accepted;
+        ac.trials += st.trials;
+        ac.exit_code = st.exit_code;
+        ac.sse0 += st.sse_start;
+        ac.sse += st.sse;
+    }
+}
+
+// ---- larger Systems: parts side by side, the top in one workgroup; five launches per trial --------------------------
+// (grid.y = System of the group; st = the System's SpLm in HBM; every kernel returns at once when its solve is over)
+__global__ __launch_bounds__(256) void spt_form_kernel(SpBlock B, SpVals V, const SpLm* __restrict__ lm) {
+    const SpLm* st = lm + blockIdx.y;
+    if (st->done) return;
+    V.shift(blockIdx.y);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+    if (st->need_form) {
+        team_form(B, st->cur ? V.j1 : V.j0, st->cur ? V.r1 : V.r0, V.a, V.rhs, V.delta, i, n, i >> 6, n >> 6);
+    } else {
+        for (uint32_t c = i; c < B.nv; c += n) V.delta[c] = V.rhs[c];
+    }
+}
+
+// which: 0 = factor + forward sweep on delta; 1 = forward sweep of the refinement on e
+__global__ __launch_bounds__(TEAM_THREADS) void spt_parts_up_kernel(SpBlock B, SpVals V, SpLm* __restrict__ lm, uint32_t which) {
+    __shared__ double s_acc[TEAM_NWAVES * 64];
+    SpLm* st = lm + blockIdx.y;
+    if (st->done || (which && st->flag)) return;
+    V.shift(blockIdx.y);
+    if (which == 0) {
+        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, blockIdx.x, V.a, st->lambda, V.l, V.delta, s_acc);
+        if (!ok && (threadIdx.x & 63) == 0) atomicOr(&st->flag, 1u);
+    } else {
+        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, blockIdx.x, V.a, 0.0, V.l, V.e, s_acc);
+    }
+}
+
+// the trial point of the columns [first, last) of list_cols: xs[cur ^ 1] = xs[cur] + delta
+__device__ __forceinline__ void team_trial_point(const SpBlock& B, const SpVals& V, uint32_t cur, uint32_t first, uint32_t last) {
+    const double* xc = cur ? V.xs1 : V.xs0;
+    double* xt = cur ? V.xs0 : V.xs1;
+    for (uint32_t t = first + threadIdx.x; t < last; t += TEAM_THREADS) {
+        const uint32_t k = B.sched.list_cols[t];
+        const uint32_t v = B.fvar[B.perm[k]];
+        xt[v] = xc[v] + V.delta[k];
+    }
+}
+__device__ __forceinline__ void team_segment_columns(const SpTeamSched& sc, uint32_t seg, uint32_t& first, uint32_t& last) {
+    first = sc.list_ptr[sc.lev_list[sc.seg_lev[seg]]];
+    last = sc.list_ptr[sc.lev_list[sc.seg_lev[seg + 1]]];
+}
+
+// the top of the tree: its factorization + forward sweep, then its backward sweep. which as above; `last` = nothing
+// follows the backward sweep of this vector but the trial point (plain step: which 0; refined step: which 1)
+__global__ __launch_bounds__(TEAM_THREADS) void spt_top_kernel(SpBlock B, SpVals V, SpLm* __restrict__ lm, uint32_t which, uint32_t last) {
+    __shared__ double s_acc[TEAM_NWAVES * 64];
+    __shared__ uint32_t s_bad;
+    SpLm* st = lm + blockIdx.y;
+    if (st->done || (which && st->flag)) return;
+    V.shift(blockIdx.y);
+    const uint32_t top = B.sched.nparts;
+    double* vec = which ? V.e : V.delta;
+    if (which == 0) {
+        if (st->flag) return;  // a part met a bad pivot
+        if (threadIdx.x == 0) s_bad = 0;
+        __syncthreads();
+        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, top, V.a, st->lambda, V.l, V.delta, s_acc);
+        if (!ok && (threadIdx.x & 63) == 0) atomicOr(&s_bad, 1u);
+        __syncthreads();
+        if (s_bad) {
+            if (threadIdx.x == 0) st->flag = 1;
+            return;
+        }
+    } else {
+        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, top, V.a, 0.0, V.l, V.e, s_acc);
+    }
+    team_backward<false>(B.chol, B.sched, top, V.l, vec);
+    uint32_t first, end;
+    team_segment_columns(B.sched, top, first, end);
+    if (which) {
+        for (uint32_t t = first + threadIdx.x; t < end; t += TEAM_THREADS) {
+            const uint32_t k = B.sched.list_cols[t];
+            V.delta[k] += V.e[k];
+        }
+        __syncthreads();
+    }
+    if (last) team_trial_point(B, V, st->cur, first, end);
+}
+
+__global__ __launch_bounds__(TEAM_THREADS) void spt_parts_down_kernel(SpBlock B, SpVals V, const SpLm* __restrict__ lm, uint32_t which, uint32_t last) {
+    const SpLm* st = lm + blockIdx.y;
+    if (st->done || st->flag) return;
+    V.shift(blockIdx.y);
+    double* vec = which ? V.e : V.delta;
+    team_backward<false>(B.chol, B.sched, blockIdx.x, V.l, vec);
+    uint32_t first, end;
+    team_segment_columns(B.sched, blockIdx.x, first, end);
+    if (which) {
+        for (uint32_t t = first + threadIdx.x; t < end; t += TEAM_THREADS) {
+            const uint32_t k = B.sched.list_cols[t];
+            V.delta[k] += V.e[k];
+        }
+        __syncthreads();
+    }
+    if (last) team_trial_point(B, V, st->cur, first, end);
+}
+
+// refined step, between the two solves: t = -r - J delta (rows), then e = Jt t - lambda delta (columns)
+__global__ __launch_bounds__(256) void spt_refine_t_kernel(SpBlock B, SpVals V, const SpLm* __restrict__ lm) {
+    const SpLm* st = lm + blockIdx.y;
+    if (st->done || st->flag) return;
+    V.shift(blockIdx.y);
+    const double* jc = st->cur ? V.j1 : V.j0;
+    const double* rc = st->cur ? V.r1 : V.r0;
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= B.m) return;
+    double acc = -rc[row];
+    for (uint32_t p = B.jac.jrow_ptr[row]; p < B.jac.jrow_ptr[row + 1]; ++p) acc -= jc[p] * V.delta[B.jcol[p]];
+    V.t[row] = acc;
+}
+__global__ __launch_bounds__(256) void spt_refine_rhs_kernel(SpBlock B, SpVals V, const SpLm* __restrict__ lm) {
+    const SpLm* st = lm + blockIdx.y;
+    if (st->done || st->flag) return;
+    V.shift(blockIdx.y);
+    const double* jc = st->cur ? V.j1 : V.j0;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B.nv) return;
+    double s = 0.0;
+    for (uint32_t p = B.cptr[c]; p < B.cptr[c + 1]; ++p) s += jc[B.cidx[p]] * V.t[B.crow[p]];
+    V.e[c] = s - st->lambda * V.delta[c];
+}
+
+// K2/K1 at the trial point; the block that finishes last adds up the squares (fixed shapes: same bits whoever it is)
+// and takes the trial's decision. start = 1: the start point of the block instead (generation 0, lm.rs:81-112).
+template <bool POSE>
+__global__ __launch_bounds__(TEAM_THREADS) void spt_eval_kernel(SpRows rows, SpBlock B, SpVals V, SpLm* __restrict__ lm,
+                                                                 uint32_t* __restrict__ tickets, fx_lm_opts o, uint32_t start) {
+    __shared__ double s_red[TEAM_THREADS];
+    __shared__ uint32_t s_last;
+    SpLm* stg = lm + blockIdx.y;
+    if (!start && stg->done) return;
+    V.shift(blockIdx.y);
+    const double* sparam = rows.sparam + (size_t)blockIdx.y * V.stride;
+    const uint32_t gen = start ? 0u : (stg->cur ^ 1u);
+    const bool bad = !start && stg->flag;
+    double* rt = gen ? V.r1 : V.r0;
+    if (!bad) {
+        const uint32_t row = blockIdx.x * TEAM_THREADS + threadIdx.x;
+        if (row < B.m) team_eval_row<POSE>(rows, sparam, B.jac, row, gen ? V.xs1 : V.xs0, rt, gen ? V.j1 : V.j0);
+    }
+    // every wavefront's stores have left, then one lane publishes for the workgroup (MI355X_MICROARCH: visibility, valid forms)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tickets[blockIdx.y] = 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    SpLm st = *stg;
+    if (start) {
+        lm_state_init(st, team_sumsq(rt, B.m, s_red), o);
+    } else {
+        if (!bad) {
+            st.dn2 = team_sumsq(V.delta, B.nv, s_red);
+            st.sse_t = team_sumsq(rt, B.m, s_red);
+        }
+        lm_state_control(st, o);
+    }
+    if (threadIdx.x == 0) *stg = st;
+}
+
+// end of a block on the two-tier path: values out, the System's sums
+__global__ __launch_bounds__(256) void spt_block_end_kernel(SpBlock B, SpVals V, const SpLm* __restrict__ lm, SpAccum* __restrict__ accum,
+                                                           uint32_t flags, double* __restrict__ vars_base, const uint64_t* __restrict__ out_off) {
+    const uint32_t sys = blockIdx.y;
+    const SpLm st = lm[sys];
+    V.shift(sys);
+    team_block_epilogue(B, V, st.cur, flags, vars_base + out_off[sys], blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SpAccum& ac = accum[sys];
+        ac.accepted += st.accepted;
+        ac.trials += st.trials;
+        ac.exit_code = st.exit_code;
+        ac.sse0 += st.sse_start;
+        ac.sse += st.sse;
+    }
+}
+
+// ---- around the blocks: start values, the closing check — one launch for the whole group -----------------------------
+// off[0..n) = first variable of the group's System k in the batch's arrays, off[n..2n) = its first expression,
+// off[2n..3n) = its index in the batch
+// start of a group solve: the Systems' start values and parameters into their slabs, the batch's output slice starts
+// as a copy of the start values, sums and tickets cleared
+__global__ void spg_begin_kernel(const double* __restrict__ vars0_base, const double* __restrict__ param_base, const uint64_t* __restrict__ off,
+                                 uint32_t n, uint32_t nvt, uint32_t net, double* __restrict__ vars0, double* __restrict__ param, size_t stride,
+                                 double* __restrict__ vars_base, SpAccum* __restrict__ accum, uint32_t* __restrict__ tickets) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, sys = blockIdx.y;
+    if (i < nvt) {
+        const double v = vars0_base[off[sys] + i];
+        vars0[(size_t)sys * stride + i] = v;
+        vars_base[off[sys] + i] = v;
+    }
+    if (i < net) param[(size_t)sys * stride + i] = param_base[off[n + sys] + i];
+    if (i == 0) {
+        accum[sys] = SpAccum{0, 0, FX_EXIT_SSE, 0, 0.0, 0.0};
+        tickets[sys] = 0;
+    }
+}
+// start of a component: the pre-solve snapshot of the working vector (quirk Q2); the component counts
+__global__ void spg_component_kernel(const double* __restrict__ xs, double* __restrict__ snap, uint32_t nvt, size_t stride,
+                                     SpAccum* __restrict__ accum) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, sys = blockIdx.y;
+    if (i < nvt) snap[(size_t)sys * stride + i] = xs[(size_t)sys * stride + i];
+    if (i == 0) {
+        accum[sys].ncomp += 1;
+        accum[sys].exit_code = FX_EXIT_SSE;
+    }
+}
+
+// post-solve check on the unscaled variables (constraints/mod.rs:96-109) and the System's result record: the sums of
+// sp_identity_residual_kernel + sp_sumsq_kernel in one workgroup per System (same order: same bits)
+template <bool POSE>
+__global__ __launch_bounds__(TEAM_THREADS) void spg_finish_kernel(SpRows rows, size_t stride, const double* __restrict__ scal,
+                                                                   const SpAccum* __restrict__ accum, const double* __restrict__ vars_base,
+                                                                   const uint64_t* __restrict__ off, uint32_t n,
+                                                                   fx_result* __restrict__ results) {
+    __shared__ double s_red[TEAM_THREADS];
+    const uint32_t sys = blockIdx.x;
+    const double* x = vars_base + off[sys];
+    const double* param = rows.param + (size_t)sys * stride;
+    double s = 0.0;
+    for (uint32_t e = threadIdx.x; e < rows.net; e += TEAM_THREADS) {
+        const int tag = rows.tag[e] & 0x7F;
+        const ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+        const uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+        uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        expand_vars<POSE>(tag, ff, vars8);
+        double v[8], g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = x[vars8[q]];
+        const double r = eval_expression<double, false, false, POSE>(tag, v, param[e], g);
+        s += r * r;
+    }
+    s = block_sum_1024(s, s_red);
+    if (threadIdx.x == 0) {
+        const SpAccum ac = accum[sys];
+        fx_result res{};
+        res.accepted = ac.accepted;
+        res.trials = ac.trials;
+        res.exit = ac.exit_code;
+        res.ncomp = ac.ncomp;
+        res.scale = scal[(size_t)sys * stride];
+        res.sse0 = ac.sse0;
+        res.sse = ac.sse;
+        res.sse_unscaled = s;
+        results[off[2 * (size_t)n + sys]] = res;
+    }
+}

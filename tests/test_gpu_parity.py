@@ -415,7 +415,9 @@ def test_refined_step_follows_the_qr_oracle_more_closely(fiksi, oracle, ctx):
 def test_refined_step_on_the_sparse_path(fiksi, oracle, ctx):
     """Systems beyond one wavefront (fx_sparse.hip) honour FX_STEP_CHOLESKY_REFINED too — it is also what FX_STEP_QR
     runs them with: on large ill-conditioned sketches the final SSE follows the oracle an order of magnitude more
-    closely than the plain normal-equation step; well-conditioned ones keep their path."""
+    closely than the plain normal-equation step did in round 2 (p90 1.9e-10 -> 1.4e-11); since round 3 the plain step
+    of this path sums shorter lists (finer nested dissection) and sits at 4e-11 itself, so the bar is: the refined step
+    is at least as close, and within 1e-9. Well-conditioned sketches keep their path."""
     from fiksi_amd import abi, workloads
 
     from helpers import random_big_sketch
@@ -428,7 +430,7 @@ def test_refined_step_on_the_sparse_path(fiksi, oracle, ctx):
         ok = np.isfinite(r["sse"]) & np.isfinite(r_o["sse"])
         d = (np.abs(r["sse"] - r_o["sse"]) / np.maximum(np.abs(r_o["sse"]), 1e-12))[ok]
         q[solver] = (float(np.median(d)), float(np.quantile(d, 0.9)), v)
-    assert q[1][1] <= 0.3 * q[0][1] and q[1][1] <= 1e-9, q
+    assert q[1][1] <= q[0][1] and q[1][1] <= 1e-9 and q[1][0] <= q[0][0], q
     assert np.array_equal(q[1][2], q[2][2])  # FX_STEP_QR == the refined step on these
     for big in (workloads.hinged_triangles(2, 64), workloads.large_sketch(300)):
         v, r = ctx.system_solve_batch(big, abi.solving_opts(solver=1))
