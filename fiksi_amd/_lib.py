@@ -134,6 +134,7 @@ SIGNATURES = [
     ("fx_timer_end", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("fx_system_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxSolvingOpts), _vp]),
     ("fx_lm_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
+    ("fx_system_solve_batch_multi", C.c_int, [C.POINTER(_vp), C.c_uint32, C.POINTER(FxBatch), C.POINTER(FxSolvingOpts), _vp, _vp]),
     ("fx_eval_residual_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp]),
     ("fx_constraint_residuals", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     ("fx_system_prepare_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp]),

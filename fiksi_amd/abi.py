@@ -235,6 +235,20 @@ class Context:
         check(lib.fx_system_solve_batch(self._h, C.byref(as_struct(a)), C.byref(o), _ptr(res)), "fx_system_solve_batch")
         return a["vars"], res
 
+    @staticmethod
+    def system_solve_batch_multi(contexts, arrays, opts: Optional[FxSolvingOpts] = None):
+        """fx_system_solve_batch_multi: one batch sharded over several contexts (one per device, or several on one
+        device), a host thread each. Returns (solved vars, results, {systems, converged, accepted, trials})."""
+        a = normalize_batch(arrays)
+        a["vars"] = a["vars"].copy()
+        res = np.zeros(len(a["var_off"]) - 1, dtype=RESULT_DTYPE)
+        o = opts if opts is not None else solving_opts()
+        handles = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+        total = (C.c_uint64 * 4)()
+        check(lib.fx_system_solve_batch_multi(handles, len(contexts), C.byref(as_struct(a)), C.byref(o), _ptr(res), total),
+              "fx_system_solve_batch_multi")
+        return a["vars"], res, dict(zip(("systems", "converged", "accepted", "trials"), (int(x) for x in total)))
+
     def lm_solve_batch(self, arrays, opts: Optional[FxLmOpts] = None):
         a = normalize_batch(arrays)
         a["vars"] = a["vars"].copy()

@@ -42,6 +42,13 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+namespace fx {
+// the builder (fx_builder.cpp) reports through the same thread-local text fx_last_error() returns
+void set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+}  // namespace fx
+namespace {
+
 #define FX_HIP(call)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \
@@ -1184,6 +1191,17 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
         for (uint32_t s = 0; s < n; ++s) index[s] = sys_first[owner(s)];
     }
     fx::QrPlans q;
+    {  // the kernel keeps a component's augmented matrix in LDS: does the largest one fit? Asked before anything is uploaded
+       // (a batch that fails here fails again on every later FX_STEP_QR solve — nothing may pile up on the device)
+        Q.max_m = max_m;
+        Q.max_h = max_h;
+        const size_t need = fx::solve_lds_bytes_qr(d, units);
+        if (need > 160u * 1024u) {
+            Q.max_m = Q.max_h = 0;
+            return fail(FX_ERR_TOO_LARGE, "FX_STEP_QR keeps the (expressions + free variables) x (free variables + 1) matrix of a component in LDS: %zu bytes needed (limit 163840)",
+                        need);
+        }
+    }
     unsigned long long* d64 = nullptr;
     int rc = dev_alloc_copy(ctx, db, &q.u16, u16.data(), u16.size());
     if (!rc) rc = dev_alloc_copy(ctx, db, &d64, reinterpret_cast<const unsigned long long*>(u64.data()), u64.size());
@@ -1197,11 +1215,6 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     q.max_h = max_h;
     q.desc = ddesc;  // set last: marks the plans as complete
     Q = q;
-    if (fx::solve_lds_bytes_qr(d, units) > 160u * 1024u) {
-        Q.desc = nullptr;
-        return fail(FX_ERR_TOO_LARGE, "FX_STEP_QR keeps the (expressions + free variables) x (free variables + 1) matrix of a component in LDS: %zu bytes needed (limit 163840)",
-                    fx::solve_lds_bytes_qr(d, units));
-    }
     return FX_OK;
 }
 
@@ -1417,74 +1430,13 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
             group_plan[g] = ctx->plan_for(std::vector<unsigned char>(groups[g].key), call_clock);
         }
     }
-    if (!(p.mode & fx::MODE_LBFGS)) {
-        // Levenberg-Marquardt: every launch covers a whole group, control flow on the device (fx_sparse_team.h)
-        for (size_t g = 0; g < groups.size(); ++g) {
-            hipError_t e = fx::sparse_solve_group(&hb, db->d, groups[g].systems.data(), (uint32_t)groups[g].systems.size(), p, ctx->stream,
-                                                  group_plan[g]);
-            if (e != hipSuccess)
-                return fail(FX_ERR_HIP, "sparse path failed on the group of system %u: %s", groups[g].systems[0], hipGetErrorString(e));
-        }
-        return FX_OK;
+    // every launch covers a whole group, control flow on the device (fx_sparse_team.h): Levenberg-Marquardt or L-BFGS
+    for (size_t g = 0; g < groups.size(); ++g) {
+        hipError_t e = fx::sparse_solve_group(&hb, db->d, groups[g].systems.data(), (uint32_t)groups[g].systems.size(), p, ctx->stream,
+                                              group_plan[g]);
+        if (e != hipSuccess)
+            return fail(FX_ERR_HIP, "sparse path failed on the group of system %u: %s", groups[g].systems[0], hipGetErrorString(e));
     }
-    // ---- Optimizer::LBfgs: one host-driven loop per System (the line search's decisions are taken on the host).
-    // A plan that is being filled belongs to one System of this call; a finished one is read-only and may serve all
-    // that share it.
-    std::vector<fx::SparsePlanCache*> plans(todo.size(), nullptr);
-    {
-        std::map<uint32_t, size_t> group_of;
-        for (size_t g = 0; g < groups.size(); ++g)
-            for (uint32_t s : groups[g].systems) group_of[s] = g;
-        std::vector<uint8_t> taken(groups.size(), 0);
-        for (size_t k = 0; k < todo.size(); ++k) {
-            const size_t g = group_of[todo[k]];
-            fx::SparsePlanCache* plan = group_plan[g];
-            plans[k] = (plan && (fx::sparse_cache_ready(plan) || !taken[g])) ? plan : nullptr;
-            taken[g] = 1;
-        }
-    }
-    auto solve_one = [&](uint32_t s, hipStream_t stream, fx::SparsePlanCache* plan) -> hipError_t {
-        fx_result res{};
-        hipError_t e = fx::sparse_solve_system(&db->h_batch, s, p, stream, db->d.vars + db->h_var_off[s], &res, plan);
-        if (e == hipSuccess) e = hipMemcpyAsync(db->d.results + s, &res, sizeof(fx_result), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        return e;
-    };
-    if (todo.size() <= 1 || ctx->host_threads <= 1u) {
-        for (size_t k = 0; k < todo.size(); ++k) {
-            hipError_t e = solve_one(todo[k], ctx->stream, plans[k]);
-            if (e != hipSuccess) return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", todo[k], hipGetErrorString(e));
-        }
-        return FX_OK;
-    }
-    // Several large Systems: each one is a host-driven loop of small launches that leaves the GPU mostly
-    // idle, so a few host threads, each with its own stream, run them side by side (Systems are
-    // independent; every result depends only on its own System, so the schedule does not show).
-    const uint32_t nt = (uint32_t)std::min<size_t>(todo.size(), std::max(1u, ctx->host_threads));
-    FX_HIP(hipStreamSynchronize(ctx->stream));  // the workers use their own streams: everything queued on ours (upload, kernels) first
-    std::atomic<uint32_t> next{0};
-    std::vector<hipError_t> err(nt, hipSuccess);
-    std::vector<uint32_t> err_sys(nt, 0);
-    std::vector<std::thread> workers;
-    for (uint32_t t = 0; t < nt; ++t) {
-        workers.emplace_back([&, t] {
-            hipError_t e = hipSetDevice(ctx->device);
-            hipStream_t stream = nullptr;
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-            while (e == hipSuccess) {
-                const uint32_t k = next.fetch_add(1);
-                if (k >= todo.size()) break;
-                e = solve_one(todo[k], stream, plans[k]);
-                if (e != hipSuccess) err_sys[t] = todo[k];
-            }
-            if (stream) (void)hipStreamDestroy(stream);
-            err[t] = e;
-        });
-    }
-    for (auto& w : workers) w.join();
-    for (uint32_t t = 0; t < nt; ++t)
-        if (err[t] != hipSuccess)
-            return fail(FX_ERR_HIP, "sparse path failed on system %u: %s", err_sys[t], hipGetErrorString(err[t]));
     return FX_OK;
 }
 }  // namespace
@@ -2101,6 +2053,70 @@ int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts
     return solve_host(ctx, batch, nullptr, opts, false, results);
 }
 
+// One batch over several devices (Systems are independent — contiguous shards, no data-path collective): one
+// host thread per context, each solving its shard with fx_system_solve_batch on its own device and stream; the
+// throughput counters are summed on the host. Shard r of n = Systems [r N / n, (r + 1) N / n) — the rule of
+// fiksi_amd/workloads.py: shard, so a result never depends on how many devices took part.
+int fx_system_solve_batch_multi(fx_ctx* const* ctxs, uint32_t n_ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results,
+                                fx_throughput* total) {
+    if (!ctxs || n_ctx == 0 || !batch) return fail(FX_ERR_INVALID, "bad argument");
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        if (!ctxs[r]) return fail(FX_ERR_INVALID, "context %u is NULL", r);
+        for (uint32_t q = 0; q < r; ++q)
+            if (ctxs[q] == ctxs[r]) return fail(FX_ERR_INVALID, "context %u is listed twice (a context is bound to one host thread)", r);
+    }
+    int rc = fx_batch_validate(batch);
+    if (rc) return rc;
+    const uint32_t n = batch->n_systems;
+    std::vector<fx_result> local;
+    if (!results) {
+        local.resize(n);
+        results = local.data();
+    }
+    std::vector<int> codes(n_ctx, FX_OK);
+    std::vector<std::string> messages(n_ctx);
+    std::vector<std::thread> workers;
+    for (uint32_t r = 0; r < n_ctx; ++r) {
+        workers.emplace_back([&, r] {
+            const uint32_t lo = (uint32_t)((uint64_t)n * r / n_ctx), hi = (uint32_t)((uint64_t)n * (r + 1) / n_ctx);
+            if (hi == lo) return;
+            const uint32_t v0 = batch->var_off[lo], e0 = batch->expr_off[lo];
+            std::vector<uint32_t> var_off(hi - lo + 1), expr_off(hi - lo + 1);
+            for (uint32_t s = lo; s <= hi; ++s) {
+                var_off[s - lo] = batch->var_off[s] - v0;
+                expr_off[s - lo] = batch->expr_off[s] - e0;
+            }
+            fx_batch sub = *batch;
+            sub.n_systems = hi - lo;
+            sub.var_off = var_off.data();
+            sub.expr_off = expr_off.data();
+            sub.vars = batch->vars + v0;  // solved in place: every shard owns its slice
+            sub.var_fixed = batch->var_fixed + v0;
+            sub.expr_tag = batch->expr_tag + e0;
+            sub.expr_idx = batch->expr_idx + 4 * (size_t)e0;
+            sub.expr_param = batch->expr_param + e0;
+            sub.var_comp = batch->var_comp ? batch->var_comp + v0 : nullptr;
+            sub.expr_comp = batch->expr_comp ? batch->expr_comp + e0 : nullptr;
+            codes[r] = fx_system_solve_batch(ctxs[r], &sub, opts, results + lo);
+            if (codes[r]) messages[r] = fx_last_error();  // (thread-local: carried over to the caller below)
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (uint32_t r = 0; r < n_ctx; ++r)
+        if (codes[r]) return fail(codes[r], "shard %u of %u: %s", r, n_ctx, messages[r].c_str());
+    if (total) {
+        fx_throughput t{};
+        t.systems = n;
+        for (uint32_t s = 0; s < n; ++s) {
+            t.converged += results[s].sse_unscaled < 1e-4 ? 1u : 0u;  // fiksi_bench.rs:65-72
+            t.accepted += results[s].accepted;
+            t.trials += results[s].trials;
+        }
+        *total = t;
+    }
+    return FX_OK;
+}
+
 // ---- Decomposer::RecursiveAssembly: the device work around the host plan of fx_recursive.h -------------------
 
 int fx_system_prepare_batch(fx_ctx* ctx, const fx_batch* batch, uint32_t perturb, double* out_vars, double* out_params,
@@ -2154,10 +2170,13 @@ int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses,
     if (rc) return rc;
     if (n_points == 0) return FX_OK;
     if (!poses || !pose_of || !var_idx || !vars) return fail(FX_ERR_INVALID, "bad argument");
-    for (uint32_t i = 0; i < n_points; ++i) {
-        if (pose_of[i] >= n_poses || (uint64_t)var_idx[i] + 1u >= n_vars) return fail(FX_ERR_INVALID, "point %u out of range", i);
-        for (uint32_t j = 0; j < i; ++j)
-            if (var_idx[j] == var_idx[i]) return fail(FX_ERR_INVALID, "point %u is listed twice", i);
+    {
+        std::vector<uint8_t> touched(n_vars, 0);  // points are moved in place, side by side: no variable may belong to two of them
+        for (uint32_t i = 0; i < n_points; ++i) {
+            if (pose_of[i] >= n_poses || (uint64_t)var_idx[i] + 1u >= n_vars) return fail(FX_ERR_INVALID, "point %u out of range", i);
+            if (touched[var_idx[i]] || touched[var_idx[i] + 1u]) return fail(FX_ERR_INVALID, "point %u overlaps an earlier point", i);
+            touched[var_idx[i]] = touched[var_idx[i] + 1u] = 1;
+        }
     }
     fx_dbatch scratch;  // owns the device blocks of this call
     double *d_poses = nullptr, *d_vars = nullptr;
@@ -2284,12 +2303,16 @@ void fx_atan2_cr_batch(uint64_t n, const double* y, const double* x, double* out
 int fx_qr_symbolic(int32_t nrows, int32_t ncols, const int32_t* colptr, const int32_t* rowidx, int use_colamd,
                    int32_t* col_perm, int32_t* row_perm, int32_t* h_ptr, int32_t* h_rows, int32_t h_cap, int32_t* r_ptr,
                    int32_t* r_rows, int32_t r_cap) {
-    if (nrows < 0 || ncols < 0 || !colptr || (colptr[ncols] > 0 && !rowidx)) return fail(FX_ERR_INVALID, "bad argument");
+    if (nrows < 0 || ncols < 0 || !colptr) return fail(FX_ERR_INVALID, "bad argument");
+    if (colptr[0] != 0) return fail(FX_ERR_INVALID, "colptr[0] must be 0");
+    for (int32_t j = 0; j < ncols; ++j)
+        if (colptr[j + 1] < colptr[j]) return fail(FX_ERR_INVALID, "colptr must not decrease (column %d)", j);
+    if (colptr[ncols] > 0 && !rowidx) return fail(FX_ERR_INVALID, "rowidx is NULL");
     fx::qr::Csc a;
     a.nrows = nrows;
     a.ncols = ncols;
     a.ptr.assign(colptr, colptr + ncols + 1);
-    a.idx.assign(rowidx, rowidx + colptr[ncols]);
+    if (colptr[ncols] > 0) a.idx.assign(rowidx, rowidx + colptr[ncols]);
     fx::qr::Symbolic sy;
     if (!fx::qr::analyze(a, use_colamd != 0, sy)) return fail(FX_ERR_INVALID, "malformed or structurally rank-deficient pattern");
     if ((h_rows && (int64_t)sy.hrows.size() > h_cap) || (r_rows && (int64_t)sy.rrows.size() > r_cap))

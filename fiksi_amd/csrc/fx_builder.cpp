@@ -14,9 +14,16 @@
 #include "../../include/fiksi_amd_builder.h"
 #include "fx_recursive.h"
 
+namespace fx {
+void set_last_error(const char* msg);  // fx_abi.cpp (fx_host_only.cpp in the sanitizer build): the text of fx_last_error()
+}
+
 namespace {
 
-int bfail(int code, const char*) { return code; }  // messages surface through the mirrors' exceptions
+int bfail(int code, const char* msg) {
+    fx::set_last_error(msg);
+    return code;
+}
 
 // EncodedElement, fiksi/src/lib.rs:123-128
 struct Element {
@@ -534,11 +541,14 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
         std::vector<uint32_t> els(comp->elements.begin(), comp->elements.end());
         std::vector<uint32_t> cons(comp->constraints.begin(), comp->constraints.end());
         const fx::ra::Plan plan = fx::ra::make_plan(graph, els, cons, o.plan_budget ? (uint64_t)o.plan_budget * 1000u : kDefaultPlanBudget);
-        if (plan.panicked || plan.exhausted) return FX_ERR_UNSUPPORTED;
+        if (plan.panicked)
+            return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: the reference's planner would panic on this sketch (recursive_assembly.rs:357-375); System untouched");
+        if (plan.exhausted) return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: the plan search ran out of its budget (fx_solving_opts.plan_budget); System untouched");
 
         for (const fx::ra::Step& step : plan.steps) {
             const fx::ra::ClusterProblem cp = fx::ra::make_cluster_problem(step, is_point);
-            if (cp.panicked) return FX_ERR_UNSUPPORTED;
+            if (cp.panicked)
+                return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: a step's expression names a variable hidden inside a contracted cluster (assemble/mod.rs:505-509); System untouched");
 
             // unknowns: the poses, then the members' variables (assemble/mod.rs:431-474); constants: the points as
             // solved so far, one pair per pose row pair
@@ -560,7 +570,7 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
             for (size_t ci = 0; ci < cp.clusters.size(); ++ci) {  // pose rows come first (:547-588)
                 for (uint32_t point : cp.clusters[ci].second) {
                     const uint32_t g = s->elements[point].a;
-                    if (local[g] < 0) return FX_ERR_UNSUPPORTED;
+                    if (local[g] < 0) return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: a cluster row names a variable outside its cluster problem; System untouched");
                     const uint32_t was = (uint32_t)x.size();
                     x.push_back(vt[g]);
                     x.push_back(vt[g + 1]);
@@ -582,7 +592,7 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
                     for (int k = 0; k < 4; ++k) {
                         uint32_t m = 0;
                         if (k < expr_fields(ex.tag)) {
-                            if (local[ex.idx[k]] < 0) return FX_ERR_UNSUPPORTED;  // the reference panics (`.unwrap()`, :505-509)
+                            if (local[ex.idx[k]] < 0) return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: a step's expression names a variable hidden inside a contracted cluster; System untouched");  // the reference panics (`.unwrap()`, :505-509)
                             m = (uint32_t)local[ex.idx[k]];
                         }
                         idx.push_back(m);

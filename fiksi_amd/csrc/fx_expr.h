@@ -5,7 +5,8 @@
 // operation order follows the reference formula by formula, and this file is compiled with
 // -ffp-contract=off, so that for f64 every residual and partial is bit-identical to the reference
 // arithmetic (sqrt and division are correctly rounded on gfx950); the only ulp-level difference
-// is atan2 (device libm vs the host's) in the two angle variants' residuals.
+// is atan2 in the two angle variants' residuals: the device libm's (<= 1 ulp) in K1 and the normal-equation
+// kernels, the correctly rounded atan2_cr (fx_atan2.h, CR = true) in the FX_STEP_QR kernels.
 #pragma once
 #ifdef FX_HOST_ONLY
 #include "fx_hip_shim.h"

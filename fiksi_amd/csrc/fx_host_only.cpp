@@ -29,9 +29,6 @@ hipError_t launch_analyze(const DeviceBatch&, const double*, uint32_t, uint32_t,
 SparsePlanCache* sparse_cache_new() { return nullptr; }
 void sparse_cache_free(SparsePlanCache*) {}
 bool sparse_cache_ready(const SparsePlanCache*) { return false; }
-hipError_t sparse_solve_system(const fx_batch*, uint32_t, const LmParams&, hipStream_t, double*, fx_result*, SparsePlanCache*) {
-    return hipErrorNoDevice;
-}
 hipError_t sparse_solve_group(const fx_batch*, const DeviceBatch&, const uint32_t*, uint32_t, const LmParams&, hipStream_t, SparsePlanCache*) {
     return hipErrorNoDevice;
 }

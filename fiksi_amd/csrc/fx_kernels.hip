@@ -12,6 +12,7 @@
 // Compiled with -ffp-contract=off: products and sums stay separate exactly as in the reference;
 // fused multiply-adds are written explicitly (fma) where the algorithm is ours (Cholesky).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <atomic>
 #include <stdint.h>
 
@@ -1176,7 +1177,9 @@ __device__ __forceinline__ uint32_t compute_slots(int tag, const uint16_t f[4], 
     return slots;
 }
 
-template <bool WANT_J>
+// NT: the results leave with non-temporal stores (the shipped form). NT = false exists for the A / B measurement only
+// (FIKSI_AMD_K1_STORES=plain, tools/k1_stores_ab.py).
+template <bool WANT_J, bool NT = true>
 __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x) {
     // Block = 256 consecutive rows. Threads take the block's rows in tag-sorted order (host-built
     // permutation) so that a wavefront sees as few expression kinds as possible (divergence: the
@@ -1270,7 +1273,10 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
     }
     __syncthreads();
     // results are written once and not read back by this kernel: streaming (non-temporal) stores
-    if (live) __builtin_nontemporal_store(rstage[threadIdx.x], &b.resid[row0 + threadIdx.x]);
+    if (live) {
+        if (NT) __builtin_nontemporal_store(rstage[threadIdx.x], &b.resid[row0 + threadIdx.x]);
+        else b.resid[row0 + threadIdx.x] = rstage[threadIdx.x];
+    }
     if (WANT_J) {
         // 16-byte stores on the 16-byte-aligned body of [jbase, jend), scalar head / tail
         const uint32_t n = bi.jcount;
@@ -1282,7 +1288,8 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
         for (uint32_t i = threadIdx.x; i < pairs; i += 256u) {
             typedef double v2d __attribute__((ext_vector_type(2)));
             v2d t = {jstage[head + 2 * i], jstage[head + 2 * i + 1]};
-            __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(dst + i));
+            if (NT) __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(dst + i));
+            else *reinterpret_cast<v2d*>(dst + i) = t;
         }
         if (((n - min(n, head)) & 1u) && threadIdx.x == 1) b.jvals[jend - 1] = jstage[n - 1];
     }
@@ -1542,13 +1549,17 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
         return units ? launch_solve_t<double, true, 1>(b, p, stream) : launch_solve_t<double, false, 1>(b, p, stream);
     }
     if (units) {
+        // Systems beyond one wavefront: the f64 walker; reference numerics stop at one wavefront, they take the refined step
+        // (as fx_step_solver documents)
+        LmParams pg = p;
+        if (pg.lm.solver == FX_STEP_QR) pg.lm.solver = FX_STEP_CHOLESKY_REFINED;
         if (p.lm.precision == 32) {
             hipError_t e = grouped_applies(b, p) ? launch_solve_grouped(b, p, stream) : launch_solve_t<float, true, 0>(b, p, stream);
-            if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);  // Systems beyond one wavefront: the f64 walker
+            if (e == hipSuccess && b.n_g) e = launch_solve_global(b, pg, stream);
             return e;
         }
         hipError_t e = grouped_applies(b, p) ? launch_solve_grouped(b, p, stream) : launch_solve_t<double, true, 0>(b, p, stream);
-        if (e == hipSuccess && b.n_g) e = launch_solve_global(b, p, stream);
+        if (e == hipSuccess && b.n_g) e = launch_solve_global(b, pg, stream);
         return e;
     }
     // components of at most 32 free variables: several Systems per wavefront (fx_grouped.hip)
@@ -1559,7 +1570,13 @@ hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t str
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream) {
     if (b.n_exprs == 0) return hipSuccess;
     dim3 grid((b.n_exprs + 255u) / 256u), block(256);
-    if (want_jacobian) {
+    static const bool plain_stores = [] {
+        const char* s = getenv("FIKSI_AMD_K1_STORES");
+        return s && s[0] == 'p';
+    }();
+    if (want_jacobian && plain_stores) {
+        hipLaunchKernelGGL((eval_rows_kernel<true, false>), grid, block, 0, stream, b, x);
+    } else if (want_jacobian) {
         hipLaunchKernelGGL(eval_rows_kernel<true>, grid, block, 0, stream, b, x);
     } else {
         hipLaunchKernelGGL(eval_rows_kernel<false>, grid, block, 0, stream, b, x);

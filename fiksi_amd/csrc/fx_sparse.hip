@@ -182,70 +182,7 @@ struct SpJac {                   // J of one component (device)
                                  // 1 = the last one wins (dense J of L-BFGS, expressions.rs:993-1008) — quirk Q4
 };
 
-// K1/K2 for one component: thread per row (subsystem.rs:93-166).
-template <bool WANT_J, bool POSE = false>
-__global__ __launch_bounds__(256) void sp_eval_kernel(SpRows rows, SpJac jac, const double* __restrict__ xs,
-                                                      double* __restrict__ r, double* __restrict__ jvals) {
-    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= jac.m) return;
-    uint32_t e = jac.rows[row];
-    int tag = rows.tag[e] & 0x7F;
-    ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
-    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars<POSE>(tag, ff, vars8);
-    double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = xs[vars8[q]];
-    r[row] = eval_expression<double, WANT_J, false, POSE>(tag, v, rows.sparam[e], g);
-    if (WANT_J) {
-        uint32_t slots = jac.jslot[row];
-        uint32_t base = jac.jrow_ptr[row];
-        uint32_t cnt = jac.jrow_ptr[row + 1] - base;
-        double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint32_t sl = (slots >> (4 * q)) & 0xFu;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (jac.overwrite) out[t] = (sl == (uint32_t)t) ? g[q] : out[t];
-                else out[t] += (sl == (uint32_t)t) ? g[q] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if ((uint32_t)t < cnt) jvals[base + t] = out[t];
-        }
-    }
-}
-
-// out[0] = sum v[i]^2 (fixed-shape tree: deterministic)
-__global__ __launch_bounds__(1024) void sp_sumsq_kernel(const double* __restrict__ v, uint32_t n, double* __restrict__ out) {
-    __shared__ double part[1024];
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += v[i] * v[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = part[0];
-}
-
-// K3b: b[c] = -sum_{rows of column c} J * r   (permuted column order)
-template <bool NEGATE>
-__global__ void sp_rhs_kernel(const uint32_t* __restrict__ cptr, const uint32_t* __restrict__ cidx,
-                              const uint32_t* __restrict__ crow, const double* __restrict__ jvals,
-                              const double* __restrict__ r, uint32_t nv, double* __restrict__ b) {
-    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nv) return;
-    double s = 0.0;
-    for (uint32_t p = cptr[c]; p < cptr[c + 1]; ++p) s += jvals[cidx[p]] * (NEGATE ? -r[crow[p]] : r[crow[p]]);
-    b[c] = s;
-}
-
-// ---- Optimizer::LBfgs on one large block: vectors in (permuted) column space, one workgroup ----------
+// sum over the 1024 threads of a workgroup: a fixed binary tree (deterministic); every thread gets the result
 __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
     sh[threadIdx.x] = v;
     __syncthreads();
@@ -256,84 +193,6 @@ __device__ __forceinline__ double block_sum_1024(double v, double* sh) {
     double out = sh[0];
     __syncthreads();
     return out;
-}
-
-// out[0] = sum a_i b_i (fixed-shape tree: deterministic)
-__global__ __launch_bounds__(1024) void sp_dot_kernel(const double* __restrict__ a, const double* __restrict__ b, uint32_t n,
-                                                      double* __restrict__ out) {
-    __shared__ double sh[1024];
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) s += a[i] * b[i];
-    s = block_sum_1024(s, sh);
-    if (threadIdx.x == 0) out[0] = s;
-}
-
-__global__ void sp_scaled_copy_kernel(const double* __restrict__ x, double alpha, uint32_t n, double* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = alpha * x[i];
-}
-
-// The two-loop recursion (lbfgs.rs:86-139) for iteration k: dir = -H_k grad, with the reference's ring
-// indexing (k + i) % 5 (unwritten slots are zero) and the gamma scaling from the previous pair.
-__global__ __launch_bounds__(1024) void sp_lbfgs_direction_kernel(uint32_t k, uint32_t n, const double* __restrict__ S,
-                                                                 const double* __restrict__ Y, const double* __restrict__ rho,
-                                                                 const double* __restrict__ grad, double* __restrict__ dir) {
-    __shared__ double sh[1024];
-    const uint32_t hl = k < 5u ? k : 5u;
-    double alpha[5] = {0., 0., 0., 0., 0.};
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) dir[i] = grad[i];
-    __syncthreads();
-    for (int i = 4; i >= 0; --i) {
-        if ((uint32_t)i >= hl) continue;
-        const uint32_t h = (k + (uint32_t)i) % 5u;
-        double part = 0.0;
-        for (uint32_t j = threadIdx.x; j < n; j += 1024) part += S[(size_t)h * n + j] * dir[j];
-        alpha[i] = rho[h] * block_sum_1024(part, sh);
-        for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] -= alpha[i] * Y[(size_t)h * n + j];
-        __syncthreads();
-    }
-    if (k > 0) {
-        const uint32_t h = (k - 1u) % 5u;
-        double p1 = 0.0, p2 = 0.0;
-        for (uint32_t j = threadIdx.x; j < n; j += 1024) {
-            double yv = Y[(size_t)h * n + j];
-            p1 += S[(size_t)h * n + j] * yv;
-            p2 += yv * yv;
-        }
-        double s_dot_y = block_sum_1024(p1, sh), y_dot_y = block_sum_1024(p2, sh);
-        if (y_dot_y > 0.) {
-            double scale = s_dot_y / y_dot_y;
-            for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] *= scale;
-        }
-        __syncthreads();
-    }
-    for (int i = 0; i < 5; ++i) {
-        if ((uint32_t)i >= hl) continue;
-        const uint32_t h = (k + (uint32_t)i) % 5u;
-        double part = 0.0;
-        for (uint32_t j = threadIdx.x; j < n; j += 1024) part += Y[(size_t)h * n + j] * dir[j];
-        double beta = rho[h] * block_sum_1024(part, sh);
-        for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] += S[(size_t)h * n + j] * (alpha[i] - beta);
-        __syncthreads();
-    }
-    for (uint32_t j = threadIdx.x; j < n; j += 1024) dir[j] *= -1.;
-}
-
-// s_k = step * dir, y_k = grad - (old gradient parked in Y[h]), rho_k = 1 / s_k.y_k   (lbfgs.rs:168-180)
-__global__ __launch_bounds__(1024) void sp_lbfgs_update_kernel(uint32_t h, uint32_t n, double step, const double* __restrict__ dir,
-                                                              const double* __restrict__ grad, double* __restrict__ S,
-                                                              double* __restrict__ Y, double* __restrict__ rho) {
-    __shared__ double sh[1024];
-    double part = 0.0;
-    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
-        double sk = step * dir[j];
-        double yk = grad[j] - Y[(size_t)h * n + j];
-        S[(size_t)h * n + j] = sk;
-        Y[(size_t)h * n + j] = yk;
-        part += sk * yk;
-    }
-    double s_dot_y = block_sum_1024(part, sh);
-    if (threadIdx.x == 0) rho[h] = 1.0 / s_dot_y;
 }
 
 struct SpChol {                  // symbolic factor (device)
@@ -360,47 +219,6 @@ struct SpRowsOfL {               // L by rows (strictly lower part), for the for
     const uint32_t* ridx;        // index of the entry in L's value array
     const uint32_t* rcol;        // its column
 };
-
-// trial point: xs_dst[fvar[perm[k]]] = xs_src[...] + delta[k]
-__global__ void sp_trial_kernel(const uint32_t* __restrict__ fvar, const uint32_t* __restrict__ perm, uint32_t nv,
-                                const double* __restrict__ delta, const double* __restrict__ xs_src,
-                                double* __restrict__ xs_dst) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nv) return;
-    uint32_t vi = fvar[perm[k]];
-    xs_dst[vi] = xs_src[vi] + delta[k];
-}
-
-__global__ void sp_copy_free_kernel(const uint32_t* __restrict__ fvar, uint32_t nv, const double* __restrict__ src,
-                                    double* __restrict__ dst) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nv) dst[fvar[k]] = src[fvar[k]];
-}
-
-// assemble/mod.rs:161-166
-__global__ void sp_writeback_kernel(const uint32_t* __restrict__ fvar, uint32_t nv, const double* __restrict__ xs,
-                                    const double* __restrict__ scal, int do_scale, double* __restrict__ vars_out) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nv) return;
-    uint32_t vi = fvar[k];
-    vars_out[vi] = do_scale ? scal[0] * xs[vi] : xs[vi];
-}
-
-// residual of every expression on unscaled variables (constraints/mod.rs:96-109)
-template <bool POSE = false>
-__global__ void sp_identity_residual_kernel(SpRows rows, const double* __restrict__ x, double* __restrict__ out) {
-    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rows.net) return;
-    int tag = rows.tag[e] & 0x7F;
-    ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
-    uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-    uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    expand_vars<POSE>(tag, ff, vars8);
-    double v[8], g[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = x[vars8[q]];
-    out[e] = eval_expression<double, false, false, POSE>(tag, v, rows.param[e], g);
-}
 
 #include "fx_sparse_team.h"
 
@@ -712,7 +530,7 @@ void trace_block(const BlockOnDevice& blk, uint32_t trials, double ms) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// host: Levenberg-Marquardt for a group of Systems of ONE structure, everything on the device
+// host: a group of Systems of ONE structure — Levenberg-Marquardt or L-BFGS, everything on the device
 // ------------------------------------------------------------------------------------------------
 hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uint32_t* systems, uint32_t n_sys, const LmParams& prm,
                               hipStream_t stream, SparsePlanCache* cache) {
@@ -731,7 +549,8 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     const uint32_t nvt = b->var_off[s0 + 1] - b->var_off[s0], net = b->expr_off[s0 + 1] - b->expr_off[s0];
     const fx_lm_opts o = prm.lm;
     const int do_scale = (prm.mode & 1u) ? 1 : 0;
-    const bool refined = o.solver != FX_STEP_CHOLESKY;  // (FX_STEP_QR beyond one wavefront: the refined step)
+    const bool lbfgs = (prm.mode & MODE_LBFGS) != 0;
+    const bool refined = !lbfgs && o.solver != FX_STEP_CHOLESKY;  // (FX_STEP_QR beyond one wavefront: the refined step)
 
     // ---- the value slab of one System, in doubles; System k of the group starts k * stride further
     auto pad = [](size_t n) { return (n + 15) & ~size_t(15); };
@@ -743,8 +562,10 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     };
     const size_t o_vars0 = take(nvt), o_xs0 = take(nvt), o_xs1 = take(nvt), o_snap = take(nvt), o_param = take(net), o_sparam = take(net),
                  o_scal = take(16), o_r0 = take(cache->max_m), o_r1 = take(cache->max_m), o_j0 = take(cache->max_nnz_j),
-                 o_j1 = take(cache->max_nnz_j), o_a = take(cache->max_nnz_a), o_l = take(cache->max_nnz_l), o_rhs = take(cache->max_nv),
-                 o_delta = take(cache->max_nv), o_t = take(refined ? cache->max_m : 0), o_e = take(refined ? cache->max_nv : 0);
+                 o_j1 = take(cache->max_nnz_j), o_a = take(std::max(cache->max_nnz_a, cache->max_nv)), o_l = take(lbfgs ? 0 : cache->max_nnz_l),
+                 o_rhs = take(cache->max_nv), o_delta = take(cache->max_nv), o_t = take(refined ? cache->max_m : 0),
+                 o_e = take(refined ? cache->max_nv : 0), o_hs = take(lbfgs ? 5 * (size_t)cache->max_nv : 0),
+                 o_hy = take(lbfgs ? 5 * (size_t)cache->max_nv : 0);
     const size_t stride = at;
 
     // the group in slices that fit a bounded slab (1 GiB)
@@ -776,7 +597,7 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         SpVals V{};
         V.xs0 = slab + o_xs0; V.xs1 = slab + o_xs1; V.snap = slab + o_snap; V.r0 = slab + o_r0; V.r1 = slab + o_r1;
         V.j0 = slab + o_j0; V.j1 = slab + o_j1; V.a = slab + o_a; V.l = slab + o_l; V.rhs = slab + o_rhs; V.delta = slab + o_delta;
-        V.t = slab + o_t; V.e = slab + o_e; V.scal = slab + o_scal;
+        V.t = slab + o_t; V.e = slab + o_e; V.scal = slab + o_scal; V.hs = slab + o_hs; V.hy = slab + o_hy;
         V.stride = stride;
         double* d_vars0 = slab + o_vars0;
 
@@ -799,8 +620,13 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                 const uint32_t flags = (refined ? TEAM_REFINED : 0u) | (single_pass ? TEAM_SINGLE_PASS : 0u) | (do_scale ? TEAM_SCALE : 0u);
                 const auto t_lm0 = std::chrono::steady_clock::now();
                 // one workgroup per System runs the whole loop; a lone large System is spread over the chip instead
-                const bool two_tier = blk.has_parts && n < TEAM_PARTS_MAX_GROUP;
-                if (!two_tier) {
+                const bool two_tier = !lbfgs && blk.has_parts && n < TEAM_PARTS_MAX_GROUP;
+                if (lbfgs) {  // Optimizer::LBfgs: the whole optimizer in one launch as well, line search included
+                    if (rows.has_pose)
+                        hipLaunchKernelGGL(sp_lbfgs_team_kernel<true>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, blk.dev, V, d_accum, flags, d.vars, d_off);
+                    else
+                        hipLaunchKernelGGL(sp_lbfgs_team_kernel<false>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, blk.dev, V, d_accum, flags, d.vars, d_off);
+                } else if (!two_tier) {
                     unsigned long long* d_prof = nullptr;
                     if (team_prof) {
                         d_prof = pool.alloc<unsigned long long>(8);
@@ -859,7 +685,7 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                     hipLaunchKernelGGL(spt_block_end_kernel, grid_for2(std::max(B.nv, 1u), n), dim3(256), 0, stream, B, V, d_lm, d_accum, flags, d.vars, d_off);
                     if (trace) trace_block(blk, h_lm[0].trials, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lm0).count());
                 }
-                if (trace && !two_tier) {
+                if (trace && (lbfgs || !two_tier)) {
                     (void)hipStreamSynchronize(stream);
                     trace_block(blk, 0, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lm0).count());
                 }
@@ -875,216 +701,6 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
-}
-
-// ------------------------------------------------------------------------------------------------
-// host: Optimizer::LBfgs for one System (all of its components); the line search's decisions on the host
-// ------------------------------------------------------------------------------------------------
-hipError_t sparse_solve_system(const fx_batch* b, uint32_t s, const LmParams& prm, hipStream_t stream,
-                               double* d_vars_out /* device, n_vars of the System */, fx_result* result,
-                               SparsePlanCache* cache) {
-    std::unique_ptr<SparsePlanCache> local;
-    if (!cache) {
-        local.reset(new SparsePlanCache());
-        cache = local.get();
-    }
-    const bool single_pass = (prm.mode & MODE_UNITS) != 0;
-    const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;  // diagnostics on stderr
-    hipError_t e = ensure_plan(b, s, single_pass, stream, cache);
-    if (e != hipSuccess) return e;
-    const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
-    const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
-    const int do_scale = (prm.mode & 1u) ? 1 : 0;
-    Arena arena;  // (several Systems may share a finished plan from different host threads: values are per call)
-    Pool pool(&arena);
-    pool.stream = stream;
-
-    // ---- System-wide device data
-    std::vector<uint8_t> tags(b->expr_tag + e0, b->expr_tag + e0 + net);
-    std::vector<uint16_t> idx16(4 * (size_t)net);
-    for (size_t q = 0; q < idx16.size(); ++q) idx16[q] = (uint16_t)b->expr_idx[4 * (size_t)e0 + q];
-    std::vector<double> params(b->expr_param + e0, b->expr_param + e0 + net);
-    std::vector<double> vars0(b->vars + v0, b->vars + v0 + nvt);
-    SpRows rows;
-    rows.tag = pool.up(tags);
-    rows.idx = pool.up(idx16);
-    rows.param = pool.up(params);
-    rows.sparam = pool.alloc<double>(net);
-    rows.net = net;
-    rows.has_pose = 0;
-    for (uint8_t t : tags)
-        if ((t & 0x7F) >= FX_TAG_POSE_X) rows.has_pose = 1;
-    double* d_vars0 = pool.up(vars0);
-    double* d_xs[2] = {pool.alloc<double>(nvt), pool.alloc<double>(nvt)};
-    double* d_snap = pool.alloc<double>(nvt);  // pre-solve snapshot (quirk Q2)
-    double* d_scal = pool.alloc<double>(8);       // scale, 1/scale, sse, dn2, sse_unscaled
-    double* d_runs = pool.alloc<double>(std::max(net, 1u));
-    if (pool.err != hipSuccess) return pool.err;
-
-    hipLaunchKernelGGL(sp_scale_kernel, dim3(1), dim3(256), 0, stream, d_vars0, nvt, rows, d_scal, do_scale, size_t(0));
-    hipLaunchKernelGGL(sp_init_kernel, grid_for(std::max(nvt, net)), dim3(256), 0, stream, d_vars0, nvt, rows, d_scal,
-                       d_xs[0], d_xs[1], do_scale, size_t(0));
-    e = hipMemcpyAsync(d_vars_out, d_vars0, nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return e;
-
-    fx_result res{};
-    res.exit = FX_EXIT_SSE;
-    uint32_t rng = 42u;  // Rng::from_seed(42), shared by the components (:47)
-    double host3[4];
-
-    for (const CompOnDevice& comp : cache->comps) {
-        // ---- the component's perturbation (:91-111), before any of its blocks
-        if (prm.mode & 2u) {
-            if (comp.nfv) hipLaunchKernelGGL(sp_perturb_kernel, grid_for(comp.nfv), dim3(256), 0, stream, comp.d_fvar, comp.nfv, rng, d_xs[0], d_xs[1], size_t(0));
-            for (uint32_t k = 0; k < 2 * comp.nfv; ++k) rng = rng * 1664525u + 1013904223u;  // integer bookkeeping only
-        }
-        e = hipMemcpyAsync(d_snap, d_xs[0], nvt * sizeof(double), hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) return e;
-        res.ncomp += 1;
-        res.exit = FX_EXIT_SSE;
-
-        for (uint32_t u = 0; u < comp.n_blocks; ++u) {
-        Pool pool(&arena);  // device memory of this block only
-        pool.stream = stream;
-        const BlockOnDevice* blk = cache->blocks[comp.first_block + u].get();
-        const ComponentPlan& P = blk->P;
-        const uint32_t m = P.m, nv = P.nv;
-        const uint32_t* d_fvar = blk->dev.fvar;
-        const uint32_t* d_perm = blk->dev.perm;
-        SpJac jac = blk->dev.jac;
-        jac.overwrite = 1;  // the dense Jacobian of L-BFGS: a later entry of a column overwrites (quirk Q4)
-        const uint32_t* d_cptr = blk->dev.cptr;
-        const uint32_t* d_cidx = blk->dev.cidx;
-        const uint32_t* d_crow = blk->dev.crow;
-        const auto t_plan1 = std::chrono::steady_clock::now();
-        double* d_r[2] = {pool.alloc<double>(m), pool.alloc<double>(m)};
-        double* d_j[2] = {pool.alloc<double>(P.nnz_j), pool.alloc<double>(P.nnz_j)};
-        double* d_delta = pool.alloc<double>(nv);
-        if (pool.err != hipSuccess) return pool.err;
-
-        auto eval = [&](int buf, double* sse_out) -> hipError_t {
-            if (m) hipLaunchKernelGGL((rows.has_pose ? sp_eval_kernel<true, true> : sp_eval_kernel<true, false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[buf], d_r[buf], d_j[buf]);
-            hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[buf], m, d_scal + 2);
-            hipError_t er = hipMemcpyAsync(sse_out, d_scal + 2, sizeof(double), hipMemcpyDeviceToHost, stream);
-            if (er == hipSuccess) er = hipStreamSynchronize(stream);
-            return er;
-        };
-        double sse = 0.0;
-        e = eval(0, &sse);
-        if (e != hipSuccess) return e;
-        const double sse_start = sse;
-        uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
-        {
-            // ---- Optimizer::LBfgs (lbfgs.rs:20-193): the host runs the line-search state machine on two
-            // scalars per evaluation, everything else is on the device
-            double* d_grad = pool.alloc<double>(nv);
-            double* d_dir = pool.alloc<double>(nv);
-            double* d_s = pool.alloc<double>(5 * (size_t)nv);
-            double* d_y = pool.alloc<double>(5 * (size_t)nv);
-            double* d_rho = pool.alloc<double>(8);
-            if (pool.err != hipSuccess) return pool.err;
-            e = hipMemsetAsync(d_s, 0, 5 * (size_t)nv * sizeof(double), stream);
-            if (e == hipSuccess) e = hipMemsetAsync(d_y, 0, 5 * (size_t)nv * sizeof(double), stream);
-            if (e == hipSuccess) e = hipMemsetAsync(d_rho, 0, 8 * sizeof(double), stream);
-            if (e != hipSuccess) return e;
-            auto gradient = [&](int buf) {
-                if (nv) hipLaunchKernelGGL(sp_rhs_kernel<false>, grid_for(nv), dim3(256), 0, stream, d_cptr, d_cidx, d_crow, d_j[buf],
-                                           d_r[buf], nv, d_grad);
-            };
-            trials = 1;
-            double prev = sse;
-            if (!(prev == prev)) {
-                exit_code = FX_EXIT_NAN;
-            } else if (prev < LbfgsConst::START_THRESHOLD) {
-                exit_code = FX_EXIT_SSE;
-            } else {
-                gradient(0);
-                for (uint32_t k = 0; k < LbfgsConst::MAX_ITERATIONS; ++k) {
-                    const uint32_t h = k % 5u;
-                    hipLaunchKernelGGL(sp_lbfgs_direction_kernel, dim3(1), dim3(1024), 0, stream, k, nv, d_s, d_y, d_rho, d_grad, d_dir);
-                    e = hipMemcpyAsync(d_y + (size_t)h * nv, d_grad, nv * sizeof(double), hipMemcpyDeviceToDevice, stream);
-                    if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(sp_dot_kernel, dim3(1), dim3(1024), 0, stream, d_grad, d_dir, nv, d_scal + 6);
-                    e = hipMemcpyAsync(host3, d_scal + 6, sizeof(double), hipMemcpyDeviceToHost, stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-                    if (e != hipSuccess) return e;
-                    HzMachine hz;
-                    double step = hz.start(prev, host3[0]);
-                    HzParam acc_pt{0., 0., 0.};
-                    for (;;) {  // calculate_phi (lbfgs.rs:270-284): xs[1] = xs[0] + step * dir
-                        if (nv) {
-                            hipLaunchKernelGGL(sp_scaled_copy_kernel, grid_for(nv), dim3(256), 0, stream, d_dir, step, nv, d_delta);
-                            hipLaunchKernelGGL(sp_trial_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, d_perm, nv, d_delta, d_xs[0], d_xs[1]);
-                        }
-                        if (m) hipLaunchKernelGGL((rows.has_pose ? sp_eval_kernel<true, true> : sp_eval_kernel<true, false>), grid_for(m), dim3(256), 0, stream, rows, jac, d_xs[1], d_r[1], d_j[1]);
-                        hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_r[1], m, d_scal + 5);
-                        gradient(1);
-                        hipLaunchKernelGGL(sp_dot_kernel, dim3(1), dim3(1024), 0, stream, d_grad, d_dir, nv, d_scal + 6);
-                        e = hipMemcpyAsync(host3, d_scal + 5, 2 * sizeof(double), hipMemcpyDeviceToHost, stream);
-                        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-                        if (e != hipSuccess) return e;
-                        trials += 1;
-                        if (hz.feed(HzParam{step, host3[0], host3[1]}, step, acc_pt)) break;
-                    }
-                    if (nv) hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[1], d_xs[0]);
-                    hipLaunchKernelGGL(sp_lbfgs_update_kernel, dim3(1), dim3(1024), 0, stream, h, nv, acc_pt.p, d_dir, d_grad, d_s, d_y, d_rho);
-                    accepted += 1;
-                    sse = acc_pt.phi;
-                    if (hz.capped) {
-                        exit_code = FX_EXIT_TRIAL_CAP;
-                        break;
-                    }
-                    if (!(acc_pt.phi == acc_pt.phi)) {
-                        exit_code = FX_EXIT_NAN;
-                        break;
-                    }
-                    if (std::fabs(prev - acc_pt.phi) < LbfgsConst::CONVERGENCE_THRESHOLD) {
-                        exit_code = FX_EXIT_FTOL;
-                        break;
-                    }
-                    if (acc_pt.phi < LbfgsConst::RESIDUAL_THRESHOLD) {
-                        exit_code = FX_EXIT_SSE;
-                        break;
-                    }
-                    prev = acc_pt.phi;
-                }
-            }
-        }
-        const int cur = 0;  // (the accepted point of every iteration was copied into generation 0)
-        if (nv) {
-            hipLaunchKernelGGL(sp_writeback_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_scal, do_scale, d_vars_out);
-            if (single_pass) {
-                // SinglePass also updates the working vector (:201-207): later blocks see this one
-                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_xs[cur], d_xs[cur ^ 1]);
-            } else {
-                // accepted point -> output only; later components see the pre-solve snapshot (quirk Q2)
-                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[0]);
-                hipLaunchKernelGGL(sp_copy_free_kernel, grid_for(nv), dim3(256), 0, stream, d_fvar, nv, d_snap, d_xs[1]);
-            }
-        }
-        e = hipStreamSynchronize(stream);  // the block's device memory is released when `pool` goes out of scope
-        if (e != hipSuccess) return e;
-        if (trace) trace_block(*blk, trials, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan1).count());
-        res.accepted += accepted;
-        res.trials += trials;
-        res.exit = exit_code;
-        res.sse0 += sse_start;
-        res.sse += sse;
-        }  // blocks
-    }
-
-    // ---- post-solve check on the unscaled variables
-    if (net) hipLaunchKernelGGL((rows.has_pose ? sp_identity_residual_kernel<true> : sp_identity_residual_kernel<false>), grid_for(net), dim3(256), 0, stream, rows, d_vars_out, d_runs);
-    hipLaunchKernelGGL(sp_sumsq_kernel, dim3(1), dim3(1024), 0, stream, d_runs, net, d_scal + 4);
-    e = hipMemcpyAsync(host3, d_scal, sizeof(double), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(host3 + 1, d_scal + 4, sizeof(double), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    res.scale = host3[0];
-    res.sse_unscaled = host3[1];
-    if (result) *result = res;
-    e = hipGetLastError();
-    return e;
 }
 
 }  // namespace fx

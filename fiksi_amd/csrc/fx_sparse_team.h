@@ -48,11 +48,12 @@ struct SpBlock {  // structure of one block, shared by the Systems of a group
 // Value arrays of the group's first System; System s of the group lives `s * stride` doubles further in every one.
 struct SpVals {
     double *xs0, *xs1, *snap, *r0, *r1, *j0, *j1, *a, *l, *rhs, *delta, *t, *e, *scal;
+    double *hs, *hy;  // Optimizer::LBfgs: the five s / y history vectors (a, l, t, e are its gradient, direction, scratch)
     size_t stride;
     __device__ __forceinline__ void shift(uint32_t s) {
         const size_t o = (size_t)s * stride;
         xs0 += o; xs1 += o; snap += o; r0 += o; r1 += o; j0 += o; j1 += o; a += o; l += o;
-        rhs += o; delta += o; t += o; e += o; scal += o;
+        rhs += o; delta += o; t += o; e += o; scal += o; hs += o; hy += o;
     }
 };
 
@@ -294,7 +295,9 @@ __device__ __forceinline__ double team_sumsq(const double* v, uint32_t n, double
 }
 
 // K1 / K2 for one row of a block (subsystem.rs:93-166), the body of sp_eval_kernel
-template <bool POSE>
+// OVERWRITE: entries of a row that share a column — 0: summed (sparse J, sparse_col_mat.rs:710-711); 1: the last one wins
+// (the dense J of L-BFGS, expressions.rs:993-1008) — quirk Q4
+template <bool POSE, bool OVERWRITE = false>
 __device__ __forceinline__ void team_eval_row(const SpRows& rows, const double* sparam, const SpJac& jac, uint32_t row, const double* xs,
                                               double* r, double* jvals) {
     const uint32_t e = jac.rows[row];
@@ -315,7 +318,10 @@ __device__ __forceinline__ void team_eval_row(const SpRows& rows, const double* 
     for (int q = 0; q < 8; ++q) {
         const uint32_t sl = (slots >> (4 * q)) & 0xFu;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) out[u] += (sl == (uint32_t)u) ? g[q] : 0.0;
+        for (int u = 0; u < 8; ++u) {
+            if (OVERWRITE) out[u] = (sl == (uint32_t)u) ? g[q] : out[u];
+            else out[u] += (sl == (uint32_t)u) ? g[q] : 0.0;
+        }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -531,6 +537,186 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
         ac.exit_code = st.exit_code;
         ac.sse0 += st.sse_start;
         ac.sse += st.sse;
+    }
+}
+
+// ---- Optimizer::LBfgs (solve/lbfgs.rs:20-193) of one block, one workgroup per System -------------------------------
+// Round 2 ran the line search on the host, two scalars read back per evaluation. Here the whole optimizer is one launch:
+// every thread carries the Hager-Zhang machine (fx_lbfgs.h: the reference's nested line search turned inside out around
+// ONE evaluation site) and feeds it the same (p, phi, phi') — uniform decisions, no host. Vectors live in the block's
+// free-variable order; every sum is taken in the reference's order — products written side by side, then added up by
+// one thread from first to last (dot_product :213-216, sum_squares utils.rs:11-19, compute_gradient :199-210 row by
+// row) — so distance-only sketches follow the oracle bit for bit at any size, as the one-wavefront build does.
+constexpr uint32_t SEQ_CHUNK = 4096;  // doubles of LDS the products of a sequential sum are staged in
+
+// sum of f(i), i = 0 .. n-1, added in index order; every thread gets the result
+template <typename F>
+__device__ __forceinline__ double team_seq_sum(uint32_t n, F f, double* s_seq, double* s_out) {
+    double sum = 0.0;
+    for (uint32_t base = 0; base < n; base += SEQ_CHUNK) {
+        const uint32_t cnt = min(SEQ_CHUNK, n - base);
+        for (uint32_t i = threadIdx.x; i < cnt; i += TEAM_THREADS) s_seq[i] = f(base + i);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (uint32_t i = 0; i < cnt; i += 16u) {
+                double t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = (i + u < cnt) ? s_seq[i + u] : 0.0;  // (+0.0 changes no sum that has begun)
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (i + u < cnt) sum += t[u];
+            }
+            s_out[0] = sum;
+        }
+        __syncthreads();
+        sum = s_out[0];
+        __syncthreads();
+    }
+    return sum;
+}
+
+template <bool POSE>
+__global__ __launch_bounds__(TEAM_THREADS) void sp_lbfgs_team_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum, uint32_t flags,
+                                                                      double* __restrict__ vars_base, const uint64_t* __restrict__ out_off) {
+    __shared__ double s_seq[SEQ_CHUNK];
+    __shared__ double s_out[2];
+    const uint32_t sys = blockIdx.x, tid = threadIdx.x;
+    V.shift(sys);
+    const double* sparam = rows.sparam + (size_t)sys * V.stride;
+    const uint32_t m = B.m, nv = B.nv;
+    double* const grad = V.a;   // (the LM arrays of the same slab, sized for at least nv)
+    double* const dir = V.rhs;
+    double* const hs = V.hs;
+    double* const hy = V.hy;
+    double rho[5] = {0., 0., 0., 0., 0.};
+
+    // residuals + dense-Jacobian rows at x (generation g), then the gradient Jt r: per variable over the rows, ascending
+    auto evaluate = [&](const double* xs, double* r, double* jv) {
+        for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE, true>(rows, sparam, B.jac, row, xs, r, jv);
+        __syncthreads();
+        for (uint32_t c = tid; c < nv; c += TEAM_THREADS) {
+            double g = 0.0;
+            for (uint32_t p = B.cptr[c]; p < B.cptr[c + 1]; ++p) g += jv[B.cidx[p]] * r[B.crow[p]];
+            grad[B.perm[c]] = g;
+        }
+        __syncthreads();
+    };
+    evaluate(V.xs0, V.r0, V.j0);
+    uint32_t accepted = 0, trials = 1, exit_code = FX_EXIT_MAX_OUTER;
+    double prev = team_seq_sum(m, [&](uint32_t i) { return V.r0[i] * V.r0[i]; }, s_seq, s_out);
+    const double sse_start = prev;
+    double sse = prev;
+    if (!(prev == prev)) {
+        exit_code = FX_EXIT_NAN;
+    } else if (prev < LbfgsConst::START_THRESHOLD) {
+        exit_code = FX_EXIT_SSE;
+    } else {
+        for (uint32_t c = tid; c < 5u * nv; c += TEAM_THREADS) {
+            hs[c] = 0.0;
+            hy[c] = 0.0;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < LbfgsConst::MAX_ITERATIONS; ++k) {
+            // ---- the two-loop recursion (:86-139), ring indexing (k + i) % 5 as the reference has it
+            const uint32_t hl = k < 5u ? k : 5u;
+            double alpha[5] = {0., 0., 0., 0., 0.};
+            for (uint32_t j = tid; j < nv; j += TEAM_THREADS) dir[j] = grad[j];
+            __syncthreads();
+            for (int i = 4; i >= 0; --i) {
+                if ((uint32_t)i >= hl) continue;
+                const uint32_t h = (k + (uint32_t)i) % 5u;
+                const double* s_i = hs + (size_t)h * nv;
+                const double* y_i = hy + (size_t)h * nv;
+                const double dp = team_seq_sum(nv, [&](uint32_t j) { return s_i[j] * dir[j]; }, s_seq, s_out);
+                alpha[i] = rho[h] * dp;
+                for (uint32_t j = tid; j < nv; j += TEAM_THREADS) dir[j] -= alpha[i] * y_i[j];
+                __syncthreads();
+            }
+            if (k > 0) {
+                const uint32_t h = (k - 1u) % 5u;
+                const double* s_h = hs + (size_t)h * nv;
+                const double* y_h = hy + (size_t)h * nv;
+                const double s_dot_y = team_seq_sum(nv, [&](uint32_t j) { return s_h[j] * y_h[j]; }, s_seq, s_out);
+                const double y_dot_y = team_seq_sum(nv, [&](uint32_t j) { return y_h[j] * y_h[j]; }, s_seq, s_out);
+                if (y_dot_y > 0.) {
+                    const double scale = s_dot_y / y_dot_y;
+                    for (uint32_t j = tid; j < nv; j += TEAM_THREADS) dir[j] *= scale;
+                    __syncthreads();
+                }
+            }
+            for (int i = 0; i < 5; ++i) {
+                if ((uint32_t)i >= hl) continue;
+                const uint32_t h = (k + (uint32_t)i) % 5u;
+                const double* s_i = hs + (size_t)h * nv;
+                const double* y_i = hy + (size_t)h * nv;
+                const double dp = team_seq_sum(nv, [&](uint32_t j) { return y_i[j] * dir[j]; }, s_seq, s_out);
+                const double beta = rho[h] * dp;
+                for (uint32_t j = tid; j < nv; j += TEAM_THREADS) dir[j] += s_i[j] * (alpha[i] - beta);
+                __syncthreads();
+            }
+            const uint32_t h = k % 5u;
+            double* y_k = hy + (size_t)h * nv;
+            for (uint32_t j = tid; j < nv; j += TEAM_THREADS) {
+                dir[j] *= -1.;
+                y_k[j] = grad[j];  // the old gradient, parked until the update (:141-143)
+            }
+            __syncthreads();
+            // ---- the line search (:218-506): one evaluation site, fed to the machine
+            HzMachine hz;
+            double step = hz.start(prev, team_seq_sum(nv, [&](uint32_t j) { return grad[j] * dir[j]; }, s_seq, s_out));
+            HzParam acc_pt{0., 0., 0.};
+            for (;;) {  // calculate_phi (:270-284): xs1 = xs0 + step * dir
+                for (uint32_t j = tid; j < nv; j += TEAM_THREADS) {
+                    const uint32_t v = B.fvar[j];
+                    V.xs1[v] = V.xs0[v] + step * dir[j];
+                }
+                __syncthreads();
+                evaluate(V.xs1, V.r1, V.j1);
+                const double phi = team_seq_sum(m, [&](uint32_t i) { return V.r1[i] * V.r1[i]; }, s_seq, s_out);
+                const double dphi = team_seq_sum(nv, [&](uint32_t j) { return grad[j] * dir[j]; }, s_seq, s_out);
+                trials += 1;
+                if (hz.feed(HzParam{step, phi, dphi}, step, acc_pt)) break;
+            }
+            // ---- variables = scratch; s_k = step * dir, y_k = grad - old grad, rho_k = 1 / s_k.y_k (:168-180)
+            for (uint32_t j = tid; j < nv; j += TEAM_THREADS) {
+                const uint32_t v = B.fvar[j];
+                V.xs0[v] = V.xs1[v];
+                hs[(size_t)h * nv + j] = acc_pt.p * dir[j];
+                y_k[j] = grad[j] - y_k[j];
+            }
+            __syncthreads();
+            const double* s_k = hs + (size_t)h * nv;
+            rho[h] = 1.0 / team_seq_sum(nv, [&](uint32_t j) { return s_k[j] * y_k[j]; }, s_seq, s_out);
+            accepted += 1;
+            sse = acc_pt.phi;
+            if (hz.capped) {
+                exit_code = FX_EXIT_TRIAL_CAP;
+                break;
+            }
+            if (!(acc_pt.phi == acc_pt.phi)) {
+                exit_code = FX_EXIT_NAN;
+                break;
+            }
+            if (::fabs(prev - acc_pt.phi) < LbfgsConst::CONVERGENCE_THRESHOLD) {
+                exit_code = FX_EXIT_FTOL;
+                break;
+            }
+            if (acc_pt.phi < LbfgsConst::RESIDUAL_THRESHOLD) {
+                exit_code = FX_EXIT_SSE;
+                break;
+            }
+            prev = acc_pt.phi;
+        }
+    }
+    __syncthreads();
+    team_block_epilogue(B, V, 0u, flags, vars_base + out_off[sys], tid, TEAM_THREADS);
+    if (tid == 0) {
+        SpAccum& ac = accum[sys];
+        ac.accepted += accepted;
+        ac.trials += trials;
+        ac.exit_code = exit_code;
+        ac.sse0 += sse_start;
+        ac.sse += sse;
     }
 }
 

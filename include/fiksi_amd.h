@@ -132,10 +132,12 @@ typedef enum fx_step_solver {
                                     per wavefront.                                                     */
     FX_STEP_QR = 2 /* the reference's own numerics (lm.rs:98-132, solvi qr.rs:226-356): Householder QR of
                       [J; sqrt(lambda) I] in the reference's column order (COLAMD, computed on the host) and row
-                      order, every sum taken in the reference's order, nothing fused. On sketches without angle
-                      constraints the LM path — trial counts, every iterate — is bit-identical to the
-                      reference's; angle residuals go through atan2 (device libm vs the host's), so those
-                      paths agree to rounding. f64, Levenberg-Marquardt, Systems the one-wavefront kernel takes
+                      order, every sum taken in the reference's order, nothing fused. The LM path — trial counts,
+                      every iterate — is bit-identical to the reference algorithm's on all eleven expression
+                      kinds, relative to a correctly rounded atan2: the QR kernels evaluate the two angle
+                      residuals with fx_atan2.h's correctly rounded routine (a platform libm's atan2 — the
+                      reference's — may be an ulp off on ~7e-4 of arguments; see fx_atan2_cr_batch). f64,
+                      Levenberg-Marquardt, Systems the one-wavefront kernel takes
                       (components of up to FX_MAX_FREE_VARS free variables); larger Systems run
                       FX_STEP_CHOLESKY_REFINED instead. Several times the cost of FX_STEP_CHOLESKY.        */
 } fx_step_solver;
@@ -301,6 +303,21 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results);
 /* == levenberg_marquardt(Subsystem): values used as given (already scaled/perturbed). */
 int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
+
+/* What a sharded solve adds up to (the counters one all-reduce would carry). */
+typedef struct fx_throughput {
+    uint64_t systems;   /* Systems solved                                                          */
+    uint64_t converged; /* ... with sum r^2 < 1e-4 on the unscaled variables (fiksi_bench.rs:65-72) */
+    uint64_t accepted;  /* Gauss-Newton iterations                                                 */
+    uint64_t trials;    /* LM trials                                                               */
+} fx_throughput;
+/* == fx_system_solve_batch over several devices: shard r of n_ctx = Systems [r N / n_ctx, (r + 1) N / n_ctx), solved by
+ * context r on its own device from its own host thread (independent Systems, no data-path collective — xGMI
+ * carries nothing); batch->vars is solved in place shard by shard; results[N] (may be NULL) and *total (may be NULL: the
+ * counters summed on the host) are filled. Every result is the bits a one-device solve gives: the shard rule does not
+ * enter a System's arithmetic. The contexts must be distinct (one per device, or several on one device). */
+int fx_system_solve_batch_multi(fx_ctx* const* ctxs, uint32_t n_ctx, const fx_batch* batch, const fx_solving_opts* opts,
+                                fx_result* results, fx_throughput* total);
 /* == Problem::calculate_residuals_and_sparse_jacobian at batch->vars; jvals in
  * fx_jacobian_structure order (may be NULL for residuals only). */
 int fx_eval_residual_jacobian(fx_ctx* ctx, const fx_batch* batch, double* r, double* jvals);

@@ -1,0 +1,34 @@
+"""fx_system_solve_batch_multi (SURVEY 8e as a library entry point): one batch sharded over several contexts, a host
+thread each. On the 1-GPU box the contexts share device 0 — the code path (threads, shard views, in-place write-back,
+host-side counter sum) is the one an 8-GPU host runs with one context per device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sharded_solve_equals_the_single_context_solve(fiksi, ctx):
+    from fiksi_amd import abi, workloads
+    from fiksi_amd._lib import FiksiError
+
+    b = workloads.concat([workloads.ring16(3001), workloads.hinged_triangles(7, 11), workloads.large_sketch(120, seed=3),
+                          workloads.ring16(500, inconsistent=True)])
+    v1, r1 = ctx.system_solve_batch(b)
+    others = [fiksi.Context(0) for _ in range(3)]
+    try:
+        for n_ctx in (1, 2, 3):
+            v, r, total = abi.Context.system_solve_batch_multi(others[:n_ctx], b)
+            assert np.array_equal(v.view(np.uint64), v1.view(np.uint64)), n_ctx
+            assert np.array_equal(r, r1), n_ctx
+            assert total == {"systems": len(r1), "converged": int((r1["sse_unscaled"] < 1e-4).sum()),
+                             "accepted": int(r1["accepted"].sum()), "trials": int(r1["trials"].sum())}
+        # more contexts than Systems: empty shards are skipped
+        tiny = workloads.ring16(2)
+        v, r, total = abi.Context.system_solve_batch_multi(others, tiny)
+        vt, rt = ctx.system_solve_batch(tiny)
+        assert np.array_equal(v.view(np.uint64), vt.view(np.uint64)) and np.array_equal(r, rt) and total["systems"] == 2
+        with pytest.raises(FiksiError):
+            abi.Context.system_solve_batch_multi([others[0], others[0]], tiny)  # a context is bound to one host thread
+    finally:
+        for c in others:
+            c.close()

@@ -74,21 +74,13 @@ def test_scale_and_perturbation_bit_exact(fiksi, oracle, ctx):
 
 
 def _compare_solves(res, res_o, v, v_o, b, oracle, min_same=0.97):
-    same = res["accepted"] == res_o["accepted"]
-    assert same.mean() >= min_same, f"accepted-step counts agree for {same.mean():.3%}"
-    assert (res["exit"][same] == res_o["exit"][same]).mean() >= 0.99
-    # final SSE (scaled space): |sse_gpu - sse_ref| <= 1e-10 + 1e-6 * sse_ref on the systems that took
-    # the same path
-    d = np.abs(res["sse"][same] - res_o["sse"][same])
-    assert np.all(d <= 1e-10 + 1e-6 * np.abs(res_o["sse"][same]))
-    # per-expression unscaled residuals at the solution
-    r = oracle.residuals_batch(b, v)
-    r_o = oracle.residuals_batch(b, v_o)
-    n = len(res)
-    for s in np.nonzero(same)[0][:2000]:
-        e0, e1 = int(b["expr_off"][s]), int(b["expr_off"][s + 1])
-        tol = 1e-7 * max(1.0, res_o["scale"][s]) + 1e-4 * np.sqrt(res_o["sse"][s])
-        assert np.max(np.abs(np.abs(r[e0:e1]) - np.abs(r_o[e0:e1]))) <= tol, f"system {s} of {n}"
+    """Every System of the batch against the oracle (tests/helpers.py: compare_outcomes with the tight bars): none is
+    dropped for having left the oracle's path — those are held to the same verdict and a bounded SSE difference."""
+    from helpers import compare_outcomes
+
+    same, verdict = compare_outcomes(b, v, res, v_o, res_o, oracle, tight=True)
+    assert same >= min_same, f"on the oracle's path: {same:.3%}"
+    assert verdict == 1.0, verdict
 
 
 def test_system_solve_ring16_matches_oracle(fiksi, oracle, ctx):

@@ -278,3 +278,21 @@ def test_world_size_2_sharding_and_reduction_gloo(fiksi, oracle, tmp_path):
     _, res = oracle.solve_batch(both, mode=3)
     assert got["elapsed"] == 2.0
     assert got["tot"] == [int((res["sse"] < 1e-8).sum()), int(res["accepted"].sum()), 2 * n]
+
+
+def test_multi_device_entry_point_rejects_bad_arguments_without_a_device(fiksi):
+    """fx_system_solve_batch_multi checks its arguments before anything touches a device (the solves themselves are
+    tests/test_gpu_multi.py)."""
+    import ctypes as C
+
+    from fiksi_amd import abi, workloads
+    from fiksi_amd._lib import lib
+
+    a = abi.normalize_batch(workloads.ring16(3))
+    st = abi.as_struct(a)
+    o = abi.solving_opts()
+    assert lib.fx_system_solve_batch_multi(None, 2, C.byref(st), C.byref(o), None, None) == -1
+    handles = (C.c_void_p * 2)(None, None)
+    assert lib.fx_system_solve_batch_multi(handles, 0, C.byref(st), C.byref(o), None, None) == -1
+    assert lib.fx_system_solve_batch_multi(handles, 2, C.byref(st), C.byref(o), None, None) == -1
+    assert b"NULL" in lib.fx_last_error()

@@ -81,6 +81,31 @@ def test_gpu_lbfgs_distance_only_sketches_follow_the_oracle_exactly(fiksi, oracl
 
 
 @pytest.mark.gpu
+def test_gpu_lbfgs_beyond_one_wavefront_follows_the_oracle_exactly(fiksi, oracle, ctx):
+    """Round 3: Systems beyond one wavefront run the whole optimizer in one launch (sp_lbfgs_team_kernel, one workgroup
+    per System, the Hager-Zhang machine on the device — no host round trip per evaluation), every sum in the
+    reference's order: the reference's own bench sketches of 16 and 64 triangles (66 / 258 variables, distances only)
+    and a 600-variable chain of distances are the oracle's bits — variables, iteration and evaluation counts, SSEs."""
+    from fiksi_amd import abi, workloads
+
+    chain = workloads.large_sketch(300, seed=5)
+    keep = chain["expr_tag"] == abi.POINT_POINT_DISTANCE  # the distance rows only (angle rows: atan2, an ulp apart)
+    chain = dict(chain, expr_tag=chain["expr_tag"][keep], expr_idx=chain["expr_idx"].reshape(-1, 4)[keep].reshape(-1),
+                 expr_param=chain["expr_param"][keep], expr_comp=chain["expr_comp"][keep],
+                 expr_off=np.array([0, int(keep.sum())], dtype=np.uint32))
+    b = workloads.concat([workloads.hinged_triangles(3, 16), workloads.hinged_triangles(2, 64), chain])
+    assert int(b["var_off"][1]) == 66 and int(b["var_off"][4] - b["var_off"][3]) == 258
+    v, res = ctx.system_solve_batch(b, abi.solving_opts(optimizer=1))
+    v_o, res_o = oracle.solve_batch(b, mode=7, nthreads=6)
+    assert np.array_equal(res["scale"], res_o["scale"])
+    assert np.array_equal(res["accepted"], res_o["accepted"]) and res["accepted"].min() >= 2  # L-BFGS iterations
+    assert np.array_equal(res["trials"], res_o["trials"])                                     # evaluations
+    assert np.array_equal(res["exit"], res_o["exit"])
+    assert np.array_equal(res["sse0"], res_o["sse0"]) and np.array_equal(res["sse"], res_o["sse"])
+    assert np.array_equal(v, v_o)
+
+
+@pytest.mark.gpu
 def test_gpu_lbfgs_ring16_batch(fiksi, oracle, ctx):
     from fiksi_amd import abi, workloads
 
