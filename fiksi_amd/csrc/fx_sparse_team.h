@@ -546,7 +546,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
 // ONE evaluation site) and feeds it the same (p, phi, phi') — uniform decisions, no host. Vectors live in the block's
 // free-variable order; every sum is taken in the reference's order — products written side by side, then added up by
 // one thread from first to last (dot_product :213-216, sum_squares utils.rs:11-19, compute_gradient :199-210 row by
-// row) — so distance-only sketches follow the oracle bit for bit at any size, as the one-wavefront build does.
+// row) — so distance-only sketches reproduce the reference algorithm bit for bit at any size, as the one-wavefront build does.
 constexpr uint32_t SEQ_CHUNK = 4096;  // doubles of LDS the products of a sequential sum are staged in
 
 // sum of f(i), i = 0 .. n-1, added in index order; every thread gets the result
