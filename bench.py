@@ -239,7 +239,7 @@ def main() -> int:
         }
         in_cache = {
             "systems": n_sys, "achieved": k1_gbs, "frac": k1_gbs / HBM_PEAK_GBS, "avg_launch_ms": k1_ms, "launches": k1_launches,
-            "algorithmic_bytes_per_launch": k1_bytes, "traffic": pmc_traffic("eval_rows_kernel<true>", n_sys),
+            "algorithmic_bytes_per_launch": k1_bytes, "traffic": pmc_traffic("eval_rows_kernel<true", n_sys),
             "note": "230 MB per launch: under the 256 MiB Infinity Cache, so this is not an HBM rate",
         }
         in_cache["frac_by_counter_bytes"] = None if in_cache["traffic"] is None else in_cache["traffic"] / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -297,7 +297,7 @@ def k1_past_l3(ctx, workloads, n_big: int = 500_000):
     ms = ctx.timer_end() / n
     nbytes = workloads.k1_algorithmic_bytes(b, db.nnz)
     gbs = nbytes / (ms * 1e-3) / 1e9
-    traffic = pmc_traffic("eval_rows_kernel<true>", n_big)
+    traffic = pmc_traffic("eval_rows_kernel<true", n_big)
     db.free()
     return {
         "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "workload_systems": n_big, "avg_launch_ms": ms, "launches": n,
