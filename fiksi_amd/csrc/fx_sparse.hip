@@ -299,6 +299,11 @@ struct BlockOnDevice {
     SpBlock dev{};             // device view; dev.sched = the whole factor as one segment
     SpTeamSched parts{};       // parts + top (large factors only)
     bool has_parts = false;
+    SpPartsX px{};             // ... and its LDS build (fx_sparse_plan.h: PartsExtra)
+    const uint32_t* solo_blob = nullptr;  // the whole factor's index data for LDS (small factors)
+    uint32_t solo_blob_words = 0;
+    uint32_t n_fslots = 0, n_bslots = 0;
+    size_t lds_part_bytes = 0, lds_top_bytes = 0;
     double plan_ms = 0.0;
 };
 
@@ -319,7 +324,7 @@ struct SparsePlanCache {
     std::unique_ptr<Pool> pool;
     std::vector<CompOnDevice> comps;
     std::vector<std::unique_ptr<BlockOnDevice>> blocks;  // in visiting order
-    uint32_t max_m = 0, max_nv = 0, max_nnz_j = 0, max_nnz_a = 0, max_nnz_l = 0;
+    uint32_t max_m = 0, max_nv = 0, max_nnz_j = 0, max_nnz_a = 0, max_nnz_l = 0, max_fslots = 0, max_bslots = 0;
     Arena values;                                    // the group solves' value slabs, kept between calls (one solve at a time)
     bool ready = false;
 };
@@ -335,12 +340,11 @@ inline dim3 grid_for2(uint32_t n, uint32_t ny, uint32_t block = 256) { return di
 SpTeamSched upload_schedule(Pool& sp, const ComponentPlan& P, const TeamSchedule& t) {
     SpTeamSched d{};
     d.seg_lev = sp.up(t.seg_lev);
-    d.lev_list = sp.up(t.lev_list);
-    d.list_ptr = sp.up(t.list_ptr);
-    d.list_cols = sp.up(t.list_cols);
-    std::vector<ColDesc> cd(t.list_cols.size());
+    d.wptr = sp.up(t.wptr);
+    d.cols = sp.up(t.cols);
+    std::vector<ColDesc> cd(t.cols.size());
     for (size_t q = 0; q < cd.size(); ++q) {
-        const uint32_t j = t.list_cols[q];
+        const uint32_t j = t.cols[q];
         ColDesc& c = cd[q];
         c.j = j;
         c.beg = P.lcolptr[j];
@@ -352,6 +356,7 @@ SpTeamSched upload_schedule(Pool& sp, const ComponentPlan& P, const TeamSchedule
         c.pad = 0;
     }
     d.cdesc = sp.up(cd);
+    d.cdesc_mid = nullptr;
     d.nparts = t.nparts;
     return d;
 }
@@ -362,7 +367,7 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
     if (cache->ready) return hipSuccess;
     cache->comps.clear();  // (an earlier attempt may have failed half-way)
     cache->blocks.clear();
-    cache->max_m = cache->max_nv = cache->max_nnz_j = cache->max_nnz_a = cache->max_nnz_l = 0;
+    cache->max_m = cache->max_nv = cache->max_nnz_j = cache->max_nnz_a = cache->max_nnz_l = cache->max_fslots = cache->max_bslots = 0;
     if (!cache->pool) cache->pool.reset(new Pool(&cache->arena));
     Pool& sp = *cache->pool;
     sp.stream = stream;
@@ -446,6 +451,12 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
             d.lrows.rcol = sp.up(Q.rcol);
             d.sched = upload_schedule(sp, Q, Q.solo);
             {
+                std::vector<uint32_t> a2l(Q.nnz_a, 0);
+                for (uint32_t k = 0; k < Q.nnz_l; ++k)
+                    if (Q.l2a[k] >= 0) a2l[(uint32_t)Q.l2a[k]] = k;
+                d.a2l = sp.up(a2l);
+            }
+            {
                 std::vector<uint32_t> along;  // long gather lists: entries of A first, then columns of the right-hand side
                 for (uint32_t k = 0; k < Q.nnz_a; ++k)
                     if (Q.apair_ptr[k + 1] - Q.apair_ptr[k] > FORM_LONG) along.push_back(k);
@@ -459,8 +470,38 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
             d.nv = Q.nv;
             d.nnz_a = Q.nnz_a;
             d.nnz_l = Q.nnz_l;
+            if (!Q.solo_blob.empty()) {
+                blk->solo_blob = sp.up(Q.solo_blob.words);
+                blk->solo_blob_words = (uint32_t)Q.solo_blob.words.size();
+            }
             blk->has_parts = !Q.parts.empty();
-            if (blk->has_parts) blk->parts = upload_schedule(sp, Q, Q.parts);
+            if (blk->has_parts) {
+                blk->parts = upload_schedule(sp, Q, Q.parts);
+                blk->parts.cdesc_mid = nullptr;
+                // the LDS build: the same lists, the top's columns described by their own products and row entries only
+                const sparse_plan::PartsExtra& E = Q.px;
+                const uint32_t np = Q.parts.nparts, ctop = E.seg_col[np], etop = E.seg_ent[np];
+                SpPartsX& X = blk->px;
+                X.nparts = np;
+                X.seg_col = sp.up(E.seg_col);
+                X.seg_ent = sp.up(E.seg_ent);
+                X.frun_ptr = sp.up(E.frun_ptr);
+                X.frun = sp.up(E.frun);
+                X.fslot_ptr = sp.up(E.fslot_ptr);
+                X.brun_ptr = sp.up(E.brun_ptr);
+                X.brun = sp.up(E.brun);
+                X.bslot_ptr = sp.up(E.bslot_ptr);
+                X.blobs = sp.up(Q.parts_blobs.words);
+                X.blob_off = sp.up(Q.parts_blobs.seg_off);
+                X.cmid = sp.up(E.cmid);
+                blk->n_fslots = E.fslot_ptr.back();
+                blk->n_bslots = E.bslot_ptr.back();
+                // values (entries of L, the vector) + the segment's blob; 0: no LDS build (a segment beyond 16-bit local indices)
+                blk->lds_part_bytes = Q.parts_blobs.empty() ? 0 : (((size_t)E.max_part_ent + 1u) & ~size_t(1)) * 8 + (((size_t)E.max_part_cols + 1u) & ~size_t(1)) * 8 + (size_t)Q.parts_blobs.max_words * 4;
+                blk->lds_top_bytes = Q.parts_blobs.empty() ? 0 : (((size_t)(Q.nnz_l - etop) + 1u) & ~size_t(1)) * 8 + (((size_t)(Q.nv - ctop) + 1u) & ~size_t(1)) * 8 + (size_t)Q.parts_blobs.top_words * 4;
+                cache->max_fslots = std::max(cache->max_fslots, blk->n_fslots);
+                cache->max_bslots = std::max(cache->max_bslots, blk->n_bslots);
+            }
             if (sp.err != hipSuccess) return sp.err;
             cache->max_m = std::max(cache->max_m, Q.m);
             cache->max_nv = std::max(cache->max_nv, Q.nv);
@@ -479,28 +520,39 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
 
 constexpr size_t TEAM_LDS_VALUES_MAX = size_t(140) << 10;  // of the CU's 160 KB
 
-template <bool POSE, bool LDSV>
+template <bool POSE, bool LDSV, bool BLOB>
 hipError_t launch_team_t(uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l, uint32_t lds_v,
-                         unsigned long long* prof) {
+                         const uint32_t* blob, uint32_t blob_words, unsigned long long* prof) {
     static bool raised = false;  // (per instantiation; the attribute is a property of the function)
     if (LDSV && !raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)TEAM_LDS_VALUES_MAX);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV>), dim3(n), dim3(TEAM_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
-                       lds_l, lds_v, prof);
+    hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV, BLOB>), dim3(n), dim3(TEAM_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
+                       lds_l, lds_v, blob, blob_words, prof);
     return hipGetLastError();
 }
-hipError_t launch_team(bool pose, bool ldsv, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V,
-                       SpAccum* accum, const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l, uint32_t lds_v,
-                       unsigned long long* prof) {
-    if (pose) return ldsv ? launch_team_t<true, true>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, prof)
-                          : launch_team_t<true, false>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, prof);
-    return ldsv ? launch_team_t<false, true>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, prof)
-                : launch_team_t<false, false>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, prof);
+hipError_t launch_team(bool pose, bool ldsv, bool blob_in_lds, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B,
+                       const SpVals& V, SpAccum* accum, const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l,
+                       uint32_t lds_v, const uint32_t* blob, uint32_t blob_words, unsigned long long* prof) {
+#define FX_TEAM(P, L, K) launch_team_t<P, L, K>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, blob, blob_words, prof)
+    if (pose) return !ldsv ? FX_TEAM(true, false, false) : blob_in_lds ? FX_TEAM(true, true, true) : FX_TEAM(true, true, false);
+    return !ldsv ? FX_TEAM(false, false, false) : blob_in_lds ? FX_TEAM(false, true, true) : FX_TEAM(false, true, false);
+#undef FX_TEAM
+}
+
+// the LDS builds of the parts kernels may ask for more than the default 64 KB of dynamic LDS
+hipError_t raise_lds_limits() {
+    static bool raised = false;
+    if (raised) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_parts_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_parts_down_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
+    raised = e == hipSuccess;
+    return e;
 }
 
 void trace_block(const BlockOnDevice& blk, uint32_t trials, double ms) {
@@ -512,18 +564,16 @@ void trace_block(const BlockOnDevice& blk, uint32_t trials, double ms) {
             if (sg > 1 && sg + 1 < t->nseg()) continue;  // (the first parts and the top)
             fprintf(stderr, " {");
             for (uint32_t q = t->seg_lev[sg]; q < t->seg_lev[sg + 1]; ++q) {
-                uint32_t maxc = 0, totc = 0;
-                for (uint32_t li = t->lev_list[q]; li < t->lev_list[q + 1]; ++li) {
-                    maxc = std::max(maxc, t->list_ptr[li + 1] - t->list_ptr[li]);
-                    totc += t->list_ptr[li + 1] - t->list_ptr[li];
-                }
-                fprintf(stderr, " %u lists / %u columns / longest %u;", t->lev_list[q + 1] - t->lev_list[q], totc, maxc);
+                uint32_t maxc = 0;
+                for (uint32_t w = 0; w < sparse_plan::TEAM_WAVES; ++w)
+                    maxc = std::max(maxc, t->wptr[q * sparse_plan::TEAM_WAVES + w + 1] - t->wptr[q * sparse_plan::TEAM_WAVES + w]);
+                fprintf(stderr, " %u columns / longest run %u;", t->wptr[(q + 1) * sparse_plan::TEAM_WAVES] - t->wptr[q * sparse_plan::TEAM_WAVES], maxc);
             }
             fprintf(stderr, " }");
         }
         fprintf(stderr, "\n");
     }
-    fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u (%zu products); plan %.2f ms, LM %.2f ms (%u trials)\n",
+    fprintf(stderr, "[fiksi_amd] sparse block: %u rows, %u cols, nnz J %u A %u L %u (%zu products); plan %.2f ms, solve %.2f ms (%u trials)\n",
             P.m, P.nv, P.nnz_j, P.nnz_a, P.nnz_l, P.lpairs.size() / 2, blk.plan_ms, ms, trials);
 }
 
@@ -565,7 +615,7 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                  o_j1 = take(cache->max_nnz_j), o_a = take(std::max(cache->max_nnz_a, cache->max_nv)), o_l = take(lbfgs ? 0 : cache->max_nnz_l),
                  o_rhs = take(cache->max_nv), o_delta = take(cache->max_nv), o_t = take(refined ? cache->max_m : 0),
                  o_e = take(refined ? cache->max_nv : 0), o_hs = take(lbfgs ? 5 * (size_t)cache->max_nv : 0),
-                 o_hy = take(lbfgs ? 5 * (size_t)cache->max_nv : 0);
+                 o_hy = take(lbfgs ? 5 * (size_t)cache->max_nv : 0), o_cf = take(cache->max_fslots), o_cb = take(cache->max_bslots);
     const size_t stride = at;
 
     // the group in slices that fit a bounded slab (1 GiB)
@@ -629,20 +679,25 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                 } else if (!two_tier) {
                     unsigned long long* d_prof = nullptr;
                     if (team_prof) {
-                        d_prof = pool.alloc<unsigned long long>(8);
+                        d_prof = pool.alloc<unsigned long long>(16);
                         if (pool.err != hipSuccess) return pool.err;
-                        (void)hipMemsetAsync(d_prof, 0, 8 * sizeof(unsigned long long), stream);
+                        (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream);
                     }
                     // the factor and the solves' vectors in LDS when they fit beside the kernel's own 17 KB
                     const uint32_t lds_l = (blk.dev.nnz_l + 15u) & ~15u, lds_v = (blk.dev.nv + 15u) & ~15u;
-                    const size_t lds_bytes = ((size_t)lds_l + 2 * (size_t)lds_v) * sizeof(double);
-                    const bool ldsv = lds_bytes <= TEAM_LDS_VALUES_MAX;
-                    e = launch_team(rows.has_pose != 0, ldsv, n, ldsv ? lds_bytes : 0, stream, rows, blk.dev, V, d_accum, o, flags, d.vars, d_off, lds_l, lds_v, d_prof);
+                    const size_t lds_vals = ((size_t)lds_l + 2 * (size_t)lds_v) * sizeof(double);
+                    const bool ldsv = lds_vals <= TEAM_LDS_VALUES_MAX;
+                    const bool with_blob = ldsv && blk.solo_blob && lds_vals + (size_t)blk.solo_blob_words * 4 <= TEAM_LDS_VALUES_MAX;  // the index data too
+                    const size_t lds_bytes = ldsv ? lds_vals + (with_blob ? (size_t)blk.solo_blob_words * 4 : 0) : 0;
+                    e = launch_team(rows.has_pose != 0, ldsv, with_blob, n, lds_bytes, stream, rows, blk.dev, V, d_accum, o, flags, d.vars, d_off, lds_l, lds_v,
+                                    blk.solo_blob, blk.solo_blob_words, d_prof);
                     if (e != hipSuccess) return e;
                     if (team_prof) {
-                        unsigned long long h[8];
+                        unsigned long long h[16];
                         (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
                         (void)hipStreamSynchronize(stream);
+                        fprintf(stderr, "[fiksi_amd]   factorization, wavefront 0 (us): level 0 walk %.1f (%llu columns) + wait %.1f | levels above: walk %.1f + wait %.1f\n",
+                                h[8] * 0.01, h[12], h[9] * 0.01, h[10] * 0.01, h[11] * 0.01);
                         fprintf(stderr, "[fiksi_amd] team kernel, %u Systems, workgroup 0 (us): start %.1f | form %.1f factor+forward %.1f backward %.1f refine %.1f "
                                         "trial+eval %.1f | epilogue %.1f; %llu trials\n", n, h[0] * 0.01, h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[4] * 0.01,
                                 h[5] * 0.01, h[6] * 0.01, h[7]);
@@ -657,6 +712,19 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         else hipLaunchKernelGGL(spt_eval_kernel<false>, g_rows, dim3(TEAM_THREADS), 0, stream, rows, B, V, d_lm, d_tickets, o, start);
                     };
                     eval(1u);
+                    // the plain step with every segment's values in LDS when they fit (they do unless a part is enormous)
+                    const bool lds_build = !refined && blk.lds_part_bytes && blk.lds_part_bytes <= TEAM_LDS_VALUES_MAX && blk.lds_top_bytes <= TEAM_LDS_VALUES_MAX;
+                    SpContrib Cn{slab + o_cf, slab + o_cb, stride};
+                    unsigned long long* d_prof = nullptr;
+                    if (team_prof && lds_build) {
+                        d_prof = pool.alloc<unsigned long long>(16);
+                        if (pool.err != hipSuccess) return pool.err;
+                        (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream);
+                    }
+                    if (lds_build) {
+                        e = raise_lds_limits();
+                        if (e != hipSuccess) return e;
+                    }
                     std::vector<SpLm> h_lm(n);
                     for (uint32_t chunk = 4;; chunk = std::min<uint32_t>(2 * chunk, 16)) {
                         e = hipMemcpyAsync(h_lm.data(), d_lm, n * sizeof(SpLm), hipMemcpyDeviceToHost, stream);
@@ -666,7 +734,14 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         for (const SpLm& st : h_lm) all_done = all_done && st.done;
                         if (all_done) break;
                         for (uint32_t t = 0; t < chunk; ++t) {
-                            hipLaunchKernelGGL(spt_form_kernel, grid_for2(std::max(B.nnz_a, B.nv), n), dim3(256), 0, stream, B, V, d_lm);
+                            if (!lds_build) hipLaunchKernelGGL(spt_form_kernel, grid_for2(std::max(B.nnz_a, B.nv), n), dim3(256), 0, stream, B, V, d_lm);
+                            if (lds_build) {  // (each segment forms its own entries of A and of the right-hand side)
+                                hipLaunchKernelGGL(sptl_parts_up_kernel, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, B, blk.px, V, Cn, d_lm, d_prof);
+                                hipLaunchKernelGGL(sptl_top_kernel, dim3(1, n), dim3(TEAM_THREADS), blk.lds_top_bytes, stream, B, blk.px, V, Cn, d_lm);
+                                hipLaunchKernelGGL(sptl_parts_down_kernel, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, B, blk.px, V, d_lm);
+                                eval(0u);
+                                continue;
+                            }
                             hipLaunchKernelGGL(spt_parts_up_kernel, dim3(np, n), dim3(TEAM_THREADS), 0, stream, B, V, d_lm, 0u);
                             hipLaunchKernelGGL(spt_top_kernel, dim3(1, n), dim3(TEAM_THREADS), 0, stream, B, V, d_lm, 0u, refined ? 0u : 1u);
                             hipLaunchKernelGGL(spt_parts_down_kernel, dim3(np, n), dim3(TEAM_THREADS), 0, stream, B, V, d_lm, 0u, refined ? 0u : 1u);
@@ -683,6 +758,13 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         if (e != hipSuccess) return e;
                     }
                     hipLaunchKernelGGL(spt_block_end_kernel, grid_for2(std::max(B.nv, 1u), n), dim3(256), 0, stream, B, V, d_lm, d_accum, flags, d.vars, d_off);
+                    if (d_prof) {
+                        unsigned long long h[16];
+                        (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
+                        (void)hipStreamSynchronize(stream);
+                        fprintf(stderr, "[fiksi_amd] parts_up, part 0 (us over %llu launches): load %.1f | factor+forward %.1f (wavefront 0: level 0 walk %.1f (%llu columns) wait %.1f, above walk %.1f wait %.1f) | "
+                                        "store + contributions %.1f\n", h[7], h[0] * 0.01, h[1] * 0.01, h[8] * 0.01, h[12], h[9] * 0.01, h[10] * 0.01, h[11] * 0.01, h[2] * 0.01);
+                    }
                     if (trace) trace_block(blk, h_lm[0].trials, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lm0).count());
                 }
                 if (trace && (lbfgs || !two_tier)) {

@@ -21,15 +21,15 @@ struct ColDesc {  // one column, as a wavefront meets it on its way through a li
     uint32_t beg, end;      // its entries in L (the first one is the diagonal)
     uint32_t rbeg, rend;    // row j of L (strictly lower part)
     uint32_t pbeg, pend0;   // the products of its first 64 entries
-    uint32_t pad;
+    uint32_t pad;           // LDS build of the parts schedule: first entry whose row is in the top (the column's end elsewhere)
 };
 
-struct SpTeamSched {
-    const uint32_t* seg_lev;
-    const uint32_t* lev_list;
-    const uint32_t* list_ptr;
-    const uint32_t* list_cols;
-    const ColDesc* cdesc;       // [nv] in the order of list_cols
+struct SpTeamSched {            // fx_sparse_plan.h: TeamSchedule on the device
+    const uint32_t* seg_lev;    // [nseg + 1]
+    const uint32_t* wptr;       // [nlev * 16 + 1]: wavefront w's columns of level q = cols[wptr[16 q + w] .. wptr[16 q + w + 1])
+    const uint32_t* cols;       // [nv] walking order
+    const ColDesc* cdesc;       // [nv] in the order of cols
+    const uint32_t* cdesc_mid;  // (unused)
     uint32_t nparts;
 };
 constexpr uint32_t FORM_LONG = 32;  // gather lists of A / of the right-hand side beyond this are summed by a wavefront
@@ -40,6 +40,7 @@ struct SpBlock {  // structure of one block, shared by the Systems of a group
     SpChol chol;
     SpRowsOfL lrows;
     SpTeamSched sched;
+    const uint32_t* a2l;     // [nnz_a] the entry of L an entry of A starts in
     const uint32_t* along;   // entries of A, then columns of the right-hand side, whose gather lists are long
     uint32_t n_along, n_clong;
     uint32_t m, nv, nnz_a, nnz_l;
@@ -91,86 +92,123 @@ __device__ __forceinline__ double bcast_first(double s) {
     return __hiloint2double(hi, lo);
 }
 
-// The columns of a list, bottom-up: numeric Cholesky (left-looking by gather lists) with the forward sweep L y = b
-// riding along — once column j is factored, row j of L is complete, so y_j follows at once. FACTOR = false: the forward
-// sweep alone with the stored factor (the refined step needs it again). LDSV: l and b live in LDS.
-// A column is a chain of dependent steps (operands -> products -> pivot -> division -> the next column's operands),
-// so everything that does NOT depend on values is taken off it: the column's description is one 32-byte record in list
-// order (a scalar load), and the index words of the first 64 products / row entries / A entries of column t + 1 are
-// loaded while column t computes. 64 entries at a time (almost every column has fewer): all their products in one
-// flat, lane-strided sweep — they are contiguous, lpair_ptr is a prefix over the entries — summed per entry with LDS
-// atomics. `acc`: 64 doubles of LDS owned by the wavefront. Returns false when a pivot is not positive and finite.
-template <bool LDSV, bool FACTOR>
-__device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& lr, const ColDesc* __restrict__ cd, uint32_t t0, uint32_t t1,
-                                             const double* __restrict__ a, double lambda, double* l, double* b, double* acc, int lane) {
+// ---- a wavefront's walk through a list ---------------------------------------------------------------------------
+// A column is a chain of dependent steps (operands -> products -> pivot -> scaling -> the next column's operands), a
+// few hundred cycles when its operands are in LDS — and 1.3 us when each column first fetches its own index words
+// from HBM (measured: the first version of this file). So everything that does NOT depend on values is taken off the
+// chain: the descriptions of up to 64 columns of the list are loaded at once, one 32-byte record per lane, and handed
+// round by v_readlane; the index words of a column's first 64 products / row entries are loaded two columns ahead
+// (three register sets in rotation); the entries of L start out as the entries of A (a parallel pass before the
+// factorization), so a column never looks at A or at the A -> L map.
+struct ColPre {  // what is prefetched for one column: products (two operands, target entry), row-j entry (value, column)
+    uint2 pr;
+    uint32_t pk, ri, rc;
+};
+__device__ __forceinline__ ColDesc desc_of_lane(const ColDesc& mine, int i) {
+    ColDesc d;
+    d.j = __builtin_amdgcn_readlane(mine.j, i);
+    d.beg = __builtin_amdgcn_readlane(mine.beg, i);
+    d.end = __builtin_amdgcn_readlane(mine.end, i);
+    d.rbeg = __builtin_amdgcn_readlane(mine.rbeg, i);
+    d.rend = __builtin_amdgcn_readlane(mine.rend, i);
+    d.pbeg = __builtin_amdgcn_readlane(mine.pbeg, i);
+    d.pend0 = __builtin_amdgcn_readlane(mine.pend0, i);
+    d.pad = __builtin_amdgcn_readlane(mine.pad, i);
+    return d;
+}
+
+// The columns [t0, t1) of a list, bottom-up: numeric Cholesky (left-looking by gather lists) with the forward sweep
+// L y = b riding along — once column j is factored, row j of L is complete, so y_j follows at once. FACTOR = false: the
+// forward sweep alone with the stored factor (the refined step needs it again). LDSV: l and b live in LDS.
+// 64 entries of a column at a time (almost every column has fewer): all their products in one flat, lane-strided sweep
+// — they are contiguous, lpair_ptr is a prefix over the entries — summed per entry with LDS atomics. `acc`: 64 doubles
+// of LDS owned by the wavefront. On entry l holds the entries of A. Returns false when a pivot is not positive and finite.
+// `first`: the lane's description of column t0 + lane, loaded by the caller (a level ahead: before the barrier).
+// BLOB: the index data is a segment blob in LDS (fx_sparse_plan.h: SegmentBlobs) — segment-local 16-bit indices, packed.
+template <bool LDSV, bool FACTOR, bool BLOB = false>
+__device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& lr, const ColDesc* cd, uint32_t t0, uint32_t t1,
+                                             const ColDesc& first, double lambda, double* l, double* b, double* acc, int lane, uint32_t lb = 0,
+                                             uint32_t cb = 0) {
+    // lb, cb: l and b hold a segment's run of entries / of columns, l[entry - lb], b[column - cb] (0: the whole factor)
     bool ok = true;
-    if (t0 >= t1) return ok;
-    const uint2* __restrict__ lpairs2 = reinterpret_cast<const uint2*>(c.lpairs);
-    ColDesc nd = cd[t0];
-    uint2 npr = make_uint2(0u, 0u);
-    uint32_t npk = 0, nri = 0, nrc = 0;
-    double nav = 0.0;
-    auto fetch = [&](const ColDesc& d) {
+    auto ld_pair = [&](uint32_t p) -> uint2 {
+        if (BLOB) {
+            const uint32_t w = c.lpairs[p];
+            return make_uint2(w & 0xFFFFu, w >> 16);
+        }
+        return reinterpret_cast<const uint2*>(c.lpairs)[p];
+    };
+    auto ld_pk = [&](uint32_t p) -> uint32_t { return BLOB ? (uint32_t)reinterpret_cast<const uint16_t*>(c.lpair_k)[p] : c.lpair_k[p]; };
+    auto ld_row = [&](uint32_t r, uint32_t& ri, uint32_t& rc) {
+        if (BLOB) {
+            const uint32_t w = lr.ridx[r];
+            ri = w & 0xFFFFu;
+            rc = w >> 16;
+        } else {
+            ri = lr.ridx[r];
+            rc = lr.rcol[r];
+        }
+    };
+    auto fetch = [&](const ColDesc& d, ColPre& o) {
         if (FACTOR) {
             const uint32_t p = d.pbeg + lane;
             if (p < d.pend0) {
-                npr = lpairs2[p];
-                npk = c.lpair_k[p];
-            }
-            const uint32_t k = d.beg + lane;
-            if (k < d.end) {
-                const int32_t ai = c.l2a[k];
-                nav = ai >= 0 ? a[ai] : 0.0;
+                o.pr = ld_pair(p);
+                o.pk = ld_pk(p);
             }
         }
         const uint32_t r = d.rbeg + lane;
-        if (r < d.rend) {
-            nri = lr.ridx[r];
-            nrc = lr.rcol[r];
-        }
+        if (r < d.rend) ld_row(r, o.ri, o.rc);
     };
-    fetch(nd);
-    for (uint32_t t = t0; t < t1; ++t) {
-        const ColDesc d = nd;
-        const uint2 pr = npr;
-        const uint32_t pk = npk, ri = nri, rc = nrc;
-        const double av = nav;
-        if (t + 1 < t1) {
-            nd = cd[t + 1];
-            fetch(nd);
-        }
+    auto column = [&](const ColDesc& d, const ColPre& q) {
         double part = 0.0;  // forward-sweep gather for row j (all of its columns are final already)
         {
             uint32_t r = d.rbeg + lane;
-            if (r < d.rend) part = l[ri] * b[rc];
-            for (r += 64; r < d.rend; r += 64) part = fma(l[lr.ridx[r]], b[lr.rcol[r]], part);
+            if (r < d.rend) part = l[q.ri - lb] * b[q.rc - cb];
+            for (r += 64; r < d.rend; r += 64) {
+                uint32_t ri, rc;
+                ld_row(r, ri, rc);
+                part = fma(l[ri - lb], b[rc - cb], part);
+            }
         }
-        double dg = 0.0;
+        double inv;  // 1 / L_jj
         if (FACTOR) {
+            inv = 0.0;
             for (uint32_t base = d.beg; base < d.end; base += 64) {
                 const bool first = base == d.beg;
                 const uint32_t k = base + lane, cend = min(base + 64u, d.end);
                 double s = 0.0;
                 if (k < cend) {
-                    if (first) {
-                        s = av;
-                    } else {
-                        const int32_t ai = c.l2a[k];
-                        s = ai >= 0 ? a[ai] : 0.0;
-                    }
+                    s = l[k - lb];  // the entry of A (0 for fill-in)
                     if (k == d.beg) s += lambda;
                 }
                 const uint32_t pb = first ? d.pbeg : c.lpair_ptr[base], pe = first ? d.pend0 : c.lpair_ptr[cend];
                 if (pe > pb) {  // (wave-uniform) leaves of the tree have no products at all
                     acc[lane] = 0.0;
+                    // a pass whose 64 products all belong to one entry (the diagonal of a column every other column
+                    // reaches): one butterfly and one add instead of 64 atomics on one address
+                    auto add = [&](bool live, uint32_t tgt, double v) {
+                        const uint32_t t0u = (uint32_t)__builtin_amdgcn_readfirstlane((int)tgt);
+                        if (__ballot(!live || tgt != t0u) == 0ull) {
+                            v = wave_sum(v);
+                            if (lane == 0) acc[t0u] += v;
+                        } else if (live) {
+                            lds_add_f64(&acc[tgt], v);
+                        }
+                    };
                     uint32_t p = pb + lane;
                     if (first) {
-                        if (p < pe) lds_add_f64(&acc[pk - base], -l[pr.x] * l[pr.y]);
+                        add(p < pe, p < pe ? q.pk - base : 0u, p < pe ? -l[q.pr.x - lb] * l[q.pr.y - lb] : 0.0);
                         p += 64;
                     }
-                    for (; p < pe; p += 64) {
-                        const uint2 q2 = lpairs2[p];
-                        lds_add_f64(&acc[c.lpair_k[p] - base], -l[q2.x] * l[q2.y]);
+                    for (uint32_t p0 = pb + (first ? 64u : 0u); p0 < pe; p0 += 64, p += 64) {
+                        uint2 q2 = make_uint2(0u, 0u);
+                        uint32_t tg = 0;
+                        if (p < pe) {
+                            q2 = ld_pair(p);
+                            tg = ld_pk(p) - base;
+                        }
+                        add(p < pe, tg, p < pe ? -l[q2.x - lb] * l[q2.y - lb] : 0.0);
                     }
                     wave_sync_lds();
                     if (k < cend) s += acc[lane];
@@ -178,86 +216,211 @@ __device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& l
                 if (first) {
                     const double piv = bcast_first(s);
                     ok = ok && (piv > 0.0) && (piv < 1.0e300);
-                    dg = ::sqrt(piv);
+                    inv = rsqrt_refined(piv);  // (v_rsq_f64 + two Newton steps: a quarter of sqrt + division on the chain)
+                    if (lane == 0) s = piv * inv;
                 }
-                if (k < cend) l[k] = (k == d.beg) ? dg : s / dg;
+                if (k < cend) l[k - lb] = (k == d.beg) ? s : s * inv;
             }
         } else {
-            dg = l[d.beg];
+            inv = 1.0 / l[d.beg - lb];  // (the stored diagonal is pivot / sqrt(pivot))
         }
-        part = wave_sum64(part);
-        if (lane == 0) b[d.j] = (b[d.j] - part) / dg;
+        part = wave_sum(part);
+        if (lane == 0) b[d.j - cb] = (b[d.j - cb] - part) * inv;
         vals_sync<LDSV>();  // the next column of this list may read what this one stored
+    };
+    for (uint32_t tb = t0; tb < t1; tb += 64) {  // (more than 64 columns: 64 descriptions at a time)
+        const uint32_t nb = min(64u, t1 - tb);
+        ColDesc mine = first;
+        if (tb != t0) {
+            mine = ColDesc{};
+            if ((uint32_t)lane < nb) mine = cd[tb + lane];
+        }
+        ColDesc d0 = desc_of_lane(mine, 0), d1{}, d2{};
+        ColPre q0{}, q1{}, q2{};
+        fetch(d0, q0);
+        if (nb > 1) {
+            d1 = desc_of_lane(mine, 1);
+            fetch(d1, q1);
+        }
+        for (uint32_t i = 0; i < nb; ++i) {  // column i + 2 is fetched while columns i and i + 1 compute
+            if (i + 2 < nb) {
+                d2 = desc_of_lane(mine, (int)(i + 2));
+                fetch(d2, q2);
+            }
+            column(d0, q0);
+            d0 = d1;  // (one copy of the column's code: the register sets rotate by moves)
+            q0 = q1;
+            d1 = d2;
+            q1 = q2;
+        }
     }
     return ok;
 }
 
 // Lt x = y, the columns of a list top-down: x_j = (y_j - sum_{i>j} L_ij x_i) / L_jj reads only ancestors of j
-template <bool LDSV>
-__device__ __forceinline__ void team_walk_down(const SpChol& c, const ColDesc* __restrict__ cd, uint32_t t0, uint32_t t1, const double* l,
-                                               double* b, int lane) {
-    if (t0 >= t1) return;
-    ColDesc nd = cd[t1 - 1];
-    uint32_t nrow = 0;
-    auto fetch = [&](const ColDesc& d) {
+// `last`: the lane's description of column t1 - min(64, t1 - t0) + lane, loaded by the caller.
+template <bool LDSV, bool USE_MID = false, bool BLOB = false>
+__device__ __forceinline__ void team_walk_down(const SpChol& c, const ColDesc* cd, uint32_t t0, uint32_t t1, const ColDesc& last,
+                                               const double* l, double* b, int lane, uint32_t lb = 0, uint32_t cb = 0) {
+    auto ld_lrow = [&](uint32_t k) -> uint32_t { return BLOB ? (uint32_t)reinterpret_cast<const uint16_t*>(c.lrow)[k] : c.lrow[k]; };
+    auto fetch = [&](const ColDesc& d, uint32_t& row) {
         const uint32_t k = d.beg + 1 + lane;
-        if (k < d.end) nrow = c.lrow[k];
+        if (k < (USE_MID ? d.pad : d.end)) row = ld_lrow(k);
     };
-    fetch(nd);
-    for (uint32_t t = t1; t-- > t0;) {
-        const ColDesc d = nd;
-        const uint32_t row = nrow;
-        if (t > t0) {
-            nd = cd[t - 1];
-            fetch(nd);
-        }
+    auto column = [&](const ColDesc& d, uint32_t row) {
         double part = 0.0;
         uint32_t k = d.beg + 1 + lane;
-        if (k < d.end) part = l[k] * b[row];
-        for (k += 64; k < d.end; k += 64) part = fma(l[k], b[c.lrow[k]], part);
-        part = wave_sum64(part);
-        if (lane == 0) b[d.j] = (b[d.j] - part) / l[d.beg];
+        const uint32_t kend = USE_MID ? d.pad : d.end;  // (LDS build of a part: the entries whose rows are in the top were taken before)
+        if (k < kend) part = l[k - lb] * b[row - cb];
+        for (k += 64; k < kend; k += 64) part = fma(l[k - lb], b[ld_lrow(k) - cb], part);
+        part = wave_sum(part);
+        if (lane == 0) b[d.j - cb] = (b[d.j - cb] - part) / l[d.beg - lb];
         vals_sync<LDSV>();
+    };
+    for (uint32_t te = t1; te > t0;) {  // 64 descriptions at a time, from the end of the list
+        const uint32_t nb = min(64u, te - t0), tb = te - nb;
+        ColDesc mine = last;
+        if (te != t1) {
+            mine = ColDesc{};
+            if ((uint32_t)lane < nb) mine = cd[tb + lane];
+        }
+        ColDesc d0 = desc_of_lane(mine, (int)nb - 1), d1{}, d2{};
+        uint32_t r0 = 0, r1 = 0, r2 = 0;
+        fetch(d0, r0);
+        if (nb > 1) {
+            d1 = desc_of_lane(mine, (int)nb - 2);
+            fetch(d1, r1);
+        }
+        for (uint32_t i = 0; i < nb; ++i) {  // i-th column from the end
+            if (i + 2 < nb) {
+                d2 = desc_of_lane(mine, (int)(nb - 3 - i));
+                fetch(d2, r2);
+            }
+            column(d0, r0);
+            d0 = d1;
+            r0 = r1;
+            d1 = d2;
+            r1 = r2;
+        }
+        te = tb;
     }
 }
 
-// A segment's factorization + forward sweep by the calling workgroup: levels bottom-up, a barrier after each.
+// A segment's factorization + forward sweep by the calling workgroup: levels bottom-up, a barrier after each; a
+// wavefront walks its run of columns of the level, and loads the descriptions of its next run before the barrier.
 // Returns (to every thread of a wavefront) whether its pivots were fine.
-template <bool LDSV, bool FACTOR>
+template <bool LDSV, bool FACTOR, bool BLOB = false>
 __device__ __forceinline__ bool team_factor_forward(const SpChol& c, const SpRowsOfL& lr, const SpTeamSched& sc, uint32_t seg,
-                                                    const double* __restrict__ a, double lambda, double* l, double* b, double* s_acc) {
+                                                    double lambda, double* l, double* b, double* s_acc, unsigned long long* wprof = nullptr,
+                                                    uint32_t lb = 0, uint32_t cb = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool wstamp = wprof && threadIdx.x == 0;  // diagnostics: wavefront 0's walk / barrier time, level 0 and above
     bool ok = true;
-    for (uint32_t q = sc.seg_lev[seg]; q < sc.seg_lev[seg + 1]; ++q) {
-        for (uint32_t list = sc.lev_list[q] + wave; list < sc.lev_list[q + 1]; list += TEAM_NWAVES)
-            ok = team_walk_up<LDSV, FACTOR>(c, lr, sc.cdesc, sc.list_ptr[list], sc.list_ptr[list + 1], a, lambda, l, b, s_acc + wave * 64, lane) && ok;
+    uint32_t q = sc.seg_lev[seg];
+    const uint32_t qend = sc.seg_lev[seg + 1];
+    if (q >= qend) return ok;
+    uint32_t t0 = sc.wptr[q * TEAM_NWAVES + wave], t1 = sc.wptr[q * TEAM_NWAVES + wave + 1];
+    ColDesc mine{};
+    if (t0 + lane < t1) mine = sc.cdesc[t0 + lane];
+    for (; q < qend; ++q) {
+        uint32_t n0 = 0, n1 = 0;
+        ColDesc next{};
+        if (q + 1 < qend) {
+            n0 = sc.wptr[(q + 1) * TEAM_NWAVES + wave];
+            n1 = sc.wptr[(q + 1) * TEAM_NWAVES + wave + 1];
+            if (n0 + lane < n1) next = sc.cdesc[n0 + lane];
+        }
+        const unsigned long long w0 = wstamp ? wall_clock64() : 0ull;
+        if (t0 < t1) ok = team_walk_up<LDSV, FACTOR, BLOB>(c, lr, sc.cdesc, t0, t1, mine, lambda, l, b, s_acc + wave * 64, lane, lb, cb) && ok;
+        const unsigned long long w1 = wstamp ? wall_clock64() : 0ull;
         __syncthreads();
+        if (wstamp) {
+            const unsigned long long w2 = wall_clock64();
+            const int slot = q == sc.seg_lev[seg] ? 0 : 2;
+            wprof[slot] += w1 - w0;
+            wprof[slot + 1] += w2 - w1;
+            if (slot == 0) wprof[4] += t1 - t0;
+        }
+        t0 = n0;
+        t1 = n1;
+        mine = next;
     }
     return ok;
 }
 
-template <bool LDSV>
-__device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched& sc, uint32_t seg, const double* l, double* b) {
+template <bool LDSV, bool USE_MID = false, bool BLOB = false>
+__device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched& sc, uint32_t seg, const double* l, double* b, uint32_t lb = 0,
+                                              uint32_t cb = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t q = sc.seg_lev[seg + 1]; q-- > sc.seg_lev[seg];) {
-        for (uint32_t list = sc.lev_list[q] + wave; list < sc.lev_list[q + 1]; list += TEAM_NWAVES)
-            team_walk_down<LDSV>(c, sc.cdesc, sc.list_ptr[list], sc.list_ptr[list + 1], l, b, lane);
+    const uint32_t qbeg = sc.seg_lev[seg];
+    uint32_t q = sc.seg_lev[seg + 1];
+    if (q <= qbeg) return;
+    auto load_last = [&](uint32_t a0, uint32_t a1) {
+        ColDesc d{};
+        const uint32_t nb = min(64u, a1 - a0);
+        if ((uint32_t)lane < nb) d = sc.cdesc[a1 - nb + lane];
+        return d;
+    };
+    uint32_t t0 = sc.wptr[(q - 1) * TEAM_NWAVES + wave], t1 = sc.wptr[(q - 1) * TEAM_NWAVES + wave + 1];
+    ColDesc mine = load_last(t0, t1);
+    for (; q-- > qbeg;) {
+        uint32_t n0 = 0, n1 = 0;
+        ColDesc next{};
+        if (q > qbeg) {
+            n0 = sc.wptr[(q - 1) * TEAM_NWAVES + wave];
+            n1 = sc.wptr[(q - 1) * TEAM_NWAVES + wave + 1];
+            next = load_last(n0, n1);
+        }
+        if (t0 < t1) team_walk_down<LDSV, USE_MID, BLOB>(c, sc.cdesc, t0, t1, mine, l, b, lane, lb, cb);
         __syncthreads();
+        t0 = n0;
+        t1 = n1;
+        mine = next;
     }
+}
+
+// A segment blob (fx_sparse_plan.h: SegmentBlobs), copied into LDS by the whole workgroup, and the views the walkers take
+__device__ __forceinline__ void team_load_blob(const uint32_t* __restrict__ g, uint32_t* s, uint32_t nwords) {
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    uint4* s4 = reinterpret_cast<uint4*>(s);
+    for (uint32_t i = threadIdx.x; i < nwords / 4u; i += TEAM_THREADS) s4[i] = g4[i];
+}
+__device__ __forceinline__ void team_blob_views(const uint32_t* s, SpChol& c, SpRowsOfL& lr, SpTeamSched& sc) {
+    c.lcolptr = nullptr;
+    c.l2a = nullptr;
+    c.lpair_ptr = s + s[7];
+    c.lrow = s + s[8];
+    c.lpairs = s + s[9];
+    c.lpair_k = s + s[10];
+    c.nv = s[1];
+    lr.rptr = nullptr;
+    lr.ridx = s + s[11];
+    lr.rcol = nullptr;
+    sc.seg_lev = s + 12;
+    sc.wptr = s + s[5];
+    sc.cols = nullptr;
+    sc.cdesc = reinterpret_cast<const ColDesc*>(s + s[6]);
+    sc.cdesc_mid = nullptr;
+    sc.nparts = 0;
 }
 
 // K3 for the calling workgroup's share (first, step over the items): A = JtJ (lower triangle, permuted order) and
 // -Jt r by deterministic gathers, one thread per entry; the few entries whose gather lists are long (the diagonal of a
 // point every constraint hangs on: one product per constraint) are summed by a wavefront each, a fixed butterfly.
-// The right-hand side goes to `rhs` (kept: a rejected trial solves with it again) and to `vec`, the vector the solves overwrite.
-__device__ __forceinline__ void team_form(const SpBlock& B, const double* jc, const double* rc, double* a, double* rhs, double* vec,
+// The right-hand side goes to `rhs` (kept: a rejected trial solves with it again) and to `vec`, the vector the solves
+// overwrite; an entry of A goes to `a` (kept likewise) and to its place in `lf`, where the factorization starts from
+// (fill-in entries start as 0).
+__device__ __forceinline__ void team_form(const SpBlock& B, const double* jc, const double* rc, double* a, double* rhs, double* vec, double* lf,
                                           uint32_t first, uint32_t step, uint32_t wave_first, uint32_t wave_step) {
+    for (uint32_t k = first; k < B.nnz_l; k += step)
+        if (B.chol.l2a[k] < 0) lf[k] = 0.0;
     for (uint32_t k = first; k < B.nnz_a; k += step) {
         const uint32_t pb = B.apair_ptr[k], pe = B.apair_ptr[k + 1];
         if (pe - pb > FORM_LONG) continue;
         double s = 0.0;
         for (uint32_t p = pb; p < pe; ++p) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
         a[k] = s;
+        lf[B.a2l[k]] = s;
     }
     for (uint32_t c = first; c < B.nv; c += step) {
         const uint32_t pb = B.cptr[c], pe = B.cptr[c + 1];
@@ -274,7 +437,10 @@ __device__ __forceinline__ void team_form(const SpBlock& B, const double* jc, co
             const uint32_t k = B.along[i];
             for (uint32_t p = B.apair_ptr[k] + lane; p < B.apair_ptr[k + 1]; p += 64) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
             s = wave_sum64(s);
-            if (lane == 0) a[k] = s;
+            if (lane == 0) {
+                a[k] = s;
+                lf[B.a2l[k]] = s;
+            }
         } else {
             const uint32_t c = B.along[i];
             for (uint32_t p = B.cptr[c] + lane; p < B.cptr[c + 1]; p += 64) s += jc[B.cidx[p]] * -rc[B.crow[p]];
@@ -282,6 +448,65 @@ __device__ __forceinline__ void team_form(const SpBlock& B, const double* jc, co
             if (lane == 0) {
                 rhs[c] = s;
                 vec[c] = s;
+            }
+        }
+    }
+}
+
+// K3 for one segment into the workgroup's LDS: the entries [eb, ee) of L start as the entries of A (0 for fill-in),
+// the columns [cb, ce) of the vector as the right-hand side. need_form: A and -Jt r are formed from the current Jacobian
+// rows (and kept in `a` / `rhs`); otherwise — a rejected trial — the kept values are taken again. Long gather lists as
+// in team_form: a wavefront each.
+__device__ __forceinline__ void team_form_segment(const SpBlock& B, const double* jc, const double* rc, double* a, double* rhs, double* s_l,
+                                                  double* s_b, uint32_t eb, uint32_t ee, uint32_t cb, uint32_t ce, bool need_form) {
+    for (uint32_t k = eb + threadIdx.x; k < ee; k += TEAM_THREADS) {
+        const int32_t ai = B.chol.l2a[k];
+        double s = 0.0;
+        if (ai >= 0) {
+            if (need_form) {
+                const uint32_t pb = B.apair_ptr[ai], pe = B.apair_ptr[ai + 1];
+                if (pe - pb > FORM_LONG) continue;
+                for (uint32_t p = pb; p < pe; ++p) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
+                a[ai] = s;
+            } else {
+                s = a[ai];
+            }
+        }
+        s_l[k - eb] = s;
+    }
+    for (uint32_t c = cb + threadIdx.x; c < ce; c += TEAM_THREADS) {
+        double s = 0.0;
+        if (need_form) {
+            const uint32_t pb = B.cptr[c], pe = B.cptr[c + 1];
+            if (pe - pb > FORM_LONG) continue;
+            for (uint32_t p = pb; p < pe; ++p) s += jc[B.cidx[p]] * -rc[B.crow[p]];
+            rhs[c] = s;
+        } else {
+            s = rhs[c];
+        }
+        s_b[c - cb] = s;
+    }
+    if (!need_form) return;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = threadIdx.x >> 6; i < B.n_along + B.n_clong; i += TEAM_NWAVES) {
+        double s = 0.0;
+        if (i < B.n_along) {
+            const uint32_t k = B.along[i], le = B.a2l[k];
+            if (le < eb || le >= ee) continue;
+            for (uint32_t p = B.apair_ptr[k] + lane; p < B.apair_ptr[k + 1]; p += 64) s += jc[B.apairs[2 * p]] * jc[B.apairs[2 * p + 1]];
+            s = wave_sum64(s);
+            if (lane == 0) {
+                a[k] = s;
+                s_l[le - eb] = s;
+            }
+        } else {
+            const uint32_t c = B.along[i];
+            if (c < cb || c >= ce) continue;
+            for (uint32_t p = B.cptr[c] + lane; p < B.cptr[c + 1]; p += 64) s += jc[B.cidx[p]] * -rc[B.crow[p]];
+            s = wave_sum64(s);
+            if (lane == 0) {
+                rhs[c] = s;
+                s_b[c - cb] = s;
             }
         }
     }
@@ -435,14 +660,26 @@ __device__ __forceinline__ void team_block_epilogue(const SpBlock& B, const SpVa
     }
 }
 
+// a rejected trial factors the same A again with a larger lambda: the factor array back to the entries of A
+__device__ __forceinline__ void team_refill(const SpBlock& B, const double* a, const double* rhs, double* vec, double* lf, uint32_t first,
+                                            uint32_t step) {
+    for (uint32_t k = first; k < B.nnz_l; k += step) {
+        const int32_t ai = B.chol.l2a[k];
+        lf[k] = ai >= 0 ? a[ai] : 0.0;
+    }
+    for (uint32_t c = first; c < B.nv; c += step) vec[c] = rhs[c];
+}
+
 // ---- the whole LM loop of one block, one workgroup per System ------------------------------------------------------
 // LDSV: the factor and the solves' vectors live in LDS (dynamic: lds_l doubles of L, then two vectors of lds_v) — every
 // step of a column's dependent chain is then an LDS round trip instead of an L2 one. The host picks it when they fit.
-template <bool POSE, bool LDSV>
+// BLOB (with LDSV): the factor's index data sits in LDS as well, copied once for the whole solve (fx_sparse_plan.h:
+// SegmentBlobs) — a column's chain then touches HBM not at all.
+template <bool POSE, bool LDSV, bool BLOB>
 __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum,
                                                                    fx_lm_opts o, uint32_t flags, double* __restrict__ vars_base,
                                                                    const uint64_t* __restrict__ out_off, uint32_t lds_l, uint32_t lds_v,
-                                                                   unsigned long long* prof) {
+                                                                   const uint32_t* __restrict__ blob, uint32_t blob_words, unsigned long long* prof) {
     // prof (diagnostics, FIKSI_AMD_TEAM_PROF=1; else null): workgroup 0 adds up the 100 MHz ticks of its phases
     const bool stamp = prof && blockIdx.x == 0 && threadIdx.x == 0;
     unsigned long long t_prev = stamp ? wall_clock64() : 0ull;
@@ -465,6 +702,15 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
     double* const dvec = LDSV ? s_dyn + lds_l : V.delta;        // right-hand side -> step
     double* const evec = LDSV ? s_dyn + lds_l + lds_v : V.e;    // the refinement's
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SpChol chol = B.chol;
+    SpRowsOfL lrows = B.lrows;
+    SpTeamSched sched = B.sched;
+    if (BLOB) {
+        uint32_t* s_blob = reinterpret_cast<uint32_t*>(s_dyn + lds_l + 2 * lds_v);
+        team_load_blob(blob, s_blob, blob_words);
+        __syncthreads();
+        team_blob_views(s_blob, chol, lrows, sched);
+    }
 
     for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, V.xs0, V.r0, V.j0);
     __syncthreads();
@@ -474,22 +720,19 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
     while (!st.done) {
         const double* jc = st.cur ? V.j1 : V.j0;
         const double* rc = st.cur ? V.r1 : V.r0;
-        if (st.need_form) {
-            team_form(B, jc, rc, V.a, V.rhs, dvec, tid, TEAM_THREADS, wave, TEAM_NWAVES);
-        } else {
-            for (uint32_t c = tid; c < nv; c += TEAM_THREADS) dvec[c] = V.rhs[c];
-        }
+        if (st.need_form) team_form(B, jc, rc, V.a, V.rhs, dvec, fl, tid, TEAM_THREADS, wave, TEAM_NWAVES);
+        else team_refill(B, V.a, V.rhs, dvec, fl, tid, TEAM_THREADS);
         if (tid == 0) s_bad = 0;
         __syncthreads();
         mark(1);
-        const bool ok = team_factor_forward<LDSV, true>(B.chol, B.lrows, B.sched, 0, V.a, st.lambda, fl, dvec, s_acc);
+        const bool ok = team_factor_forward<LDSV, true, BLOB>(chol, lrows, sched, 0, st.lambda, fl, dvec, s_acc, stamp ? prof + 8 : nullptr);
         if (!ok && (tid & 63) == 0) atomicOr(&s_bad, 1u);
         __syncthreads();
         st.flag = s_bad;
         __syncthreads();  // (s_bad is cleared again at the top of the next trial)
         mark(2);
         if (!st.flag) {
-            team_backward<LDSV>(B.chol, B.sched, 0, fl, dvec);
+            team_backward<LDSV, false, BLOB>(chol, sched, 0, fl, dvec);
             mark(3);
             if (flags & TEAM_REFINED) {  // corrected semi-normal equations, as sp_refine_*: t = -r - J delta, (A + lambda I) e = Jt t - lambda delta
                 for (uint32_t row = tid; row < m; row += TEAM_THREADS) {
@@ -504,8 +747,8 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
                     evec[c] = s - st.lambda * dvec[c];
                 }
                 __syncthreads();
-                team_factor_forward<LDSV, false>(B.chol, B.lrows, B.sched, 0, V.a, 0.0, fl, evec, s_acc);
-                team_backward<LDSV>(B.chol, B.sched, 0, fl, evec);
+                team_factor_forward<LDSV, false, BLOB>(chol, lrows, sched, 0, 0.0, fl, evec, s_acc);
+                team_backward<LDSV, false, BLOB>(chol, sched, 0, fl, evec);
                 for (uint32_t c = tid; c < nv; c += TEAM_THREADS) dvec[c] += evec[c];
                 __syncthreads();
                 mark(4);
@@ -727,11 +970,8 @@ __global__ __launch_bounds__(256) void spt_form_kernel(SpBlock B, SpVals V, cons
     if (st->done) return;
     V.shift(blockIdx.y);
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
-    if (st->need_form) {
-        team_form(B, st->cur ? V.j1 : V.j0, st->cur ? V.r1 : V.r0, V.a, V.rhs, V.delta, i, n, i >> 6, n >> 6);
-    } else {
-        for (uint32_t c = i; c < B.nv; c += n) V.delta[c] = V.rhs[c];
-    }
+    if (st->need_form) team_form(B, st->cur ? V.j1 : V.j0, st->cur ? V.r1 : V.r0, V.a, V.rhs, V.delta, V.l, i, n, i >> 6, n >> 6);
+    else team_refill(B, V.a, V.rhs, V.delta, V.l, i, n);
 }
 
 // which: 0 = factor + forward sweep on delta; 1 = forward sweep of the refinement on e
@@ -741,26 +981,26 @@ __global__ __launch_bounds__(TEAM_THREADS) void spt_parts_up_kernel(SpBlock B, S
     if (st->done || (which && st->flag)) return;
     V.shift(blockIdx.y);
     if (which == 0) {
-        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, blockIdx.x, V.a, st->lambda, V.l, V.delta, s_acc);
+        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, blockIdx.x, st->lambda, V.l, V.delta, s_acc);
         if (!ok && (threadIdx.x & 63) == 0) atomicOr(&st->flag, 1u);
     } else {
-        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, blockIdx.x, V.a, 0.0, V.l, V.e, s_acc);
+        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, blockIdx.x, 0.0, V.l, V.e, s_acc);
     }
 }
 
-// the trial point of the columns [first, last) of list_cols: xs[cur ^ 1] = xs[cur] + delta
+// the trial point of the columns [first, last) of the walking order: xs[cur ^ 1] = xs[cur] + delta
 __device__ __forceinline__ void team_trial_point(const SpBlock& B, const SpVals& V, uint32_t cur, uint32_t first, uint32_t last) {
     const double* xc = cur ? V.xs1 : V.xs0;
     double* xt = cur ? V.xs0 : V.xs1;
     for (uint32_t t = first + threadIdx.x; t < last; t += TEAM_THREADS) {
-        const uint32_t k = B.sched.list_cols[t];
+        const uint32_t k = B.sched.cols[t];
         const uint32_t v = B.fvar[B.perm[k]];
         xt[v] = xc[v] + V.delta[k];
     }
 }
 __device__ __forceinline__ void team_segment_columns(const SpTeamSched& sc, uint32_t seg, uint32_t& first, uint32_t& last) {
-    first = sc.list_ptr[sc.lev_list[sc.seg_lev[seg]]];
-    last = sc.list_ptr[sc.lev_list[sc.seg_lev[seg + 1]]];
+    first = sc.wptr[sc.seg_lev[seg] * TEAM_NWAVES];
+    last = sc.wptr[sc.seg_lev[seg + 1] * TEAM_NWAVES];
 }
 
 // the top of the tree: its factorization + forward sweep, then its backward sweep. which as above; `last` = nothing
@@ -777,7 +1017,7 @@ __global__ __launch_bounds__(TEAM_THREADS) void spt_top_kernel(SpBlock B, SpVals
         if (st->flag) return;  // a part met a bad pivot
         if (threadIdx.x == 0) s_bad = 0;
         __syncthreads();
-        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, top, V.a, st->lambda, V.l, V.delta, s_acc);
+        const bool ok = team_factor_forward<false, true>(B.chol, B.lrows, B.sched, top, st->lambda, V.l, V.delta, s_acc);
         if (!ok && (threadIdx.x & 63) == 0) atomicOr(&s_bad, 1u);
         __syncthreads();
         if (s_bad) {
@@ -785,14 +1025,14 @@ __global__ __launch_bounds__(TEAM_THREADS) void spt_top_kernel(SpBlock B, SpVals
             return;
         }
     } else {
-        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, top, V.a, 0.0, V.l, V.e, s_acc);
+        team_factor_forward<false, false>(B.chol, B.lrows, B.sched, top, 0.0, V.l, V.e, s_acc);
     }
     team_backward<false>(B.chol, B.sched, top, V.l, vec);
     uint32_t first, end;
     team_segment_columns(B.sched, top, first, end);
     if (which) {
         for (uint32_t t = first + threadIdx.x; t < end; t += TEAM_THREADS) {
-            const uint32_t k = B.sched.list_cols[t];
+            const uint32_t k = B.sched.cols[t];
             V.delta[k] += V.e[k];
         }
         __syncthreads();
@@ -810,12 +1050,170 @@ __global__ __launch_bounds__(TEAM_THREADS) void spt_parts_down_kernel(SpBlock B,
     team_segment_columns(B.sched, blockIdx.x, first, end);
     if (which) {
         for (uint32_t t = first + threadIdx.x; t < end; t += TEAM_THREADS) {
-            const uint32_t k = B.sched.list_cols[t];
+            const uint32_t k = B.sched.cols[t];
             V.delta[k] += V.e[k];
         }
         __syncthreads();
     }
     if (last) team_trial_point(B, V, st->cur, first, end);
+}
+
+// ---- the same three steps with every segment's values in LDS (the plain step; fx_sparse_plan.h: PartsExtra) ----------
+// A column's chain then runs on LDS round trips instead of L2 ones (measured on cfg2: the top alone took 100 us per
+// trial from HBM). Segments are runs of columns and of entries, so LDS slot = index - first index of the segment. What
+// the top needs from the parts — the products of its entries and of its right-hand side that belong to part columns —
+// each part sums from its own LDS into a slot of a contribution buffer; the top subtracts its slots and then only sees
+// its own columns.
+struct SpPartsX {
+    const uint32_t *seg_col, *seg_ent;
+    const uint32_t *frun_ptr, *frun, *fslot_ptr, *brun_ptr, *brun, *bslot_ptr;
+    const uint32_t* blobs;     // the segments' index data for LDS (fx_sparse_plan.h: SegmentBlobs; the top's: its own products)
+    const uint32_t* blob_off;  // [nseg + 1]
+    const uint32_t* cmid;      // [nv] first entry of a column whose row is in the top
+    uint32_t nparts;
+};
+struct SpContrib {
+    double *f, *b;         // [slots] per System, at System * stride
+    size_t stride;
+};
+
+__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_up_kernel(SpBlock B, SpPartsX X, SpVals V, SpContrib C, SpLm* __restrict__ lm,
+                                                                      unsigned long long* prof) {
+    extern __shared__ double s_dyn[];
+    __shared__ double s_acc[TEAM_NWAVES * 64];
+    SpLm* st = lm + blockIdx.y;
+    if (st->done) return;
+    const bool stamp = prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;  // diagnostics (FIKSI_AMD_TEAM_PROF)
+    unsigned long long t_prev = stamp ? wall_clock64() : 0ull;
+    auto mark = [&](int slot) {
+        if (stamp) {
+            const unsigned long long now = wall_clock64();
+            prof[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
+    V.shift(blockIdx.y);
+    const uint32_t part = blockIdx.x, tid = threadIdx.x;
+    const uint32_t eb = X.seg_ent[part], ne = X.seg_ent[part + 1] - eb, cb = X.seg_col[part], nc = X.seg_col[part + 1] - cb;
+    double* const s_l = s_dyn;
+    double* const s_b = s_dyn + ((ne + 1u) & ~1u);
+    uint32_t* const s_blob = reinterpret_cast<uint32_t*>(s_b + ((nc + 1u) & ~1u));
+    team_load_blob(X.blobs + X.blob_off[part], s_blob, X.blob_off[part + 1] - X.blob_off[part]);
+    team_form_segment(B, st->cur ? V.j1 : V.j0, st->cur ? V.r1 : V.r0, V.a, V.rhs, s_l, s_b, eb, eb + ne, cb, cb + nc, st->need_form != 0);
+    __syncthreads();
+    SpChol chol;
+    SpRowsOfL lrows;
+    SpTeamSched sched;
+    team_blob_views(s_blob, chol, lrows, sched);
+    mark(0);
+    const bool ok = team_factor_forward<true, true, true>(chol, lrows, sched, 0, st->lambda, s_l, s_b, s_acc, stamp ? prof + 8 : nullptr);
+    if (!ok && (tid & 63) == 0) atomicOr(&st->flag, 1u);
+    mark(1);
+    // the part's columns of L and of y for the backward sweep (another launch); its share of the top's sums
+    for (uint32_t i = tid; i < ne; i += TEAM_THREADS) V.l[eb + i] = s_l[i];
+    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) V.delta[cb + c] = s_b[c];
+    double* const cf = C.f + blockIdx.y * C.stride;
+    double* const cbv = C.b + blockIdx.y * C.stride;
+    for (uint32_t r = X.frun_ptr[part] + tid; r < X.frun_ptr[part + 1]; r += TEAM_THREADS) {
+        const uint32_t slot = X.frun[3 * r], lo = X.frun[3 * r + 1], hi = X.frun[3 * r + 2];
+        double s = 0.0;
+        for (uint32_t t = lo; t < hi; ++t) s += s_l[B.chol.lpairs[2 * t] - eb] * s_l[B.chol.lpairs[2 * t + 1] - eb];
+        cf[slot] = s;
+    }
+    for (uint32_t r = X.brun_ptr[part] + tid; r < X.brun_ptr[part + 1]; r += TEAM_THREADS) {
+        const uint32_t slot = X.brun[3 * r], lo = X.brun[3 * r + 1], hi = X.brun[3 * r + 2];
+        double s = 0.0;
+        for (uint32_t t = lo; t < hi; ++t) s += s_l[B.lrows.ridx[t] - eb] * s_b[B.lrows.rcol[t] - cb];
+        cbv[slot] = s;
+    }
+    mark(2);
+    if (stamp) prof[7] += 1;
+}
+
+__global__ __launch_bounds__(TEAM_THREADS) void sptl_top_kernel(SpBlock B, SpPartsX X, SpVals V, SpContrib C, SpLm* __restrict__ lm) {
+    extern __shared__ double s_dyn[];
+    __shared__ double s_acc[TEAM_NWAVES * 64];
+    __shared__ uint32_t s_bad;
+    SpLm* st = lm + blockIdx.y;
+    if (st->done || st->flag) return;  // (flag: a part met a bad pivot)
+    V.shift(blockIdx.y);
+    const uint32_t top = X.nparts, tid = threadIdx.x;
+    const uint32_t eb = X.seg_ent[top], ne = X.seg_ent[top + 1] - eb, cb = X.seg_col[top], nc = X.seg_col[top + 1] - cb;
+    double* const s_l = s_dyn;
+    double* const s_b = s_dyn + ((ne + 1u) & ~1u);
+    uint32_t* const s_blob = reinterpret_cast<uint32_t*>(s_b + ((nc + 1u) & ~1u));
+    team_load_blob(X.blobs + X.blob_off[top], s_blob, X.blob_off[top + 1] - X.blob_off[top]);
+    const double* const cf = C.f + blockIdx.y * C.stride;
+    const double* const cbv = C.b + blockIdx.y * C.stride;
+    team_form_segment(B, st->cur ? V.j1 : V.j0, st->cur ? V.r1 : V.r0, V.a, V.rhs, s_l, s_b, eb, eb + ne, cb, cb + nc, st->need_form != 0);
+    __syncthreads();
+    for (uint32_t i = tid; i < ne; i += TEAM_THREADS) {  // ... minus what the parts summed for it
+        double s = s_l[i];
+        for (uint32_t q = X.fslot_ptr[i]; q < X.fslot_ptr[i + 1]; ++q) s -= cf[q];
+        s_l[i] = s;
+    }
+    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
+        double s = s_b[c];
+        for (uint32_t q = X.bslot_ptr[c]; q < X.bslot_ptr[c + 1]; ++q) s -= cbv[q];
+        s_b[c] = s;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    SpChol chol;
+    SpRowsOfL lrows;
+    SpTeamSched sched;
+    team_blob_views(s_blob, chol, lrows, sched);
+    const bool ok = team_factor_forward<true, true, true>(chol, lrows, sched, 0, st->lambda, s_l, s_b, s_acc);
+    if (!ok && (tid & 63) == 0) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) st->flag = 1;
+        return;
+    }
+    team_backward<true, false, true>(chol, sched, 0, s_l, s_b);
+    const double* xc = st->cur ? V.xs1 : V.xs0;
+    double* xt = st->cur ? V.xs0 : V.xs1;
+    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {  // the step of the top's columns, and their trial point
+        const double dx = s_b[c];
+        V.delta[cb + c] = dx;
+        const uint32_t v = B.fvar[B.perm[cb + c]];
+        xt[v] = xc[v] + dx;
+    }
+}
+
+__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_down_kernel(SpBlock B, SpPartsX X, SpVals V, const SpLm* __restrict__ lm) {
+    extern __shared__ double s_dyn[];
+    const SpLm* st = lm + blockIdx.y;
+    if (st->done || st->flag) return;
+    V.shift(blockIdx.y);
+    const uint32_t part = blockIdx.x, tid = threadIdx.x;
+    const uint32_t eb = X.seg_ent[part], ne = X.seg_ent[part + 1] - eb, cb = X.seg_col[part], nc = X.seg_col[part + 1] - cb;
+    double* const s_l = s_dyn;
+    double* const s_b = s_dyn + ((ne + 1u) & ~1u);
+    uint32_t* const s_blob = reinterpret_cast<uint32_t*>(s_b + ((nc + 1u) & ~1u));
+    team_load_blob(X.blobs + X.blob_off[part], s_blob, X.blob_off[part + 1] - X.blob_off[part]);
+    for (uint32_t i = tid; i < ne; i += TEAM_THREADS) s_l[i] = V.l[eb + i];
+    // y_j minus what the top's columns of x take from it: the entries of column j whose rows are in the top come last
+    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
+        const uint32_t j = cb + c;
+        double s = V.delta[j];
+        for (uint32_t k = X.cmid[j]; k < B.chol.lcolptr[j + 1]; ++k) s -= V.l[k] * V.delta[B.chol.lrow[k]];
+        s_b[c] = s;
+    }
+    __syncthreads();
+    SpChol chol;
+    SpRowsOfL lrows;
+    SpTeamSched sched;
+    team_blob_views(s_blob, chol, lrows, sched);
+    team_backward<true, true, true>(chol, sched, 0, s_l, s_b);
+    const double* xc = st->cur ? V.xs1 : V.xs0;
+    double* xt = st->cur ? V.xs0 : V.xs1;
+    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
+        const double dx = s_b[c];
+        V.delta[cb + c] = dx;
+        const uint32_t v = B.fvar[B.perm[cb + c]];
+        xt[v] = xc[v] + dx;
+    }
 }
 
 // refined step, between the two solves: t = -r - J delta (rows), then e = Jt t - lambda delta (columns)
