@@ -69,18 +69,19 @@ __global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict_
     rows.param += blockIdx.y * stride;
     scal += blockIdx.y * stride;
     constexpr uint32_t CH = 4096;
-    __shared__ double sq[CH];
+    __shared__ double sq[CH + 64];
     __shared__ uint32_t cnt_s[256];
     double sum = 0.0;
     uint32_t ndist = 0;
     const uint32_t total = do_scale ? nvt + rows.net : 0u;
     for (uint32_t base = 0; base < total; base += CH) {
-        const uint32_t n = min(CH, total - base);
+        const uint32_t n = min(CH, total - base), n_pad = (n + 31u) & ~31u;
         uint32_t mine = 0;
-        for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        for (uint32_t i = threadIdx.x; i < n_pad; i += 256u) {  // (+0.0 past the end and for rows without a distance: exact)
             const uint32_t g = base + i;
             double v = 0.0;
-            if (g < nvt) {
+            if (i >= n) {
+            } else if (g < nvt) {
                 v = vars0[g];
             } else {
                 const int tag = rows.tag[g - nvt] & 0x7F;
@@ -94,12 +95,23 @@ __global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict_
         cnt_s[threadIdx.x] = mine;
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (uint32_t i = 0; i < n; i += 16u) {
-                double t[16];
+            // one chain of dependent adds (the order IS the result): 32 values per step, no test inside, and the next 32
+            // are already on their way from LDS while these are added (the last step loads 32 it never adds)
+            const double2* sq2 = reinterpret_cast<const double2*>(sq);
+            double2 t[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = (i + u < n) ? sq[i + u] : 0.0;
+            for (int u = 0; u < 16; ++u) t[u] = sq2[u];
+            for (uint32_t i = 0; i < n_pad; i += 32u) {
+                double2 nx[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) sum += t[u];
+                for (int u = 0; u < 16; ++u) nx[u] = sq2[(i + 32u) / 2u + u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    sum += t[u].x;
+                    sum += t[u].y;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = nx[u];
             }
             for (uint32_t i = 0; i < 256u; ++i) ndist += cnt_s[i];
         }
@@ -494,6 +506,8 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
                 X.blobs = sp.up(Q.parts_blobs.words);
                 X.blob_off = sp.up(Q.parts_blobs.seg_off);
                 X.cmid = sp.up(E.cmid);
+                X.erow_ptr = sp.up(E.erow_ptr);
+                X.erows = sp.up(E.erows);
                 blk->n_fslots = E.fslot_ptr.back();
                 blk->n_bslots = E.bslot_ptr.back();
                 // values (entries of L, the vector) + the segment's blob; 0: no LDS build (a segment beyond 16-bit local indices)
@@ -548,9 +562,10 @@ hipError_t launch_team(bool pose, bool ldsv, bool blob_in_lds, uint32_t n, size_
 hipError_t raise_lds_limits() {
     static bool raised = false;
     if (raised) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_parts_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sptl_parts_down_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
+    hipError_t e = hipSuccess;
+    for (const void* f : {reinterpret_cast<const void*>(&sptl_parts_up_kernel<false>), reinterpret_cast<const void*>(&sptl_parts_up_kernel<true>),
+                          reinterpret_cast<const void*>(&sptl_parts_down_kernel<false>), reinterpret_cast<const void*>(&sptl_parts_down_kernel<true>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
     raised = e == hipSuccess;
     return e;
 }
@@ -736,11 +751,15 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         for (uint32_t t = 0; t < chunk; ++t) {
                             if (!lds_build) hipLaunchKernelGGL(spt_form_kernel, grid_for2(std::max(B.nnz_a, B.nv), n), dim3(256), 0, stream, B, V, d_lm);
                             if (lds_build) {  // (each segment forms its own entries of A and of the right-hand side)
-                                hipLaunchKernelGGL(sptl_parts_up_kernel, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, B, blk.px, V, Cn, d_lm, d_prof);
-                                hipLaunchKernelGGL(sptl_top_kernel, dim3(1, n), dim3(TEAM_THREADS), blk.lds_top_bytes, stream, B, blk.px, V, Cn, d_lm);
-                                hipLaunchKernelGGL(sptl_parts_down_kernel, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, B, blk.px, V, d_lm);
-                                eval(0u);
-                                continue;
+                                const size_t lds_up = std::max(blk.lds_part_bytes, blk.lds_top_bytes);  // (the last part's workgroup goes on with the top)
+                                if (rows.has_pose) {
+                                    hipLaunchKernelGGL(sptl_parts_up_kernel<true>, dim3(np, n), dim3(TEAM_THREADS), lds_up, stream, rows, B, blk.px, V, Cn, d_lm, d_tickets, d_prof);
+                                    hipLaunchKernelGGL(sptl_parts_down_kernel<true>, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, rows, B, blk.px, V, d_lm, d_tickets, o);
+                                } else {
+                                    hipLaunchKernelGGL(sptl_parts_up_kernel<false>, dim3(np, n), dim3(TEAM_THREADS), lds_up, stream, rows, B, blk.px, V, Cn, d_lm, d_tickets, d_prof);
+                                    hipLaunchKernelGGL(sptl_parts_down_kernel<false>, dim3(np, n), dim3(TEAM_THREADS), blk.lds_part_bytes, stream, rows, B, blk.px, V, d_lm, d_tickets, o);
+                                }
+                                continue;  // (two launches per trial: up — the last part goes on with the top —, down + evaluation + decision)
                             }
                             hipLaunchKernelGGL(spt_parts_up_kernel, dim3(np, n), dim3(TEAM_THREADS), 0, stream, B, V, d_lm, 0u);
                             hipLaunchKernelGGL(spt_top_kernel, dim3(1, n), dim3(TEAM_THREADS), 0, stream, B, V, d_lm, 0u, refined ? 0u : 1u);

@@ -382,6 +382,7 @@ struct PartsExtra {
     std::vector<uint32_t> bslot_ptr;                 // [n_top_columns + 1]
     std::vector<uint32_t> rmid;                      // [n_top_columns] first entry of row j of L whose column is in the top
     std::vector<uint32_t> cmid;                      // [nv] first entry of column j whose row is in the top (part columns; = end for top columns)
+    std::vector<uint32_t> erow_ptr, erows;           // [nseg + 1], [m]: the block's rows by segment (a row's columns lie in one part and the top)
     uint32_t max_part_ent = 0, max_part_cols = 0;
     bool empty() const { return seg_col.empty(); }
 };
@@ -742,6 +743,19 @@ inline void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint
             X.frun_ptr.push_back((uint32_t)X.frun.size() / 3);
             X.brun.insert(X.brun.end(), bruns[sgm].begin(), bruns[sgm].end());
             X.brun_ptr.push_back((uint32_t)X.brun.size() / 3);
+        }
+        // the rows by segment: the part of a row's columns (they lie in ONE part and the top — two parts never share a row, or
+        // their columns would meet in A), the top for rows without a part's column
+        {
+            std::vector<uint32_t> rseg(P.m, nparts);
+            for (uint32_t r2 = 0; r2 < P.m; ++r2)
+                for (uint32_t q = P.jrow_ptr[r2]; q < P.jrow_ptr[r2 + 1]; ++q) rseg[r2] = std::min(rseg[r2], col_seg[P.jcol[q]]);
+            X.erow_ptr.assign((size_t)nseg + 1, 0);
+            for (uint32_t r2 = 0; r2 < P.m; ++r2) X.erow_ptr[rseg[r2] + 1]++;
+            for (uint32_t sgm = 0; sgm < nseg; ++sgm) X.erow_ptr[sgm + 1] += X.erow_ptr[sgm];
+            X.erows.resize(P.m);
+            std::vector<uint32_t> fill(X.erow_ptr.begin(), X.erow_ptr.end() - 1);
+            for (uint32_t r2 = 0; r2 < P.m; ++r2) X.erows[fill[rseg[r2]]++] = r2;
         }
         // backward sweep of a part column: its entries whose rows are in the top come last (rows ascend)
         X.cmid.resize(P.nv);

@@ -92,6 +92,18 @@ __device__ __forceinline__ double bcast_first(double s) {
     return __hiloint2double(hi, lo);
 }
 
+// sum over the wavefront's lanes when only the first n hold something (n wave-uniform): one DPP row butterfly for n <= 16
+__device__ __forceinline__ double wave_sum_first(double v, uint32_t n) {
+    if (n <= 16u) {
+        v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_move<0x141>(v);  // row_half_mirror
+        v += dpp_move<0x140>(v);  // row_mirror
+        return bcast(v, 0);
+    }
+    return wave_sum(v);
+}
+
 // ---- a wavefront's walk through a list ---------------------------------------------------------------------------
 // A column is a chain of dependent steps (operands -> products -> pivot -> scaling -> the next column's operands), a
 // few hundred cycles when its operands are in LDS — and 1.3 us when each column first fetches its own index words
@@ -228,12 +240,63 @@ __device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& l
         if (lane == 0) b[d.j - cb] = (b[d.j - cb] - part) * inv;
         vals_sync<LDSV>();  // the next column of this list may read what this one stored
     };
+    // BLOB builds: everything a column touches is in LDS, and a lone wavefront's time is its instruction count (in-order
+    // issue: ~250 instructions per column in the general code were 1.2 us) — so no prefetch rotation, and a short path
+    // for the usual column: at most 64 entries, 64 products, 64 row entries, each one pass.
+    auto lean_column = [&](const ColDesc& d) {
+        const uint32_t k = d.beg + lane, p = d.pbeg + lane, r = d.rbeg + lane;
+        const uint32_t np = d.pend0 - d.pbeg, nr = d.rend - d.rbeg;
+        double part = 0.0;
+        if (r < d.rend) {
+            const uint32_t w = lr.ridx[r];
+            part = l[w & 0xFFFFu] * b[w >> 16];
+        }
+        double inv;
+        if (FACTOR) {
+            double s = 0.0;
+            if (k < d.end) {
+                s = l[k];
+                if (lane == 0) s += lambda;
+            }
+            if (np) {
+                acc[lane] = 0.0;
+                if (p < d.pend0) {
+                    const uint32_t w = c.lpairs[p];
+                    lds_add_f64(&acc[(uint32_t)reinterpret_cast<const uint16_t*>(c.lpair_k)[p] - d.beg], -l[w & 0xFFFFu] * l[w >> 16]);
+                }
+                wave_sync_lds();
+                s += acc[lane];
+            }
+            const double piv = bcast_first(s);
+            ok = ok && (piv > 0.0) && (piv < 1.0e300);
+            inv = rsqrt_refined(piv);
+            if (k < d.end) l[k] = lane == 0 ? piv * inv : s * inv;
+        } else {
+            inv = 1.0 / l[d.beg];
+        }
+        if (nr) part = wave_sum_first(part, nr);
+        if (lane == 0) b[d.j] = (b[d.j] - part) * inv;
+        wave_sync_lds();
+    };
     for (uint32_t tb = t0; tb < t1; tb += 64) {  // (more than 64 columns: 64 descriptions at a time)
         const uint32_t nb = min(64u, t1 - tb);
         ColDesc mine = first;
         if (tb != t0) {
             mine = ColDesc{};
             if ((uint32_t)lane < nb) mine = cd[tb + lane];
+        }
+        if (BLOB) {
+            for (uint32_t i = 0; i < nb; ++i) {
+                const ColDesc d = desc_of_lane(mine, (int)i);
+                if (d.end - d.beg <= 64u && d.rend - d.rbeg <= 64u && (!FACTOR || c.lpair_ptr[d.end] - d.pbeg <= 64u)) {
+                    lean_column(d);
+                } else {
+                    ColPre q{};
+                    fetch(d, q);
+                    column(d, q);
+                }
+            }
+            continue;
         }
         ColDesc d0 = desc_of_lane(mine, 0), d1{}, d2{};
         ColPre q0{}, q1{}, q2{};
@@ -283,6 +346,26 @@ __device__ __forceinline__ void team_walk_down(const SpChol& c, const ColDesc* c
         if (te != t1) {
             mine = ColDesc{};
             if ((uint32_t)lane < nb) mine = cd[tb + lane];
+        }
+        if (BLOB) {  // (LDS everywhere: no prefetch rotation, a short path for columns of at most 64 entries)
+            for (uint32_t i = nb; i-- > 0;) {
+                const ColDesc d = desc_of_lane(mine, (int)i);
+                const uint32_t kend = USE_MID ? d.pad : d.end;
+                if (kend - d.beg <= 65u) {
+                    const uint32_t k = d.beg + 1 + lane, n = kend - d.beg - 1u;
+                    double part = 0.0;
+                    if (k < kend) part = l[k] * b[(uint32_t)reinterpret_cast<const uint16_t*>(c.lrow)[k]];
+                    if (n) part = wave_sum_first(part, n);
+                    if (lane == 0) b[d.j] = (b[d.j] - part) / l[d.beg];
+                    wave_sync_lds();
+                } else {
+                    uint32_t row = 0;
+                    fetch(d, row);
+                    column(d, row);
+                }
+            }
+            te = tb;
+            continue;
         }
         ColDesc d0 = desc_of_lane(mine, (int)nb - 1), d1{}, d2{};
         uint32_t r0 = 0, r1 = 0, r2 = 0;
@@ -1070,6 +1153,7 @@ struct SpPartsX {
     const uint32_t* blobs;     // the segments' index data for LDS (fx_sparse_plan.h: SegmentBlobs; the top's: its own products)
     const uint32_t* blob_off;  // [nseg + 1]
     const uint32_t* cmid;      // [nv] first entry of a column whose row is in the top
+    const uint32_t *erow_ptr, *erows;  // [nseg + 1], [m]: the block's rows by segment — a row reads variables of ONE part and of the top
     uint32_t nparts;
 };
 struct SpContrib {
@@ -1077,10 +1161,16 @@ struct SpContrib {
     size_t stride;
 };
 
-__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_up_kernel(SpBlock B, SpPartsX X, SpVals V, SpContrib C, SpLm* __restrict__ lm,
-                                                                      unsigned long long* prof) {
+template <bool POSE>
+__device__ __forceinline__ void sptl_top_body(const SpRows& rows, const SpBlock& B, const SpPartsX& X, const SpVals& V, const SpContrib& C, SpLm* st,
+                                              double* s_dyn, double* s_acc, uint32_t* s_badp);
+
+template <bool POSE>
+__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_up_kernel(SpRows rows, SpBlock B, SpPartsX X, SpVals V, SpContrib C, SpLm* __restrict__ lm,
+                                                                      uint32_t* __restrict__ tickets, unsigned long long* prof) {
     extern __shared__ double s_dyn[];
     __shared__ double s_acc[TEAM_NWAVES * 64];
+    __shared__ uint32_t s_last, s_bad;
     SpLm* st = lm + blockIdx.y;
     if (st->done) return;
     const bool stamp = prof && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;  // diagnostics (FIKSI_AMD_TEAM_PROF)
@@ -1128,15 +1218,33 @@ __global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_up_kernel(SpBlock B, 
     }
     mark(2);
     if (stamp) prof[7] += 1;
+    // the workgroup that finishes last goes on with the top (no launch boundary: every part publishes, the last one acquires)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tickets[blockIdx.y] = 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    sptl_top_body<POSE>(rows, B, X, V, C, st, s_dyn, s_acc, &s_bad);
 }
 
-__global__ __launch_bounds__(TEAM_THREADS) void sptl_top_kernel(SpBlock B, SpPartsX X, SpVals V, SpContrib C, SpLm* __restrict__ lm) {
-    extern __shared__ double s_dyn[];
-    __shared__ double s_acc[TEAM_NWAVES * 64];
-    __shared__ uint32_t s_bad;
-    SpLm* st = lm + blockIdx.y;
-    if (st->done || st->flag) return;  // (flag: a part met a bad pivot)
-    V.shift(blockIdx.y);
+// The top of the tree, by the workgroup that finished its part last (V is that System's already): the parts' sums off
+// its entries and its right-hand side, its factorization + forward sweep, its backward sweep, its columns' trial point,
+// the rows that read no part's variables.
+template <bool POSE>
+__device__ __forceinline__ void sptl_top_body(const SpRows& rows, const SpBlock& B, const SpPartsX& X, const SpVals& V, const SpContrib& C, SpLm* st,
+                                              double* s_dyn, double* s_acc, uint32_t* s_badp) {
+    uint32_t& s_bad = *s_badp;
+    if (st->flag) return;  // (a part met a bad pivot)
     const uint32_t top = X.nparts, tid = threadIdx.x;
     const uint32_t eb = X.seg_ent[top], ne = X.seg_ent[top + 1] - eb, cb = X.seg_col[top], nc = X.seg_col[top + 1] - cb;
     double* const s_l = s_dyn;
@@ -1179,41 +1287,84 @@ __global__ __launch_bounds__(TEAM_THREADS) void sptl_top_kernel(SpBlock B, SpPar
         const uint32_t v = B.fvar[B.perm[cb + c]];
         xt[v] = xc[v] + dx;
     }
+    __syncthreads();
+    // K2 / K1 at the trial point for the rows that read no part's variables (the parts evaluate theirs after their sweep)
+    const double* sparam = rows.sparam + (size_t)blockIdx.y * V.stride;
+    for (uint32_t q = X.erow_ptr[top] + tid; q < X.erow_ptr[top + 1]; q += TEAM_THREADS)
+        team_eval_row<POSE>(rows, sparam, B.jac, X.erows[q], xt, st->cur ? V.r0 : V.r1, st->cur ? V.j0 : V.j1);
 }
 
-__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_down_kernel(SpBlock B, SpPartsX X, SpVals V, const SpLm* __restrict__ lm) {
+// The parts' backward sweep, their columns' trial point, the evaluation of their rows there — and, in the block that
+// finishes last, the sums over all rows / all columns (fixed shapes: the same bits whoever it is) and the trial's decision
+// (lm.rs:134-191): what spt_eval_kernel did in a launch of its own.
+template <bool POSE>
+__global__ __launch_bounds__(TEAM_THREADS) void sptl_parts_down_kernel(SpRows rows, SpBlock B, SpPartsX X, SpVals V, SpLm* __restrict__ lm,
+                                                                        uint32_t* __restrict__ tickets, fx_lm_opts o) {
     extern __shared__ double s_dyn[];
-    const SpLm* st = lm + blockIdx.y;
-    if (st->done || st->flag) return;
+    __shared__ double s_red[TEAM_THREADS];
+    __shared__ uint32_t s_last;
+    SpLm* stg = lm + blockIdx.y;
+    if (stg->done) return;
+    const bool bad = stg->flag != 0;  // (a bad pivot: no step; the decision is still taken)
     V.shift(blockIdx.y);
-    const uint32_t part = blockIdx.x, tid = threadIdx.x;
-    const uint32_t eb = X.seg_ent[part], ne = X.seg_ent[part + 1] - eb, cb = X.seg_col[part], nc = X.seg_col[part + 1] - cb;
-    double* const s_l = s_dyn;
-    double* const s_b = s_dyn + ((ne + 1u) & ~1u);
-    uint32_t* const s_blob = reinterpret_cast<uint32_t*>(s_b + ((nc + 1u) & ~1u));
-    team_load_blob(X.blobs + X.blob_off[part], s_blob, X.blob_off[part + 1] - X.blob_off[part]);
-    for (uint32_t i = tid; i < ne; i += TEAM_THREADS) s_l[i] = V.l[eb + i];
-    // y_j minus what the top's columns of x take from it: the entries of column j whose rows are in the top come last
-    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
-        const uint32_t j = cb + c;
-        double s = V.delta[j];
-        for (uint32_t k = X.cmid[j]; k < B.chol.lcolptr[j + 1]; ++k) s -= V.l[k] * V.delta[B.chol.lrow[k]];
-        s_b[c] = s;
+    const uint32_t part = blockIdx.x, tid = threadIdx.x, cur = stg->cur;
+    double* rt = cur ? V.r0 : V.r1;
+    if (!bad) {
+        const uint32_t eb = X.seg_ent[part], ne = X.seg_ent[part + 1] - eb, cb = X.seg_col[part], nc = X.seg_col[part + 1] - cb;
+        double* const s_l = s_dyn;
+        double* const s_b = s_dyn + ((ne + 1u) & ~1u);
+        uint32_t* const s_blob = reinterpret_cast<uint32_t*>(s_b + ((nc + 1u) & ~1u));
+        team_load_blob(X.blobs + X.blob_off[part], s_blob, X.blob_off[part + 1] - X.blob_off[part]);
+        for (uint32_t i = tid; i < ne; i += TEAM_THREADS) s_l[i] = V.l[eb + i];
+        // y_j minus what the top's columns of x take from it: the entries of column j whose rows are in the top come last
+        for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
+            const uint32_t j = cb + c;
+            double s = V.delta[j];
+            for (uint32_t k = X.cmid[j]; k < B.chol.lcolptr[j + 1]; ++k) s -= V.l[k] * V.delta[B.chol.lrow[k]];
+            s_b[c] = s;
+        }
+        __syncthreads();
+        SpChol chol;
+        SpRowsOfL lrows;
+        SpTeamSched sched;
+        team_blob_views(s_blob, chol, lrows, sched);
+        team_backward<true, true, true>(chol, sched, 0, s_l, s_b);
+        const double* xc = cur ? V.xs1 : V.xs0;
+        double* xt = cur ? V.xs0 : V.xs1;
+        for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
+            const double dx = s_b[c];
+            V.delta[cb + c] = dx;
+            const uint32_t v = B.fvar[B.perm[cb + c]];
+            xt[v] = xc[v] + dx;
+        }
+        __syncthreads();
+        const double* sparam = rows.sparam + (size_t)blockIdx.y * V.stride;
+        for (uint32_t q = X.erow_ptr[part] + tid; q < X.erow_ptr[part + 1]; q += TEAM_THREADS)
+            team_eval_row<POSE>(rows, sparam, B.jac, X.erows[q], xt, rt, cur ? V.j0 : V.j1);
+    }
+    // every wavefront's stores have left, then one lane publishes for the workgroup (MI355X_MICROARCH: visibility, valid forms)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(tickets + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tickets[blockIdx.y] = 0;
+        }
     }
     __syncthreads();
-    SpChol chol;
-    SpRowsOfL lrows;
-    SpTeamSched sched;
-    team_blob_views(s_blob, chol, lrows, sched);
-    team_backward<true, true, true>(chol, sched, 0, s_l, s_b);
-    const double* xc = st->cur ? V.xs1 : V.xs0;
-    double* xt = st->cur ? V.xs0 : V.xs1;
-    for (uint32_t c = tid; c < nc; c += TEAM_THREADS) {
-        const double dx = s_b[c];
-        V.delta[cb + c] = dx;
-        const uint32_t v = B.fvar[B.perm[cb + c]];
-        xt[v] = xc[v] + dx;
+    if (!s_last) return;
+    SpLm st = *stg;
+    if (!bad) {
+        st.dn2 = team_sumsq(V.delta, B.nv, s_red);
+        st.sse_t = team_sumsq(rt, B.m, s_red);
     }
+    lm_state_control(st, o);
+    if (tid == 0) *stg = st;
 }
 
 // refined step, between the two solves: t = -r - J delta (rows), then e = Jt t - lambda delta (columns)
