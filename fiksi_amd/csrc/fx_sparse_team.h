@@ -243,26 +243,32 @@ __device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& l
     // BLOB builds: everything a column touches is in LDS, and a lone wavefront's time is its instruction count (in-order
     // issue: ~250 instructions per column in the general code were 1.2 us) — so no prefetch rotation, and a short path
     // for the usual column: at most 64 entries, 64 products, 64 row entries, each one pass.
-    auto lean_column = [&](const ColDesc& d) {
+    auto lean_column = [&](const ColDesc& d, uint32_t pend_all) {
         const uint32_t k = d.beg + lane, p = d.pbeg + lane, r = d.rbeg + lane;
         const uint32_t np = d.pend0 - d.pbeg, nr = d.rend - d.rbeg;
-        double part = 0.0;
-        if (r < d.rend) {
-            const uint32_t w = lr.ridx[r];
-            part = l[w & 0xFFFFu] * b[w >> 16];
-        }
+        const bool has_k = k < d.end, has_p = FACTOR && p < d.pend0, has_r = r < d.rend;
+        // loads without tests (an idle lane reads a word some busy lane reads anyway), so that they leave in two batches
+        // with one wait each instead of seven waits one after the other
+        const uint32_t rw = lr.ridx[has_r ? r : d.rbeg];
+        const uint32_t pw = FACTOR ? c.lpairs[has_p ? p : d.pbeg] : 0u;
+        const uint32_t pk = FACTOR ? (uint32_t)reinterpret_cast<const uint16_t*>(c.lpair_k)[has_p ? p : d.pbeg] : 0u;
+        const double lk = l[has_k ? k : d.beg];
+        const double lri = l[nr ? (rw & 0xFFFFu) : d.beg], brc = b[nr ? (rw >> 16) : d.j];
+        double part = has_r ? lri * brc : 0.0;
         double inv;
         if (FACTOR) {
-            double s = 0.0;
-            if (k < d.end) {
-                s = l[k];
-                if (lane == 0) s += lambda;
-            }
+            double s = has_k ? lk : 0.0;
+            if (lane == 0) s += lambda;
             if (np) {
+                const double lx = l[pw & 0xFFFFu], ly = l[pw >> 16];
                 acc[lane] = 0.0;
-                if (p < d.pend0) {
-                    const uint32_t w = c.lpairs[p];
-                    lds_add_f64(&acc[(uint32_t)reinterpret_cast<const uint16_t*>(c.lpair_k)[p] - d.beg], -l[w & 0xFFFFu] * l[w >> 16]);
+                if (has_p) lds_add_f64(&acc[pk - d.beg], -lx * ly);
+                for (uint32_t p2 = p + 64u; p2 - lane < pend_all; p2 += 64u) {  // (a column of a few hundred products: more passes)
+                    const bool live = p2 < pend_all;
+                    const uint32_t w2 = c.lpairs[live ? p2 : d.pbeg];
+                    const uint32_t k2 = (uint32_t)reinterpret_cast<const uint16_t*>(c.lpair_k)[live ? p2 : d.pbeg];
+                    const double x2 = l[w2 & 0xFFFFu], y2 = l[w2 >> 16];
+                    if (live) lds_add_f64(&acc[k2 - d.beg], -x2 * y2);
                 }
                 wave_sync_lds();
                 s += acc[lane];
@@ -270,9 +276,9 @@ __device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& l
             const double piv = bcast_first(s);
             ok = ok && (piv > 0.0) && (piv < 1.0e300);
             inv = rsqrt_refined(piv);
-            if (k < d.end) l[k] = lane == 0 ? piv * inv : s * inv;
+            if (has_k) l[k] = lane == 0 ? piv * inv : s * inv;
         } else {
-            inv = 1.0 / l[d.beg];
+            inv = 1.0 / bcast_first(lk);
         }
         if (nr) part = wave_sum_first(part, nr);
         if (lane == 0) b[d.j] = (b[d.j] - part) * inv;
@@ -288,8 +294,8 @@ __device__ __forceinline__ bool team_walk_up(const SpChol& c, const SpRowsOfL& l
         if (BLOB) {
             for (uint32_t i = 0; i < nb; ++i) {
                 const ColDesc d = desc_of_lane(mine, (int)i);
-                if (d.end - d.beg <= 64u && d.rend - d.rbeg <= 64u && (!FACTOR || c.lpair_ptr[d.end] - d.pbeg <= 64u)) {
-                    lean_column(d);
+                if (d.end - d.beg <= 64u && d.rend - d.rbeg <= 64u) {
+                    lean_column(d, FACTOR ? c.lpair_ptr[d.end] : 0u);
                 } else {
                     ColPre q{};
                     fetch(d, q);
