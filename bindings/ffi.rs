@@ -132,6 +132,7 @@ extern "C" {
     pub fn fx_cluster_solve_batch(ctx: *mut fx_ctx, batch: *const fx_batch, opts: *const fx_lm_opts, results: *mut fx_result) -> c_int;
     pub fn fx_pose_transform_points(ctx: *mut fx_ctx, poses: *const f64, n_poses: u32, pose_of: *const u32, var_idx: *const u32, n_points: u32, vars: *mut f64, n_vars: u32) -> c_int;
     pub fn fx_unscale_vars(ctx: *mut fx_ctx, scale: f64, scaled: *const f64, mask: *const u8, vars: *mut f64, n: u32) -> c_int;
+    pub fn fx_unscale_vars_strided(ctx: *mut fx_ctx, scales: *const f64, n_systems: u32, nvars: u32, scaled: *const f64, mask: *const u8, vars: *mut f64) -> c_int;
     pub fn fx_single_pass_blocks(batch: *const fx_batch, system: u32, n_blocks: *mut u32, block_comp: *mut u32, row_off: *mut u32, rows: *mut u32, var_off: *mut u32, vars: *mut u32) -> c_int;
     pub fn fx_atan2_cr_batch(n: u64, y: *const f64, x: *const f64, out: *mut f64);
     pub fn fx_qr_symbolic(nrows: i32, ncols: i32, colptr: *const i32, rowidx: *const i32, use_colamd: c_int, col_perm: *mut i32, row_perm: *mut i32, h_ptr: *mut i32, h_rows: *mut i32, h_cap: i32, r_ptr: *mut i32, r_rows: *mut i32, r_cap: i32) -> c_int;

@@ -141,6 +141,7 @@ SIGNATURES = [
     ("fx_cluster_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxLmOpts), _vp]),
     ("fx_pose_transform_points", C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp, C.c_uint32]),
     ("fx_unscale_vars", C.c_int, [_vp, C.c_double, _vp, _vp, _vp, C.c_uint32]),
+    ("fx_unscale_vars_strided", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     ("fx_analyze_batch", C.c_int, [_vp, C.POINTER(FxBatch), _vp]),
     ("fx_eval_residual_dense_jacobian", C.c_int, [_vp, C.POINTER(FxBatch), _vp, _vp, _vp, _vp]),
     ("fx_single_pass_blocks", C.c_int, [C.POINTER(FxBatch), C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +43,18 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// FIKSI_AMD_TRACE=1: where the wall time of a host-buffer call goes (one line per phase on stderr)
+struct PhaseTrace {
+    bool on = std::getenv("FIKSI_AMD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void stamp(const char* what, uint32_t n) {
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fiksi_amd] host call, %u Systems: %-24s %8.3f ms\n", n, what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+};
+
 }  // namespace
 namespace fx {
 // the builder (fx_builder.cpp) reports through the same thread-local text fx_last_error() returns
@@ -54,6 +67,18 @@ namespace {
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) return fail(FX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
+
+// A vector whose resize() leaves new elements unwritten: the analysis fills every entry of its big arrays, and zeroing
+// 40 MB first (100k Systems) costs as much as a third of the analysis.
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <typename U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <typename U, typename... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <typename T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 // Host-side analysis of a batch: everything the device needs besides the raw arrays.
 struct HostPlan {
@@ -68,10 +93,11 @@ struct HostPlan {
     uint32_t n_large = 0;            // Systems with sys_large != 0
     std::vector<uint32_t> wide_list;
     uint32_t w_max_free = 0, w_max_vars = 0, w_max_rows = 0;
-    std::vector<uint16_t> var_info;
-    std::vector<uint16_t> expr_comp;
-    std::vector<uint16_t> expr_idx16;
-    std::vector<uint8_t> expr_tagx;   // tag | 0x80 when a free column repeats inside the row
+    RawVec<uint16_t> var_info;
+    RawVec<uint16_t> expr_comp;
+    RawVec<uint16_t> expr_idx16;
+    RawVec<uint8_t> expr_tagx;   // tag | 0x80 when a free column repeats inside the row
+    std::vector<uint8_t> same_as_prev;  // System s has the raw structure of System s - 1 (its analysis was copied)
 };
 
 // What only the row-parallel kernels need (eval_rows_kernel, identity_residual_kernel): built on first use from
@@ -91,9 +117,9 @@ struct CsrPlan {
 // Runs fn(t, begin, end) over [0, n) cut into contiguous ranges, on up to 16 host threads when the
 // work is worth it (the per-expression analysis is ~0.1 us; a thread costs ~50 us to start).
 template <typename F>
-void parallel_ranges(uint32_t n, uint64_t work_items, F&& fn, uint32_t* n_ranges_out = nullptr) {
+void parallel_ranges(uint32_t n, uint64_t work_items, F&& fn, uint32_t* n_ranges_out = nullptr, uint64_t min_items = 200000) {
     uint32_t nt = std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (work_items < 200000) nt = 1;
+    if (work_items < min_items) nt = 1;
     nt = std::min<uint32_t>(nt, std::max(1u, n));
     if (n_ranges_out) *n_ranges_out = nt;
     if (nt == 1) {
@@ -261,10 +287,11 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     p.n_exprs = ne;
     p.sys_ncomp.assign(n, 0);
     p.sys_large.assign(n, 0);
-    p.var_info.assign(nv, 0);
-    p.expr_comp.assign(ne, 0);
-    p.expr_idx16.assign(4 * (size_t)ne, 0);
-    p.expr_tagx.assign(ne, 0);
+    p.var_info.resize(nv);
+    p.expr_comp.resize(ne);
+    p.expr_idx16.resize(4 * (size_t)ne);
+    p.expr_tagx.resize(ne);
+    p.same_as_prev.assign(n, 0);
 
     struct Partial {
         uint64_t nnz = 0;
@@ -273,9 +300,19 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0, max_pairs_tri = 0;
         int err = FX_OK;
         uint32_t err_system = 0;
+        uint32_t first = 0;      // first System of the range
+        bool chain_same = true;  // every System of the range came out as the one before it (sizes and analysed arrays)
         char msg[192] = {0};
     } part[MAX_RANGES];
     uint32_t nr = 1;
+    const int n_tags = g_allow_pose ? FX_NTAGS_POSE : FX_NTAGS;  // read here: the ranges below may run on other threads
+    // One sketch, many parameter sets (the last System has the first one's sizes and kinds): nearly every System will take
+    // the analysis of the one before it, a few nanoseconds per item — threads then pay from some millions of items on
+    uint64_t min_items = 200000;
+    if (n >= 2 && b->var_off[1] == nv / n && b->expr_off[1] == ne / n && b->var_off[n - 1] == (uint64_t)(n - 1) * b->var_off[1] &&
+        b->expr_off[n - 1] == (uint64_t)(n - 1) * b->expr_off[1] && nv == (uint64_t)n * b->var_off[1] && ne == (uint64_t)n * b->expr_off[1] &&
+        memcmp(b->expr_tag, b->expr_tag + b->expr_off[n - 1], b->expr_off[1] * sizeof(*b->expr_tag)) == 0)
+        min_items = 4000000;
     parallel_ranges(n, (uint64_t)ne + nv, [&](uint32_t t, uint32_t s_lo, uint32_t s_hi) {
         Partial& pt = part[t];
         auto bad = [&](int code, uint32_t s, const char* fmt, unsigned a0 = 0, unsigned a1 = 0, unsigned a2 = 0, unsigned a3 = 0) {
@@ -285,9 +322,42 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         };
         std::vector<int32_t> free_rank;  // per variable of the current system: system-wide free rank
         std::vector<uint32_t> comp_free, comp_rows, comp_pairs, comp_ents, comp_tri;
+        pt.first = s_lo;
+        // One sketch with many parameter sets is the common batch: a System whose raw structure arrays are those of the
+        // System before it takes that System's analysis (two memcmp / memcpy passes instead of the walk below; every
+        // statistic of the range is a maximum — unchanged — or a sum of per-System terms kept here).
+        uint64_t prev_nnz = 0;
+        uint32_t prev_large = 0;
+        auto outputs_equal = [&](uint32_t s, uint32_t q, uint32_t nvt, uint32_t net) {
+            const uint32_t v0 = b->var_off[s], e0 = b->expr_off[s], pv0 = b->var_off[q], pe0 = b->expr_off[q];
+            return memcmp(&p.var_info[v0], &p.var_info[pv0], nvt * sizeof(uint16_t)) == 0 && memcmp(&p.expr_tagx[e0], &p.expr_tagx[pe0], net) == 0 &&
+                   memcmp(&p.expr_comp[e0], &p.expr_comp[pe0], net * sizeof(uint16_t)) == 0 &&
+                   memcmp(&p.expr_idx16[4 * (size_t)e0], &p.expr_idx16[4 * (size_t)pe0], 4 * (size_t)net * sizeof(uint16_t)) == 0;
+        };
         for (uint32_t s = s_lo; s < s_hi && pt.err == FX_OK; ++s) {
             const uint32_t v0 = b->var_off[s], nvt = b->var_off[s + 1] - v0;
             const uint32_t e0 = b->expr_off[s], net = b->expr_off[s + 1] - e0;
+            if (s > s_lo) {
+                const uint32_t pv0 = b->var_off[s - 1], pe0 = b->expr_off[s - 1];
+                if (nvt == v0 - pv0 && net == e0 - pe0 && memcmp(b->var_fixed + v0, b->var_fixed + pv0, nvt) == 0 &&
+                    memcmp(b->expr_tag + e0, b->expr_tag + pe0, net * sizeof(*b->expr_tag)) == 0 &&
+                    memcmp(b->expr_idx + 4 * (size_t)e0, b->expr_idx + 4 * (size_t)pe0, 4 * (size_t)net * sizeof(uint32_t)) == 0 &&
+                    (!b->var_comp || memcmp(b->var_comp + v0, b->var_comp + pv0, nvt * sizeof(*b->var_comp)) == 0) &&
+                    (!b->expr_comp || memcmp(b->expr_comp + e0, b->expr_comp + pe0, net * sizeof(*b->expr_comp)) == 0)) {
+                    memcpy(&p.var_info[v0], &p.var_info[pv0], nvt * sizeof(uint16_t));
+                    memcpy(&p.expr_tagx[e0], &p.expr_tagx[pe0], net);
+                    memcpy(&p.expr_comp[e0], &p.expr_comp[pe0], net * sizeof(uint16_t));
+                    memcpy(&p.expr_idx16[4 * (size_t)e0], &p.expr_idx16[4 * (size_t)pe0], 4 * (size_t)net * sizeof(uint16_t));
+                    p.sys_ncomp[s] = p.sys_ncomp[s - 1];
+                    p.sys_large[s] = p.sys_large[s - 1];
+                    p.same_as_prev[s] = 1;
+                    pt.nnz += prev_nnz;
+                    pt.n_large += prev_large;
+                    continue;
+                }
+            }
+            const uint64_t nnz_before = pt.nnz;
+            const uint32_t large_before = pt.n_large;
             if (nvt > FX_MAX_LARGE_SYSTEM_VARS) {
                 bad(FX_ERR_TOO_LARGE, s, "system %u has %u variables (limit %u)", s, nvt, FX_MAX_LARGE_SYSTEM_VARS);
                 break;
@@ -347,7 +417,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             for (uint32_t i = 0; i < net; ++i) {
                 const uint32_t e = e0 + i;
                 const int tag = b->expr_tag[e];
-                if (tag < 0 || tag >= (g_allow_pose ? FX_NTAGS_POSE : FX_NTAGS)) {
+                if (tag < 0 || tag >= n_tags) {
                     bad(FX_ERR_INVALID, s, "expression %u of system %u: bad tag %d", i, s, (unsigned)tag);
                     break;
                 }
@@ -430,8 +500,12 @@ int analyze(const fx_batch* b, HostPlan* plan) {
                     pt.max_rows = std::max(pt.max_rows, comp_rows[c]);
                 }
             }
+            prev_nnz = pt.nnz - nnz_before;
+            prev_large = pt.n_large - large_before;
+            if (s > s_lo && pt.chain_same)
+                pt.chain_same = nvt == v0 - b->var_off[s - 1] && net == e0 - b->expr_off[s - 1] && outputs_equal(s, s - 1, nvt, net);
         }
-    }, &nr);
+    }, &nr, min_items);
     for (uint32_t t = 0; t < nr; ++t)  // ranges are in system order: the first failing System is reported
         if (part[t].err != FX_OK) return fail(part[t].err, "%s", part[t].msg);
     for (uint32_t t = 0; t < nr; ++t) {
@@ -459,8 +533,12 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     if (n >= 2) {
         const uint32_t nv0 = b->var_off[1] - b->var_off[0], ne0 = b->expr_off[1] - b->expr_off[0];
         bool same = (uint64_t)nv0 * n == nv && (uint64_t)ne0 * n == ne;
-        for (uint32_t s = 1; same && s < n; ++s) {
-            same = b->var_off[s] == s * nv0 && b->expr_off[s] == s * ne0 &&
+        // (inside a range the walk above has compared every System with the one before it: the ranges' first Systems
+        // are left; sizes equal all along and the totals above make the offsets regular)
+        for (uint32_t t = 0; same && t < nr; ++t) {
+            const uint32_t s = part[t].first;
+            same = part[t].chain_same && b->var_off[s + 1] - b->var_off[s] == nv0 && b->expr_off[s + 1] - b->expr_off[s] == ne0 &&
+                   b->var_off[s] == s * nv0 && b->expr_off[s] == s * ne0 &&
                    memcmp(&p.var_info[(size_t)s * nv0], &p.var_info[0], nv0 * sizeof(uint16_t)) == 0 &&
                    memcmp(&p.expr_tagx[(size_t)s * ne0], &p.expr_tagx[0], ne0) == 0 &&
                    memcmp(&p.expr_comp[(size_t)s * ne0], &p.expr_comp[0], ne0 * sizeof(uint16_t)) == 0 &&
@@ -482,6 +560,10 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         std::vector<uint64_t> hash(n);
         parallel_ranges(n, (uint64_t)nv + ne, [&](uint32_t, uint32_t lo, uint32_t hi) {
             for (uint32_t s = lo; s < hi; ++s) {
+                if (s > lo && p.same_as_prev[s]) {
+                    hash[s] = hash[s - 1];
+                    continue;
+                }
                 const void* ptr[4];
                 size_t len[4];
                 slices(s, ptr, len);
@@ -507,6 +589,10 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         first.reserve(1024);
         p.sys_class.resize(n);
         for (uint32_t s = 0; s < n; ++s) {
+            if (s && p.same_as_prev[s]) {
+                p.sys_class[s] = p.sys_class[s - 1];
+                continue;
+            }
             auto it = first.find(hash[s]);
             if (it == first.end()) {
                 first.emplace(hash[s], s);
@@ -544,10 +630,11 @@ struct fx_ctx {
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: workers of the sparse path when a batch holds several large Systems
-    // Page-locked staging for small one-shot solves (System::solve on one sketch): first half carries the packed upload,
-    // second half the read-back — both copies are then truly asynchronous and the call waits on the stream once.
+    // Page-locked staging for one-shot solves up to 8 MB of batch (System::solve on one sketch ... some ten thousand small
+    // Systems): first half carries the packed upload, second half the read-back — both copies are then truly
+    // asynchronous, one each, and the call waits on the stream once.
     unsigned char* pinned = nullptr;
-    static constexpr size_t PINNED_HALF = size_t(128) << 10;
+    static constexpr size_t PINNED_HALF = size_t(8) << 20;
     bool pinned_busy = false;  // an upload from the first half may still be in flight
     // Plans of the sparse path for one-shot calls (System::solve on a large sketch, again and again while it is dragged):
     // keyed by the System's structure and the solve mode, a handful kept, least recently used dropped. Values never
@@ -1608,8 +1695,10 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     int rc = bind(ctx);
     if (rc) return rc;
     HostPlan p;
+    PhaseTrace tr;
     rc = analyze(batch, &p);
     if (rc) return rc;
+    tr.stamp("  analysis", batch->n_systems);
     fx_dbatch* db = new (std::nothrow) fx_dbatch();
     if (!db) return fail(FX_ERR_NOMEM, "out of host memory");
     db->resident = true;
@@ -1650,12 +1739,12 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     FX_UP(sys_large, p.sys_large.data(), p.n_systems)
     FX_UP(vars0, (const double*)batch->vars, p.n_vars)
     FX_UP(vars, (const double*)batch->vars, p.n_vars)
+    FX_UP(results, (const fx_result*)nullptr, p.n_systems)  // (next to vars: a one-shot solve reads the two back in one copy)
     FX_UP(var_info, p.var_info.data(), p.n_vars)
     FX_UP(expr_tag, p.expr_tagx.data(), p.n_exprs)
     FX_UP(expr_comp, p.expr_comp.data(), p.n_exprs)
     FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
     FX_UP(expr_param, batch->expr_param, p.n_exprs)
-    FX_UP(results, (const fx_result*)nullptr, p.n_systems)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
     if (!p.sys_class.empty()) FX_UP(sys_class, p.sys_class.data(), p.n_systems)
     FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
@@ -1663,7 +1752,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     size_t packed = 0;
     for (const Req& r : reqs) packed += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
     std::vector<unsigned char> stage;
-    if (packed <= (size_t(256) << 10)) {
+    if (packed <= fx_ctx::PINNED_HALF) {
         hipError_t e1 = hipSuccess;
         unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
         if (!base) {
@@ -1680,7 +1769,6 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
                 ctx->pinned_busy = false;
             }
             st = ctx->pinned;
-            memset(st, 0, packed);
             db->upload_pending = true;
         } else {
             stage.assign(packed, 0);
@@ -1688,9 +1776,15 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
         }
         size_t at = 0;
         for (const Req& r : reqs) {
-            if (r.src && r.bytes) memcpy(st + at, r.src, r.bytes);
+            const size_t room = (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
+            if (r.src && r.bytes) {
+                memcpy(st + at, r.src, r.bytes);
+                memset(st + at + r.bytes, 0, room - r.bytes);
+            } else {
+                memset(st + at, 0, room);
+            }
             *r.dst = base + at;
-            at += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
+            at += room;
         }
         e1 = hipMemcpyAsync(base, st, packed, hipMemcpyHostToDevice, ctx->stream);
         if (e1 != hipSuccess) {
@@ -1729,7 +1823,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     if (p.n_large) {
         const uint32_t nv = p.n_vars, ne = p.n_exprs, n = p.n_systems;
         db->n_large = p.n_large;
-        db->h_sys_large = p.sys_large;
+        db->h_sys_large.assign(p.sys_large.begin(), p.sys_large.end());
         db->h_var_off.assign(batch->var_off, batch->var_off + n + 1);
         db->h_expr_off.assign(batch->expr_off, batch->expr_off + n + 1);
         db->h_vars.assign(batch->vars, batch->vars + nv);
@@ -2038,11 +2132,16 @@ static int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch,
 static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
                       bool system_level, fx_result* results) {
     fx_dbatch* db = nullptr;
+    PhaseTrace tr;
     int rc = fx_batch_upload(ctx, batch, &db);
     if (rc) return rc;
+    tr.stamp("analysis + upload", batch->n_systems);
     db->resident = false;  // solved once and freed: no point in keeping plans
     rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
-    return read_back_and_free(ctx, db, batch, results, rc);
+    tr.stamp("solve (launches)", batch->n_systems);
+    rc = read_back_and_free(ctx, db, batch, results, rc);
+    tr.stamp("wait + read back", batch->n_systems);
+    return rc;
 }
 
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results) {
@@ -2154,14 +2253,19 @@ int fx_cluster_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts*
     if (o.precision == 32) return fail(FX_ERR_UNSUPPORTED, "cluster problems are solved in f64");
     if (o.solver > FX_STEP_QR) return fail(FX_ERR_UNSUPPORTED, "unknown step solver %u", o.solver);
     fx_dbatch* db = nullptr;
+    PhaseTrace tr;
     g_allow_pose = true;
     int rc = fx_batch_upload(ctx, batch, &db);
     g_allow_pose = false;
     if (rc) return rc;
+    tr.stamp("analysis + upload", batch->n_systems);
     db->resident = false;
     db->d.has_pose = 1u;
     rc = fx_lm_solve_device(ctx, db, &o);
-    return read_back_and_free(ctx, db, batch, results, rc);
+    tr.stamp("solve (launches)", batch->n_systems);
+    rc = read_back_and_free(ctx, db, batch, results, rc);
+    tr.stamp("wait + read back", batch->n_systems);
+    return rc;
 }
 
 int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses, const uint32_t* pose_of, const uint32_t* var_idx,
@@ -2213,6 +2317,33 @@ int fx_unscale_vars(fx_ctx* ctx, double scale, const double* scaled, const uint8
         if (r) return r;
         FX_HIP(fx::launch_unscale(scale, d_scaled, d_mask, d_vars, n, ctx->stream));
         FX_HIP(hipMemcpyAsync(vars, d_vars, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        FX_HIP(hipStreamSynchronize(ctx->stream));
+        return FX_OK;
+    };
+    rc = run();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& blk : scratch.allocations) ctx->give_back(blk.p, blk.size);
+    return rc;
+}
+
+int fx_unscale_vars_strided(fx_ctx* ctx, const double* scales, uint32_t n_systems, uint32_t nvars, const double* scaled, const uint8_t* mask,
+                            double* vars) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    const uint64_t n = (uint64_t)n_systems * nvars;
+    if (n == 0) return FX_OK;
+    if (!scales || !scaled || !mask || !vars) return fail(FX_ERR_INVALID, "bad argument");
+    fx_dbatch scratch;
+    double *d_scaled = nullptr, *d_vars = nullptr, *d_scales = nullptr;
+    uint8_t* d_mask = nullptr;
+    auto run = [&]() -> int {
+        int r = dev_alloc_copy<double>(ctx, &scratch, &d_scaled, scaled, n);
+        if (!r) r = dev_alloc_copy<double>(ctx, &scratch, &d_vars, vars, n);
+        if (!r) r = dev_alloc_copy<double>(ctx, &scratch, &d_scales, scales, n_systems);
+        if (!r) r = dev_alloc_copy<uint8_t>(ctx, &scratch, &d_mask, mask, nvars);
+        if (r) return r;
+        FX_HIP(fx::launch_unscale_strided(d_scales, n_systems, nvars, d_scaled, d_mask, d_vars, ctx->stream));
+        FX_HIP(hipMemcpyAsync(vars, d_vars, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipStreamSynchronize(ctx->stream));
         return FX_OK;
     };

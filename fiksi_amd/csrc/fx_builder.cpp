@@ -1,14 +1,18 @@
 // Host-side System builder behind include/fiksi_amd_builder.h. Bookkeeping only: it records
 // elements, constraints, fixed variables and the incremental connected components exactly as the
 // reference builder does, and flattens Systems into fx_batch. No numerics live here.
+#include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <set>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/fiksi_amd_builder.h"
@@ -64,6 +68,7 @@ struct fxs_system {
     // graph.rs:135-147
     std::vector<int32_t> element_component;  // 1-based index into `components`, 0 = None
     std::vector<Component> components;
+    uint32_t listed = 0;  // scratch of fxs_systems_solve: the group of the current call this System already belongs to, + 1
 };
 
 struct fxs_flat {
@@ -503,33 +508,80 @@ int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) 
 
 namespace {
 
-// assemble::solve, Decomposer::RecursiveAssembly (assemble/mod.rs:212-277). Host: the plan and the
-// make-up of each cluster problem. Device: scale + perturbation (fx_system_prepare_batch), every
-// cluster solve (fx_cluster_solve_batch), the rigid moves (fx_pose_transform_points), the final
-// un-scaling (fx_unscale_vars) and the closing residual check.
-int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result) {
+// assemble::solve, Decomposer::RecursiveAssembly (assemble/mod.rs:212-277) for Systems that share one STRUCTURE (elements,
+// constraints, components — values and parameters differ: one sketch, many parameter sets). Host: the plan — made once,
+// it reads structure only — and the make-up of each cluster problem. Device: scale + perturbation of every System
+// (fx_system_prepare_batch), step k of EVERY System in one cluster solve (fx_cluster_solve_batch on a batch of n cluster
+// problems), the rigid moves (one fx_pose_transform_points), the un-scaling (fx_unscale_vars_strided) and the closing
+// residual check. Round 2 did this one System at a time: three device round trips per step and System.
+bool same_structure(const fxs_system* x, const fxs_system* y) {
+    if (x->elements.size() != y->elements.size() || x->constraints.size() != y->constraints.size() ||
+        x->expressions.size() != y->expressions.size() || x->variables.size() != y->variables.size() ||
+        x->element_component != y->element_component || x->components.size() != y->components.size() ||
+        x->fixed_variables != y->fixed_variables)
+        return false;
+    for (size_t i = 0; i < x->elements.size(); ++i)
+        if (x->elements[i].tag != y->elements[i].tag || x->elements[i].a != y->elements[i].a || x->elements[i].b != y->elements[i].b) return false;
+    for (size_t i = 0; i < x->constraints.size(); ++i) {
+        const Constraint &c1 = x->constraints[i], &c2 = y->constraints[i];
+        if (c1.tag != c2.tag || c1.expressions_idx != c2.expressions_idx || c1.n_incident != c2.n_incident ||
+            std::memcmp(c1.incident, c2.incident, sizeof(uint32_t) * c1.n_incident) != 0)
+            return false;
+    }
+    for (size_t i = 0; i < x->expressions.size(); ++i)
+        if (x->expressions[i].tag != y->expressions[i].tag || std::memcmp(x->expressions[i].idx, y->expressions[i].idx, sizeof(x->expressions[i].idx)) != 0)
+            return false;
+    for (size_t i = 0; i < x->components.size(); ++i)
+        if (x->components[i].elements != y->components[i].elements || x->components[i].constraints != y->components[i].constraints) return false;
+    return true;
+}
+
+uint64_t structure_hash(const fxs_system* x) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+    mix(x->elements.size()); mix(x->constraints.size()); mix(x->expressions.size()); mix(x->variables.size());
+    for (const Element& e : x->elements) mix(((uint64_t)e.tag << 48) ^ ((uint64_t)e.a << 24) ^ e.b);
+    for (const Expr& e : x->expressions) mix(((uint64_t)e.tag << 56) ^ ((uint64_t)e.idx[0] << 42) ^ ((uint64_t)e.idx[1] << 28) ^ ((uint64_t)e.idx[2] << 14) ^ e.idx[3]);
+    return h;
+}
+
+int solve_recursive_assembly(fxs_system* const* systems, uint32_t n_sys, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* results) {
     fx_solving_opts o;
     if (opts) o = *opts; else fx_solving_opts_default(&o);
     // the arm always runs Levenberg-Marquardt (assemble/mod.rs:224-227 ignores opts.optimizer)
-    fx_result total{};
-    total.exit = FX_EXIT_SSE;
+    fxs_system* s = systems[0];  // the structure
+    std::vector<fx_result> total(n_sys);
+    for (fx_result& t : total) {
+        t = fx_result{};
+        t.exit = FX_EXIT_SSE;
+    }
     if (s->variables.empty()) {
-        if (result) *result = total;
+        if (results) std::copy(total.begin(), total.end(), results);
         return FX_OK;
     }
-    const fxs_system* one[1] = {s};
+    // FIKSI_AMD_TRACE=1: where the wall time of the arm goes, one line per phase on stderr
+    const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[fiksi_amd] recursive assembly, %u Systems: %-28s %8.3f ms\n", n_sys, what,
+                     std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     fxs_flat* f = nullptr;
-    int rc = fxs_flatten(one, 1, &f);
+    int rc = fxs_flatten(systems, n_sys, &f);
     if (rc) return rc;
     struct Guard { fxs_flat* f; ~Guard() { fxs_flat_free(f); } } guard{f};
+    stamp("flatten");
 
     const uint32_t nvars = (uint32_t)s->variables.size(), nexprs = (uint32_t)s->expressions.size();
-    std::vector<double> vt(nvars), params(nexprs + 1);
-    double scale = 1.;
-    rc = fx_system_prepare_batch(ctx, &f->batch, o.perturb, vt.data(), params.data(), &scale);
+    std::vector<double> vt((size_t)n_sys * nvars), params((size_t)n_sys * nexprs + 1), scales(n_sys, 1.);
+    rc = fx_system_prepare_batch(ctx, &f->batch, o.perturb, vt.data(), params.data(), scales.data());
     if (rc) return rc;
-    total.scale = scale;
+    for (uint32_t k = 0; k < n_sys; ++k) total[k].scale = scales[k];
     std::vector<uint8_t> touched(nvars, 0);
+    stamp("prepare (device)");
 
     const fx::ra::Graph graph = plan_graph(s);
     auto is_point = [&](uint32_t e) { return s->elements[e].tag == FXS_POINT; };
@@ -537,6 +589,7 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
     std::vector<const Component*> live;
     live_components(s, live);
     std::vector<int32_t> local(nvars, -1);
+    std::vector<fx_result> step_results(n_sys);
     for (const Component* comp : live) {
         std::vector<uint32_t> els(comp->elements.begin(), comp->elements.end());
         std::vector<uint32_t> cons(comp->constraints.begin(), comp->constraints.end());
@@ -550,37 +603,37 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
             if (cp.panicked)
                 return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: a step's expression names a variable hidden inside a contracted cluster (assemble/mod.rs:505-509); System untouched");
 
-            // unknowns: the poses, then the members' variables (assemble/mod.rs:431-474); constants: the points as
-            // solved so far, one pair per pose row pair
-            std::vector<double> x(3 * cp.clusters.size(), 0.);
-            std::vector<uint32_t> global_of;  // unknown -> System variable (poses: none)
+            // ---- the cluster problem's structure (one for all Systems). Unknowns: the poses, then the members' variables
+            // (assemble/mod.rs:431-474); constants: the points as solved so far, one pair per pose row pair. `src[i]`: the
+            // System variable the start value of entry i comes from (-1: a pose, starts at 0).
+            std::vector<int32_t> src(3 * cp.clusters.size(), -1);
             std::fill(local.begin(), local.end(), -1);
             for (uint32_t e : cp.members) {
                 const Element& el = s->elements[e];
-                const int n = el.tag == FXS_LENGTH ? 1 : el.tag == FXS_POINT ? 2 : 0;
-                for (int q = 0; q < n; ++q) {
-                    local[el.a + q] = (int32_t)x.size();
-                    x.push_back(vt[el.a + q]);
+                const int nn = el.tag == FXS_LENGTH ? 1 : el.tag == FXS_POINT ? 2 : 0;
+                for (int q = 0; q < nn; ++q) {
+                    local[el.a + q] = (int32_t)src.size();
+                    src.push_back((int32_t)(el.a + q));
                 }
             }
-            const uint32_t n_unknown = (uint32_t)x.size();
+            const uint32_t n_unknown = (uint32_t)src.size();
             std::vector<uint8_t> tags;
             std::vector<uint32_t> idx;
-            std::vector<double> prm;
+            std::vector<int32_t> prm_src;  // expression the parameter comes from (-1: none, 0)
             for (size_t ci = 0; ci < cp.clusters.size(); ++ci) {  // pose rows come first (:547-588)
                 for (uint32_t point : cp.clusters[ci].second) {
                     const uint32_t g = s->elements[point].a;
                     if (local[g] < 0) return bfail(FX_ERR_UNSUPPORTED, "RecursiveAssembly: a cluster row names a variable outside its cluster problem; System untouched");
-                    const uint32_t was = (uint32_t)x.size();
-                    x.push_back(vt[g]);
-                    x.push_back(vt[g + 1]);
+                    const uint32_t was = (uint32_t)src.size();
+                    src.push_back((int32_t)g);
+                    src.push_back((int32_t)g + 1);
                     for (int q = 0; q < 2; ++q) {
                         tags.push_back((uint8_t)(FX_POSE_COINCIDENCE_X + q));
                         idx.push_back((uint32_t)(3 * ci));
                         idx.push_back(was);
                         idx.push_back((uint32_t)local[g] + (uint32_t)q);
                         idx.push_back(0);
-                        prm.push_back(0.);
+                        prm_src.push_back(-1);
                     }
                 }
             }
@@ -597,38 +650,61 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
                         }
                         idx.push_back(m);
                     }
-                    prm.push_back(params[con.expressions_idx + q]);
+                    prm_src.push_back((int32_t)(con.expressions_idx + q));
                 }
             }
-            std::vector<uint8_t> fixed(x.size(), 0);
-            for (size_t i = n_unknown; i < x.size(); ++i) fixed[i] = 1;
-            const uint32_t var_off[2] = {0, (uint32_t)x.size()}, expr_off[2] = {0, (uint32_t)tags.size()};
+            // (a System's entries start at a multiple of three, so that its poses are whole entries of the pose table the
+            // rigid moves index: up to two idle fixed entries at the end)
+            while (src.size() % 3) src.push_back(-2);
+            const uint32_t xs = (uint32_t)src.size(), nrows = (uint32_t)tags.size();
+
+            // ---- the batch: n_sys cluster problems of this structure, each System's values
+            std::vector<double> x((size_t)n_sys * xs), prm((size_t)n_sys * nrows);
+            std::vector<uint8_t> fixed((size_t)n_sys * xs), tags_all((size_t)n_sys * nrows);
+            std::vector<uint32_t> idx_all(4 * (size_t)n_sys * nrows), var_off(n_sys + 1), expr_off(n_sys + 1);
+            for (uint32_t k = 0; k < n_sys; ++k) {
+                var_off[k] = k * xs;
+                expr_off[k] = k * nrows;
+                const double* v = vt.data() + (size_t)k * nvars;
+                for (uint32_t i = 0; i < xs; ++i) {
+                    x[(size_t)k * xs + i] = src[i] >= 0 ? v[src[i]] : 0.;
+                    fixed[(size_t)k * xs + i] = i >= n_unknown ? 1 : 0;
+                }
+                for (uint32_t r = 0; r < nrows; ++r) prm[(size_t)k * nrows + r] = prm_src[r] >= 0 ? params[(size_t)k * nexprs + (uint32_t)prm_src[r]] : 0.;
+                std::copy(tags.begin(), tags.end(), tags_all.begin() + (size_t)k * nrows);
+                std::copy(idx.begin(), idx.end(), idx_all.begin() + 4 * (size_t)k * nrows);
+            }
+            var_off[n_sys] = n_sys * xs;
+            expr_off[n_sys] = n_sys * nrows;
             fx_batch b{};
-            b.n_systems = 1;
-            b.var_off = var_off;
-            b.expr_off = expr_off;
+            b.n_systems = n_sys;
+            b.var_off = var_off.data();
+            b.expr_off = expr_off.data();
             b.vars = x.data();
             b.var_fixed = fixed.data();
-            b.expr_tag = tags.data();
-            b.expr_idx = idx.data();
+            b.expr_tag = tags_all.data();
+            b.expr_idx = idx_all.data();
             b.expr_param = prm.data();
-            fx_result r{};
-            rc = fx_cluster_solve_batch(ctx, &b, &o.lm, &r);
+            stamp("step: host make-up");
+            rc = fx_cluster_solve_batch(ctx, &b, &o.lm, step_results.data());
             if (rc) return rc;
-            total.accepted += r.accepted;
-            total.trials += r.trials;
-            total.exit = r.exit;
-            total.ncomp += 1;
-            total.sse0 += r.sse0;
-            total.sse += r.sse;
-
-            for (uint32_t g = 0; g < nvars; ++g) {  // :228-236
-                if (local[g] >= 0) {
-                    vt[g] = x[(size_t)local[g]];
-                    touched[g] = 1;
-                }
+            stamp("step: cluster solve (device)");
+            for (uint32_t k = 0; k < n_sys; ++k) {
+                const fx_result& r = step_results[k];
+                total[k].accepted += r.accepted;
+                total[k].trials += r.trials;
+                total[k].exit = r.exit;
+                total[k].ncomp += 1;
+                total[k].sse0 += r.sse0;
+                total[k].sse += r.sse;
+                double* v = vt.data() + (size_t)k * nvars;
+                for (uint32_t g = 0; g < nvars; ++g)  // :228-236
+                    if (local[g] >= 0) v[g] = x[(size_t)k * xs + (size_t)local[g]];
             }
-            // :238-275 what a moved cluster carries along
+            for (uint32_t g = 0; g < nvars; ++g)
+                if (local[g] >= 0) touched[g] = 1;
+            // :238-275 what a moved cluster carries along — every System's points in one call: pose ci of System k is entry
+            // k * xs / 3 + ci of the pose table (= x itself), its variables start at k * nvars
             std::vector<uint32_t> pose_of, point_var;
             for (size_t ci = 0; ci < cp.clusters.size(); ++ci) {
                 const std::vector<uint32_t>* carried = fx::ra::lookup(step.owned_elements, cp.clusters[ci].first);
@@ -640,25 +716,42 @@ int solve_recursive_assembly(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* 
                     touched[s->elements[e].a] = touched[s->elements[e].a + 1] = 1;
                 }
             }
-            rc = fx_pose_transform_points(ctx, x.data(), (uint32_t)cp.clusters.size(), pose_of.data(), point_var.data(),
-                                          (uint32_t)pose_of.size(), vt.data(), nvars);
-            if (rc) return rc;
+            if (!pose_of.empty()) {
+                const size_t np = pose_of.size();
+                std::vector<uint32_t> pose_all(np * n_sys), var_all(np * n_sys);
+                for (uint32_t k = 0; k < n_sys; ++k)
+                    for (size_t i = 0; i < np; ++i) {
+                        pose_all[(size_t)k * np + i] = k * (xs / 3u) + pose_of[i];
+                        var_all[(size_t)k * np + i] = k * nvars + point_var[i];
+                    }
+                rc = fx_pose_transform_points(ctx, x.data(), n_sys * (xs / 3u), pose_all.data(), var_all.data(), (uint32_t)(np * n_sys), vt.data(),
+                                              n_sys * nvars);
+                if (rc) return rc;
+            }
+            stamp("step: carry results, moves");
         }
     }
 
-    rc = fx_unscale_vars(ctx, scale, vt.data(), touched.data(), s->variables.data(), nvars);
+    std::vector<double> solved((size_t)n_sys * nvars);
+    for (uint32_t k = 0; k < n_sys; ++k) std::copy(systems[k]->variables.begin(), systems[k]->variables.end(), solved.begin() + (size_t)k * nvars);
+    rc = fx_unscale_vars_strided(ctx, scales.data(), n_sys, nvars, vt.data(), touched.data(), solved.data());
     if (rc) return rc;
+    stamp("unscale (device)");
     // the closing check: sum of squared expression residuals on the solved variables, from the device
     // (no LM step is taken: max_outer = 0)
-    std::memcpy(f->vars.data(), s->variables.data(), nvars * sizeof(double));
+    std::memcpy(f->vars.data(), solved.data(), solved.size() * sizeof(double));
     fx_lm_opts probe;
     fx_lm_opts_default(&probe);
     probe.max_outer = 0;
-    fx_result pr{};
-    rc = fx_lm_solve_batch(ctx, &f->batch, &probe, &pr);
+    std::vector<fx_result> pr(n_sys);
+    rc = fx_lm_solve_batch(ctx, &f->batch, &probe, pr.data());
     if (rc) return rc;
-    total.sse_unscaled = pr.sse_unscaled;
-    if (result) *result = total;
+    for (uint32_t k = 0; k < n_sys; ++k) {
+        std::copy(solved.begin() + (size_t)k * nvars, solved.begin() + (size_t)(k + 1) * nvars, systems[k]->variables.begin());
+        total[k].sse_unscaled = pr[k].sse_unscaled;
+    }
+    stamp("closing check (device)");
+    if (results) std::copy(total.begin(), total.end(), results);
     return FX_OK;
 }
 
@@ -668,12 +761,46 @@ extern "C" {
 
 int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const fx_solving_opts* opts,
                       fx_result* results) {
-    if (opts && opts->decomposer == 2) {  // RecursiveAssembly plans each System from its elements: one after the other
+    if (opts && opts->decomposer == 2) {
+        // RecursiveAssembly plans from a System's elements; Systems of one structure (one sketch, many parameter sets)
+        // share the plan and every device call — groups in order of their first System
         if (n && !systems) return FX_ERR_INVALID;
-        for (uint32_t k = 0; k < n; ++k) {
+        for (uint32_t k = 0; k < n; ++k)
             if (!systems[k]) return FX_ERR_INVALID;
-            int rc = solve_recursive_assembly(systems[k], ctx, opts, results ? results + k : nullptr);
+        // (a hash of the structure finds the candidates, same_structure() decides; a System listed twice is solved once
+        // per listing: the second listing opens a group of its own)
+        struct Group {
+            uint64_t hash;
+            std::vector<fxs_system*> systems;
+            std::vector<uint32_t> members;
+        };
+        std::vector<Group> groups;
+        std::unordered_multimap<uint64_t, size_t> by_hash;
+        for (uint32_t k = 0; k < n; ++k) systems[k]->listed = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint64_t h = structure_hash(systems[k]);
+            size_t at = groups.size();
+            auto range = by_hash.equal_range(h);
+            for (auto it = range.first; it != range.second; ++it) {
+                if (systems[k]->listed != it->second + 1u && same_structure(groups[it->second].systems[0], systems[k])) {
+                    at = it->second;
+                    break;
+                }
+            }
+            if (at == groups.size()) {
+                groups.push_back(Group{h, {}, {}});
+                by_hash.emplace(h, at);
+            }
+            groups[at].systems.push_back(systems[k]);
+            groups[at].members.push_back(k);
+            systems[k]->listed = (uint32_t)at + 1u;
+        }
+        for (Group& g : groups) {
+            std::vector<fx_result> r(g.systems.size());
+            int rc = solve_recursive_assembly(g.systems.data(), (uint32_t)g.systems.size(), ctx, opts, r.data());
             if (rc) return rc;
+            if (results)
+                for (size_t i = 0; i < g.members.size(); ++i) results[g.members[i]] = r[i];
         }
         return FX_OK;
     }

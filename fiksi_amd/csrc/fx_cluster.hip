@@ -102,6 +102,20 @@ __global__ __launch_bounds__(256) void unscale_kernel(double scale, const double
     if (i < n && mask[i]) vars[i] = scale * scaled[i];
 }
 
+// the same for a batch of Systems of one structure (nvars variables each, one mask): System k's scale for its slice
+__global__ __launch_bounds__(256) void unscale_strided_kernel(const double* __restrict__ scales, uint32_t nvars, const double* __restrict__ scaled,
+                                                              const uint8_t* __restrict__ mask, double* __restrict__ vars, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n && mask[i % nvars]) vars[i] = scales[i / nvars] * scaled[i];
+}
+hipError_t launch_unscale_strided(const double* scales, uint32_t n_systems, uint32_t nvars, const double* scaled, const uint8_t* mask, double* vars,
+                                  hipStream_t stream) {
+    const uint64_t n = (uint64_t)n_systems * nvars;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unscale_strided_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, scales, nvars, scaled, mask, vars, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_unscale(double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(unscale_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, scale, scaled, mask, vars, n);

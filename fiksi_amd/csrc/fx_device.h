@@ -158,6 +158,8 @@ hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void
 hipError_t launch_prepare(const DeviceBatch& b, uint32_t mode, double* out_vars, double* out_params, double* out_scale, hipStream_t stream);
 // vars[i] = scale * scaled[i] where mask[i] (assemble/mod.rs:234-235, 259-262)
 hipError_t launch_unscale(double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n, hipStream_t stream);
+hipError_t launch_unscale_strided(const double* scales, uint32_t n_systems, uint32_t nvars, const double* scaled, const uint8_t* mask, double* vars,
+                                  hipStream_t stream);
 // Pose2D::transform_point (expressions.rs:1120-1134) of n points in place: vars[idx[i]], vars[idx[i]+1] by pose[3*pose_of[i]..]
 hipError_t launch_pose_transform(const double* poses, const uint32_t* pose_of, const uint32_t* idx, uint32_t n, double* vars,
                                  hipStream_t stream);

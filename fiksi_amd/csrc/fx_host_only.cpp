@@ -19,6 +19,7 @@ size_t presort_temp_bytes(uint32_t) { return 0; }
 hipError_t launch_presort(const DeviceBatch&, float*, uint32_t*, void*, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_prepare(const DeviceBatch&, uint32_t, double*, double*, double*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_unscale(double, const double*, const uint8_t*, double*, uint32_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_unscale_strided(const double*, uint32_t, uint32_t, const double*, const uint8_t*, double*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_pose_transform(const double*, const uint32_t*, const uint32_t*, uint32_t, double*, hipStream_t) { return hipErrorNoDevice; }
 size_t wide_lds_bytes(const DeviceBatch&) { return 0; }
 size_t solve_lds_bytes(const DeviceBatch&) { return 0; }

@@ -1130,11 +1130,13 @@ __global__ __launch_bounds__(64) void lm_solve_qr_kernel(DeviceBatch b, LmParams
 }
 
 // cluster problems of Decomposer::RecursiveAssembly (fx_recursive.h): the same solve with the two pose rows
-// of fx_expr.h switched on; one build of 64 columns serves every step (a step is a single small problem)
-template <bool QR>
+// of fx_expr.h switched on. Builds of 16, 32 and 64 columns: a step of one System is a single small problem, but the
+// batched arm solves that step for every System of a group at once (10 000 triangles: 10 000 problems of 9 columns,
+// which the 64-column build runs at a quarter of the 16-column build's occupancy); FX_STEP_QR keeps to one build.
+template <bool QR, int N = 64>
 __global__ __launch_bounds__(64) void lm_solve_pose_kernel(DeviceBatch b, LmParams prm, SolveLayout L) {
     extern __shared__ __align__(16) unsigned char smem[];
-    lm_solve_body<64, double, false, false, 0, false, QR, true>(b, prm, L, smem);
+    lm_solve_body<N, double, false, false, 0, false, QR, true>(b, prm, L, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1517,10 +1519,12 @@ static hipError_t launch_solve_pose(const DeviceBatch& b, const LmParams& p, hip
     if (p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 64u) return hipErrorInvalidValue;
     const bool qr = p.lm.solver == FX_STEP_QR;
     if (qr && !b.qr_none.desc) return hipErrorInvalidValue;
-    SolveLayout L = make_layout(64u, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents, qr ? b.qr_none.max_m : 0u,
+    const uint32_t n = qr ? 64u : b.max_free <= 16u ? 16u : b.max_free <= 32u ? 32u : 64u;
+    SolveLayout L = make_layout(n, b.max_vars, b.max_rows, 8u, false, b.max_pairs, b.max_ents, qr ? b.qr_none.max_m : 0u,
                                 qr ? b.qr_none.max_h : 0u);
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
-    void (*fn)(DeviceBatch, LmParams, SolveLayout) = qr ? &lm_solve_pose_kernel<true> : &lm_solve_pose_kernel<false>;
+    void (*fn)(DeviceBatch, LmParams, SolveLayout) = qr ? &lm_solve_pose_kernel<true> : n == 16u ? &lm_solve_pose_kernel<false, 16> :
+                                                     n == 32u ? &lm_solve_pose_kernel<false, 32> : &lm_solve_pose_kernel<false, 64>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);

@@ -356,6 +356,10 @@ int fx_pose_transform_points(fx_ctx* ctx, const double* poses, uint32_t n_poses,
                              uint32_t n_points, double* vars, uint32_t n_vars);
 /* vars[i] = scale * scaled[i] where mask[i] != 0 (assemble/mod.rs:234-235, 259-262); other entries keep their bits. */
 int fx_unscale_vars(fx_ctx* ctx, double scale, const double* scaled, const uint8_t* mask, double* vars, uint32_t n);
+/* The same for n_systems Systems of one structure solved side by side (the batched RecursiveAssembly arm): System k owns
+ * entries [k * nvars, (k + 1) * nvars) of scaled / vars and is un-scaled by scales[k]; mask[nvars] is shared. */
+int fx_unscale_vars_strided(fx_ctx* ctx, const double* scales, uint32_t n_systems, uint32_t nvars, const double* scaled,
+                            const uint8_t* mask, double* vars);
 
 /* == find_strongly_connected_expressions per connected component (analyze/graph/equations.rs:186-221),
  * the structural plan Decomposer::SinglePass solves by: the blocks of System `system` in solve order.

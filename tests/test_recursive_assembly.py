@@ -308,3 +308,40 @@ def test_device_arm_edge_cases(fiksi, ctx, oracle):
     assert e.value.code == -6 and np.array_equal(s.flatten()["vars"], before)
     s.solve(RA, ctx)
     assert s.last_result["ncomp"] > 0
+
+
+@pytest.mark.gpu
+def test_batched_arm_equals_one_system_at_a_time(fiksi, ctx):
+    """Round 3: Systems of one structure share the plan and every device call of the arm (assemble/mod.rs:212-277 once
+    per step for the whole batch). 300 hinged-triangle sketches with their own targets and start points, two structures
+    mixed in one call: every variable and result field the bits of the same System solved alone."""
+    from fiksi_amd.system import solve_systems
+
+    F = fiksi
+    P, D = F.elements.Point.create, F.constraints.PointPointDistance.create
+    RA = F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly)
+    g = Lcg(77)
+
+    def sketch(n_tri, jitter):
+        s = F.System()
+        c = P(s, 0.5 + jitter * g.u(-1, 1), jitter * g.u(-1, 1))
+        for t in range(n_tri):
+            a = P(s, 1.1 + t + jitter * g.u(-1, 1), 0.5 + 0.3 * t)
+            b = P(s, 2.1 + t, 1. + 0.2 * t + jitter * g.u(-1, 1))
+            D(s, c, a, 1. + 0.1 * g.u(0, 1)); D(s, c, b, 1. + 0.1 * g.u(0, 1)); D(s, a, b, 1. + 0.1 * g.u(0, 1))
+        return s
+
+    seeds = [(1 if k % 3 else 2, 0.05) for k in range(300)]  # two structures, interleaved
+    g = Lcg(77)
+    batch = [sketch(*a) for a in seeds]
+    g = Lcg(77)
+    alone = [sketch(*a) for a in seeds]
+    res = solve_systems(batch, RA, ctx=ctx)
+    for k, s in enumerate(alone):
+        s.solve(RA, ctx=ctx)
+        assert np.array_equal(batch[k].flatten()["vars"].view(np.uint64), s.flatten()["vars"].view(np.uint64)), k
+        for f in ("accepted", "trials", "exit", "ncomp"):
+            assert res[f][k] == s.last_result[f], (k, f)
+        for f in ("scale", "sse0", "sse", "sse_unscaled"):
+            assert res[f][k] == s.last_result[f], (k, f)
+    assert np.all(res["sse_unscaled"] < 1e-6) and np.all(res["ncomp"] >= 3)

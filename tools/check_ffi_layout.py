@@ -53,7 +53,54 @@ def layout(structs, name, memo):
     return memo[name]
 
 
+TMAP = {
+    'int': 'c_int', 'uint32_t': 'u32', 'int32_t': 'i32', 'uint64_t': 'u64', 'double': 'f64', 'float': 'f32', 'size_t': 'usize', 'char': 'c_char',
+    'uint8_t': 'u8', 'uint16_t': 'u16', 'void': 'c_void',
+}
+
+
+def rust_type(t):
+    t = re.sub(r'\s+', ' ', t.strip())
+    m = re.match(r'^(const )?(\w+)( const)?\s*((?:\*\s*(?:const\s*)?)*)$', t)
+    if not m:
+        raise SystemExit('cannot parse type: ' + t)
+    const, base, _, stars = m.groups()
+    rust = TMAP.get(base, base)
+    marks = re.findall(r'\*\s*(const)?', stars)
+    for k in range(len(marks)):
+        is_const = (const is not None) if k == 0 else (marks[k - 1] == 'const')
+        rust = ('*const ' if is_const else '*mut ') + rust
+    return rust
+
+
+def regen():
+    """Rewrites the `extern "C"` block of bindings/ffi.rs from the header's prototypes."""
+    hdr = re.sub(r'/\*.*?\*/', '', open(HDR).read(), flags=re.S)
+    protos = re.findall(r'^(int|void|const char\*|uint64_t) (fx_\w+)\(([^;]*?)\);', hdr, flags=re.M | re.S)
+    out = []
+    for ret, name, args in protos:
+        args = ' '.join(args.split())
+        params = []
+        if args != 'void':
+            for a in args.split(','):
+                m = re.match(r'^(.*?)(\w+)(\[\d+\])?$', a.strip())
+                ty, nm, arr = m.groups()
+                ty = ty.strip() + (' *' if arr else '')
+                if nm in ('type', 'ref', 'in', 'loop', 'fn', 'mod', 'use', 'box', 'self'):
+                    nm += '_'
+                params.append(f'{nm}: {rust_type(ty)}')
+        r = {'int': ' -> c_int', 'void': '', 'const char*': ' -> *const c_char', 'uint64_t': ' -> u64'}[ret]
+        out.append(f'    pub fn {name}({", ".join(params)}){r};')
+    src = open(RS).read()
+    a = src.index('extern "C" {\n') + len('extern "C" {\n')
+    b = src.rindex('}')
+    open(RS, 'w').write(src[:a] + '\n'.join(out) + '\n' + src[b:])
+    print(f'bindings/ffi.rs: extern block regenerated ({len(out)} functions)')
+
+
 def main():
+    if '--regen' in sys.argv:
+        regen()
     src = open(RS).read()
     hdr = open(HDR).read()
     structs = parse_structs(src)
