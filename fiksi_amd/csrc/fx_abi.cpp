@@ -635,7 +635,21 @@ struct fx_ctx {
     // asynchronous, one each, and the call waits on the stream once.
     unsigned char* pinned = nullptr;
     static constexpr size_t PINNED_HALF = size_t(8) << 20;
-    bool pinned_busy = false;  // an upload from the first half may still be in flight
+    bool pinned_busy = false;  // an upload from the first half may still be in flight (ev_pinned follows its copy)
+    hipEvent_t ev_pinned = nullptr;
+    hipStream_t pinned_stream = nullptr;
+    // a second stream: fx_system_solve_batch on a big batch of small Systems works in chunks, chunk k + 1 analysed and
+    // uploaded while chunk k is solved (solve_host_chunked)
+    hipStream_t stream2 = nullptr;  // the copies
+    hipStream_t stream3 = nullptr;  // every other chunk's solve (the end of one chunk's solve overlaps the next one's start)
+    hipEvent_t ev_chunk = nullptr;
+    void wait_pinned() {
+        if (pinned_busy) (void)hipEventSynchronize(ev_pinned);
+        pinned_busy = false;
+    }
+    void stream_synced() {  // ctx->stream has just been waited for
+        if (pinned_stream == stream) pinned_busy = false;
+    }
     // Plans of the sparse path for one-shot calls (System::solve on a large sketch, again and again while it is dragged):
     // keyed by the System's structure and the solve mode, a handful kept, least recently used dropped. Values never
     // enter a plan, so a hit only skips the host planning and the upload of its index arrays.
@@ -673,6 +687,7 @@ struct fx_ctx {
     bool ensure_pinned() {
         if (pinned) return true;
         void* p = nullptr;
+        if (!ev_pinned && hipEventCreateWithFlags(&ev_pinned, hipEventDisableTiming) != hipSuccess) return false;
         if (hipHostMalloc(&p, 2 * PINNED_HALF, 0) != hipSuccess) return false;
         pinned = static_cast<unsigned char*>(p);
         return true;
@@ -879,7 +894,7 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
         unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
         FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->pinned_busy = false;
+        ctx->stream_synced();
         auto grab = [&](void* dst, const void* dev, size_t bytes) {
             if (bytes) memcpy(dst, img + (reinterpret_cast<const unsigned char*>(dev) - db->packed_base), bytes);
         };
@@ -1134,7 +1149,7 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
         unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
         FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->pinned_busy = false;
+        ctx->stream_synced();
         auto grab = [&](void* dst, const void* dev, size_t bytes) {
             if (bytes) memcpy(dst, img + (reinterpret_cast<const unsigned char*>(dev) - db->packed_base), bytes);
         };
@@ -1588,6 +1603,10 @@ void fx_ctx_destroy(fx_ctx* ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->ev_chunk) (void)hipEventDestroy(ctx->ev_chunk);
+    if (ctx->ev_pinned) (void)hipEventDestroy(ctx->ev_pinned);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
     ctx->drop_plans();
@@ -1689,24 +1708,23 @@ int fx_jacobian_structure(const fx_batch* batch, uint64_t* nnz, uint32_t* row_pt
     return FX_OK;
 }
 
-int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
-    if (!out) return fail(FX_ERR_INVALID, "out-pointer is NULL");
+// Systems [s0, s1) of an analysed batch onto the device (the whole batch, or one chunk of solve_host_chunked: the limits
+// that size kernels and LDS are the whole batch's either way, so a chunk runs the very kernels the whole batch would).
+static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out) {
     *out = nullptr;
-    int rc = bind(ctx);
-    if (rc) return rc;
-    HostPlan p;
-    PhaseTrace tr;
-    rc = analyze(batch, &p);
-    if (rc) return rc;
-    tr.stamp("  analysis", batch->n_systems);
+    int rc = FX_OK;
+    const bool whole = s0 == 0 && s1 == p.n_systems;
+    const uint32_t n_sys = s1 - s0;
+    const uint32_t v0 = n_sys ? batch->var_off[s0] : 0, e0 = n_sys ? batch->expr_off[s0] : 0;
+    const uint32_t n_vars = n_sys ? batch->var_off[s1] - v0 : 0, n_exprs = n_sys ? batch->expr_off[s1] - e0 : 0;
     fx_dbatch* db = new (std::nothrow) fx_dbatch();
     if (!db) return fail(FX_ERR_NOMEM, "out of host memory");
     db->resident = true;
     fx::DeviceBatch& d = db->d;
-    d.n_systems = p.n_systems;
-    d.n_vars = p.n_vars;
-    d.n_exprs = p.n_exprs;
-    d.nnz = p.nnz;
+    d.n_systems = n_sys;
+    d.n_vars = n_vars;
+    d.n_exprs = n_exprs;
+    d.nnz = p.nnz;  // (of the whole batch: an upper bound for a chunk, which never builds its CSR)
     d.max_free = p.max_free;
     d.max_rows = p.max_rows;
     d.max_vars = p.max_vars;
@@ -1716,94 +1734,144 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     d.max_pairs = p.max_pairs;
     d.max_ents = p.max_ents;
     d.max_pairs_tri = p.max_pairs_tri;
-    d.uniform = p.uniform;
-    d.u_nvars = p.uniform ? batch->var_off[1] : 0;
-    d.u_nexprs = p.uniform ? batch->expr_off[1] : 0;
-    d.u_ncomp = p.uniform ? p.sys_ncomp[0] : 0;
+    d.uniform = p.uniform && n_sys >= 2 ? 1u : 0u;
+    d.u_nvars = d.uniform ? batch->var_off[1] : 0;
+    d.u_nexprs = d.uniform ? batch->expr_off[1] : 0;
+    d.u_ncomp = d.uniform ? p.sys_ncomp[0] : 0;
     d.max_pairs_g = p.max_pairs_large;  // blocks of a large System hold at most its components' products
     d.max_ents_g = p.max_ents_large;
     const uint32_t zero_off[1] = {0};
-    const uint32_t* voff = p.n_systems ? batch->var_off : zero_off;
-    const uint32_t* eoff = p.n_systems ? batch->expr_off : zero_off;
-    // Every array of the batch: (device pointer to set, host source or NULL for zeros, bytes). A small
-    // batch (one System::solve) goes up as ONE block with ONE copy from a packed staging buffer — a
-    // dozen-and-a-half separate hipMemcpy calls cost more than its solve; a big batch keeps one block and
-    // one copy per array (no extra pass over 100 MB on the host).
+    const uint32_t* voff = n_sys ? batch->var_off : zero_off;
+    const uint32_t* eoff = n_sys ? batch->expr_off : zero_off;
+    std::vector<uint32_t> voff_r, eoff_r, class_r;
+    if (!whole) {  // a chunk's offsets start at 0; a structure class is the first System OF THE CHUNK with the structure
+        voff_r.resize((size_t)n_sys + 1);
+        eoff_r.resize((size_t)n_sys + 1);
+        for (uint32_t s = 0; s <= n_sys; ++s) {
+            voff_r[s] = batch->var_off[s0 + s] - v0;
+            eoff_r[s] = batch->expr_off[s0 + s] - e0;
+        }
+        voff = voff_r.data();
+        eoff = eoff_r.data();
+        if (!p.sys_class.empty()) {
+            class_r.resize(n_sys);
+            std::unordered_map<uint32_t, uint32_t> first;
+            for (uint32_t s = 0; s < n_sys; ++s) {
+                if (s && p.sys_class[s0 + s] == p.sys_class[s0 + s - 1]) {
+                    class_r[s] = class_r[s - 1];
+                    continue;
+                }
+                class_r[s] = first.emplace(p.sys_class[s0 + s], s).first->second;
+            }
+        }
+    }
+    const uint32_t* sys_class = p.sys_class.empty() ? nullptr : whole ? p.sys_class.data() : class_r.data();
+    // Every array of the batch: (device pointer to set, host source or NULL for zeros, bytes) — ONE device block.
+    //  - a small batch (one System::solve) goes up with ONE copy from the page-locked staging area: a dozen-and-a-half
+    //    separate hipMemcpy calls cost more than its solve;
+    //  - up to PINNED_HALF the same, but `vars` (the working copy of vars0) and the zeroed `results` at the block's end
+    //    are made on the device (a copy, a memset) instead of crossing the bus;
+    //  - a big batch: one copy per array straight from the caller's memory (no extra pass over 100 MB on the host).
     struct Req { void** dst; const void* src; size_t bytes; };
     std::vector<Req> reqs;
 #define FX_UP(field, host, count) \
     reqs.push_back({reinterpret_cast<void**>(&d.field), static_cast<const void*>(host), (size_t)(count) * sizeof(*d.field)});
-    FX_UP(var_off, voff, (size_t)p.n_systems + 1)
-    FX_UP(expr_off, eoff, (size_t)p.n_systems + 1)
-    FX_UP(sys_ncomp, p.sys_ncomp.data(), p.n_systems)
-    FX_UP(sys_large, p.sys_large.data(), p.n_systems)
-    FX_UP(vars0, (const double*)batch->vars, p.n_vars)
-    FX_UP(vars, (const double*)batch->vars, p.n_vars)
-    FX_UP(results, (const fx_result*)nullptr, p.n_systems)  // (next to vars: a one-shot solve reads the two back in one copy)
-    FX_UP(var_info, p.var_info.data(), p.n_vars)
-    FX_UP(expr_tag, p.expr_tagx.data(), p.n_exprs)
-    FX_UP(expr_comp, p.expr_comp.data(), p.n_exprs)
-    FX_UP(expr_idx, p.expr_idx16.data(), 4 * (size_t)p.n_exprs)
-    FX_UP(expr_param, batch->expr_param, p.n_exprs)
+    FX_UP(var_off, voff, (size_t)n_sys + 1)
+    FX_UP(expr_off, eoff, (size_t)n_sys + 1)
+    FX_UP(sys_ncomp, p.sys_ncomp.data() + s0, n_sys)
+    FX_UP(sys_large, p.sys_large.data() + s0, n_sys)
+    FX_UP(vars0, (const double*)batch->vars + v0, n_vars)
+    FX_UP(var_info, p.var_info.data() + v0, n_vars)
+    FX_UP(expr_tag, p.expr_tagx.data() + e0, n_exprs)
+    FX_UP(expr_comp, p.expr_comp.data() + e0, n_exprs)
+    FX_UP(expr_idx, p.expr_idx16.data() + 4 * (size_t)e0, 4 * (size_t)n_exprs)
+    FX_UP(expr_param, batch->expr_param + e0, n_exprs)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
-    if (!p.sys_class.empty()) FX_UP(sys_class, p.sys_class.data(), p.n_systems)
-    FX_UP(w_list, p.wide_list.data(), p.wide_list.size())
+    if (sys_class) FX_UP(sys_class, sys_class, n_sys)
+    FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
+    const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy
+    FX_UP(vars, (const double*)batch->vars + v0, n_vars)
+    FX_UP(results, (const fx_result*)nullptr, n_sys)
 #undef FX_UP
-    size_t packed = 0;
-    for (const Req& r : reqs) packed += (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
-    std::vector<unsigned char> stage;
-    if (packed <= fx_ctx::PINNED_HALF) {
-        hipError_t e1 = hipSuccess;
-        unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
-        if (!base) {
-            fx_batch_free(ctx, db);
-            return fail(e1 == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", packed, hipGetErrorString(e1));
-        }
-        db->allocations.push_back({base, packed});
-        db->packed_base = base;
-        db->packed_bytes = packed;
-        unsigned char* st = nullptr;
-        if (packed <= fx_ctx::PINNED_HALF && ctx->ensure_pinned()) {
-            if (ctx->pinned_busy) {  // an earlier upload may still be reading the staging area
-                (void)hipStreamSynchronize(ctx->stream);
-                ctx->pinned_busy = false;
-            }
-            st = ctx->pinned;
-            db->upload_pending = true;
-        } else {
-            stage.assign(packed, 0);
-            st = stage.data();
-        }
+    auto room_of = [](const Req& r) { return (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255); };
+    size_t packed = 0, front = 0;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        packed += room_of(reqs[i]);
+        if (i + 1 == n_front) front = packed;
+    }
+    hipError_t e1 = hipSuccess;
+    unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
+    if (!base) {
+        fx_batch_free(ctx, db);
+        return fail(e1 == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", packed, hipGetErrorString(e1));
+    }
+    db->allocations.push_back({base, packed});
+    {
         size_t at = 0;
         for (const Req& r : reqs) {
-            const size_t room = (std::max<size_t>(r.bytes, 1) + 255u) & ~size_t(255);
-            if (r.src && r.bytes) {
-                memcpy(st + at, r.src, r.bytes);
-                memset(st + at + r.bytes, 0, room - r.bytes);
-            } else {
-                memset(st + at, 0, room);
-            }
             *r.dst = base + at;
-            at += room;
-        }
-        e1 = hipMemcpyAsync(base, st, packed, hipMemcpyHostToDevice, ctx->stream);
-        if (e1 != hipSuccess) {
-            fx_batch_free(ctx, db);
-            return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e1));
-        }
-        if (db->upload_pending) ctx->pinned_busy = true;
-    } else {
-        for (const Req& r : reqs) {
-            unsigned char* dptr = nullptr;
-            rc = dev_alloc_copy(ctx, db, &dptr, static_cast<const unsigned char*>(r.src), r.bytes);
-            if (rc) {
-                fx_batch_free(ctx, db);
-                return rc;
-            }
-            *r.dst = dptr;
+            at += room_of(r);
         }
     }
-    d.n_wide = (uint32_t)p.wide_list.size();
+    static const bool host_tail = std::getenv("FIKSI_AMD_UPLOAD_TAIL") != nullptr;  // (A / B switch of the measurement in DESIGN.md)
+    const bool on_device_tail = !host_tail && packed > (size_t(256) << 10);  // vars and results made on the device
+    auto upload = [&]() -> int {
+        if (packed <= fx_ctx::PINNED_HALF) {
+            db->packed_base = base;
+            db->packed_bytes = packed;
+            const size_t staged = on_device_tail ? front : packed;
+            std::vector<unsigned char> stage;
+            unsigned char* st = nullptr;
+            if (ctx->ensure_pinned()) {
+                ctx->wait_pinned();  // an earlier upload may still be reading the staging area
+                st = ctx->pinned;
+                db->upload_pending = true;
+            } else {
+                stage.resize(staged);
+                st = stage.data();
+            }
+            size_t at = 0;
+            for (size_t i = 0; i < reqs.size() && at < staged; ++i) {
+                const Req& r = reqs[i];
+                const size_t room = room_of(r);
+                if (r.src && r.bytes) {
+                    memcpy(st + at, r.src, r.bytes);
+                    memset(st + at + r.bytes, 0, room - r.bytes);
+                } else {
+                    memset(st + at, 0, room);
+                }
+                at += room;
+            }
+            FX_HIP(hipMemcpyAsync(base, st, staged, hipMemcpyHostToDevice, ctx->stream));
+            if (db->upload_pending) {
+                (void)hipEventRecord(ctx->ev_pinned, ctx->stream);
+                ctx->pinned_stream = ctx->stream;
+                ctx->pinned_busy = true;
+            } else {
+                FX_HIP(hipStreamSynchronize(ctx->stream));  // `stage` goes away with this frame
+            }
+        } else {
+            for (size_t i = 0; i < n_front; ++i) {
+                const Req& r = reqs[i];
+                if (r.src && r.bytes) {
+                    FX_HIP(hipMemcpyAsync(*r.dst, r.src, r.bytes, hipMemcpyHostToDevice, ctx->stream));
+                } else {
+                    FX_HIP(hipMemsetAsync(*r.dst, 0, room_of(r), ctx->stream));
+                }
+            }
+        }
+        if (on_device_tail) {
+            if (n_vars) FX_HIP(hipMemcpyAsync(d.vars, d.vars0, (size_t)n_vars * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            FX_HIP(hipMemsetAsync(d.results, 0, room_of(reqs.back()), ctx->stream));
+        }
+        return FX_OK;
+    };
+    rc = upload();
+    if (rc) {
+        fx_batch_free(ctx, db);
+        return rc;
+    }
+    d.n_wide = whole ? (uint32_t)p.wide_list.size() : 0u;
     d.w_max_free = p.w_max_free;
     d.w_max_vars = p.w_max_vars;
     d.w_max_rows = p.w_max_rows;
@@ -1819,6 +1887,10 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
             fx_batch_free(ctx, db);
             return fail(FX_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
         }
+    }
+    if (p.n_large && !whole) {
+        fx_batch_free(ctx, db);
+        return fail(FX_ERR_INVALID, "internal: a batch with Systems beyond one wavefront is not cut into chunks");
     }
     if (p.n_large) {
         const uint32_t nv = p.n_vars, ne = p.n_exprs, n = p.n_systems;
@@ -1853,12 +1925,25 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     return FX_OK;
 }
 
+int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
+    if (!out) return fail(FX_ERR_INVALID, "out-pointer is NULL");
+    *out = nullptr;
+    int rc = bind(ctx);
+    if (rc) return rc;
+    HostPlan p;
+    PhaseTrace tr;
+    rc = analyze(batch, &p);
+    if (rc) return rc;
+    tr.stamp("  analysis", batch->n_systems);
+    return upload_planned(ctx, batch, p, 0, p.n_systems, out);
+}
+
 static void free_batch(fx_ctx* ctx, fx_dbatch* db, bool stream_idle) {
     if (!db) return;
     if (ctx && !stream_idle) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
-        ctx->pinned_busy = false;
+        ctx->stream_synced();
     }
     for (auto& kv : db->sparse_plans) fx::sparse_cache_free(kv.second.plan);
     for (auto& blk : db->allocations) {
@@ -2114,7 +2199,7 @@ static int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch,
                 return FX_OK;
             };
             rc = run();
-            ctx->pinned_busy = false;
+            ctx->stream_synced();
             if (!rc) {
                 memcpy(batch->vars, back, (size_t)db->d.n_vars * sizeof(double));
                 if (results) memcpy(results, back + (reinterpret_cast<const unsigned char*>(db->d.results) - lo), (size_t)db->d.n_systems * sizeof(fx_result));
@@ -2129,13 +2214,88 @@ static int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch,
     return rc;
 }
 
+// A big batch of one-wavefront Systems, analysed as a whole, goes up and is solved in chunks of some megabytes: chunk k + 1
+// is copied up (second stream) while chunk k is being solved; the read-backs follow in order. Every System is solved on its
+// own and every chunk runs the kernels the whole batch would, so the cut changes nothing in the results (the tests compare
+// the bits). FIKSI_AMD_HOST_CHUNKS=0 switches it off, =k sets the number of chunks.
+static int solve_host_chunked(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t n_chunks, const fx_solving_opts* sopts,
+                              const fx_lm_opts* lopts, bool system_level, fx_result* results) {
+    const uint32_t n = p.n_systems;
+    struct Chunk {
+        fx_batch b{};
+        fx_dbatch* db = nullptr;
+        hipStream_t solve_stream = nullptr;
+        uint32_t s0 = 0;
+    };
+    std::vector<Chunk> chunks(n_chunks);
+    hipStream_t const main_stream = ctx->stream;
+    PhaseTrace tr;
+    int rc = FX_OK;
+    for (uint32_t k = 0; k < n_chunks && rc == FX_OK; ++k) {
+        Chunk& c = chunks[k];
+        const uint32_t s0 = (uint32_t)((uint64_t)n * k / n_chunks), s1 = (uint32_t)((uint64_t)n * (k + 1) / n_chunks);
+        c.s0 = s0;
+        c.b.n_systems = s1 - s0;
+        c.b.vars = batch->vars + batch->var_off[s0];  // (all the read-back needs of the chunk's host side)
+        // the copies on the second stream (never behind a solve), the solve on the context's own, after them
+        ctx->stream = ctx->stream2;
+        rc = upload_planned(ctx, batch, p, s0, s1, &c.db);
+        c.solve_stream = (k & 1u) ? ctx->stream3 : main_stream;
+        ctx->stream = c.solve_stream;
+        if (rc) break;
+        c.db->resident = false;
+        if (hipEventRecord(ctx->ev_chunk, ctx->stream2) != hipSuccess || hipStreamWaitEvent(c.solve_stream, ctx->ev_chunk, 0) != hipSuccess) {
+            rc = fail(FX_ERR_HIP, "event between the copy and the solve stream failed");
+            break;
+        }
+        rc = system_level ? fx_system_solve_device(ctx, c.db, sopts) : fx_lm_solve_device(ctx, c.db, lopts);
+    }
+    tr.stamp("chunks: up + launched", n);
+    if (rc != FX_OK) {  // nothing has been written to the caller's arrays yet
+        (void)hipStreamSynchronize(ctx->stream2);
+        for (Chunk& c : chunks)
+            if (c.db) {
+                ctx->stream = c.solve_stream ? c.solve_stream : main_stream;
+                free_batch(ctx, c.db, /*stream_idle=*/false);
+            }
+        ctx->stream = main_stream;
+        return rc;
+    }
+    for (Chunk& c : chunks) {
+        ctx->stream = c.solve_stream;
+        int r = read_back_and_free(ctx, c.db, &c.b, results ? results + c.s0 : nullptr, FX_OK);
+        if (r && !rc) rc = r;
+    }
+    ctx->stream = main_stream;
+    tr.stamp("chunks: read back", n);
+    return rc;
+}
+
 static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
                       bool system_level, fx_result* results) {
+    int rc = bind(ctx);
+    if (rc) return rc;
     fx_dbatch* db = nullptr;
     PhaseTrace tr;
-    int rc = fx_batch_upload(ctx, batch, &db);
+    {
+        HostPlan p;
+        rc = analyze(batch, &p);
+        if (rc) return rc;
+        tr.stamp("analysis", p.n_systems);
+        // Two chunks from 65 536 Systems on: measured on 100 000 ring16 sketches (tools/host_path.py), 2 chunks
+        // 6.3 ms, 3 and 4 chunks 6.8 ms, 8 chunks 8.7 ms, uncut 7.6 ms — every chunk pays its own dozen copies and the slow
+        // end of its own solve, so more chunks lose what the earlier start of the first solve wins
+        static const int forced = [] { const char* e = std::getenv("FIKSI_AMD_HOST_CHUNKS"); return e ? atoi(e) : -1; }();
+        uint32_t n_chunks = p.n_systems >= 65536u ? 2u : 0u;
+        if (forced >= 0) n_chunks = std::min<uint32_t>((uint32_t)forced, p.n_systems / 2u);
+        if (n_chunks >= 2 && p.n_large == 0 && (ctx->stream2 || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess) &&
+            (ctx->stream3 || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) == hipSuccess) &&
+            (ctx->ev_chunk || hipEventCreateWithFlags(&ctx->ev_chunk, hipEventDisableTiming) == hipSuccess))
+            return solve_host_chunked(ctx, batch, p, n_chunks, sopts, lopts, system_level, results);
+        rc = upload_planned(ctx, batch, p, 0, p.n_systems, &db);
+    }
     if (rc) return rc;
-    tr.stamp("analysis + upload", batch->n_systems);
+    tr.stamp("upload", batch->n_systems);
     db->resident = false;  // solved once and freed: no point in keeping plans
     rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
     tr.stamp("solve (launches)", batch->n_systems);

@@ -36,7 +36,10 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipErrorNoDevice; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned) { return hipErrorNoDevice; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t*) { return hipErrorNoDevice; }
+constexpr unsigned hipEventDisableTiming = 2u;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t*, unsigned) { return hipErrorNoDevice; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipErrorNoDevice; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipErrorNoDevice; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipErrorNoDevice; }
 inline hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t) { return hipErrorNoDevice; }

@@ -298,3 +298,26 @@ def test_one_shot_calls_reuse_the_plan_of_a_structure_seen_before(fiksi, ctx):
     v2, r2 = ctx.system_solve_batch(flats[5], abi.solving_opts(solver=1))
     v3, r3 = ctx.system_solve_batch(flats[5], abi.solving_opts(solver=1))
     assert np.array_equal(v2.view(np.uint64), v3.view(np.uint64)) and r2.tobytes() == r3.tobytes()
+
+
+def test_a_big_host_batch_solved_in_chunks_is_the_plain_solve(fiksi, ctx):
+    """fx_system_solve_batch on 65 536 one-wavefront Systems and more is analysed once, then copied up and solved in two
+    chunks (the second goes up while the first is solved; copy stream + two solve streams); a resident batch never chunks.
+    Same bits in every variable and result field; mixed structures, a fixed gauge in some; also under SinglePass."""
+    from fiksi_amd import abi, workloads
+
+    parts = []
+    for k in range(24):
+        parts += [workloads.ring16(3000, seed0=100 + 5000 * k), workloads.hinged_triangles(700, 5), workloads.ring16(300, seed0=9 + k, fix_gauge=True)]
+    b = workloads.concat(parts)
+    assert len(b["var_off"]) - 1 == 96000
+    for opts in (None, abi.solving_opts(decomposer=1)):
+        v, res = ctx.system_solve_batch(b, opts)      # chunked
+        db = ctx.upload(b)                              # resident: one block, one launch sequence
+        db.system_solve(opts)
+        v0, res0 = db.get_vars(), db.get_results()
+        db.free()
+        assert np.array_equal(v.view(np.uint64), v0.view(np.uint64))
+        for f in res.dtype.names:
+            x, y = res[f], res0[f]
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64)) if x.dtype.kind == "f" else np.array_equal(x, y), f
