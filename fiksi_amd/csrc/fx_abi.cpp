@@ -629,7 +629,7 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
-    uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: workers of the sparse path when a batch holds several large Systems
+    uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: kept for source compatibility, unused since the team kernels (round 3)
     // Page-locked staging for one-shot solves up to 8 MB of batch (System::solve on one sketch ... some ten thousand small
     // Systems): first half carries the packed upload, second half the read-back — both copies are then truly
     // asynchronous, one each, and the call waits on the stream once.

@@ -225,10 +225,9 @@ int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
  * second row to finish, so that the two take their next Systems side by side — the hand-over blocks cost the wavefront
  * the same for one row as for four. 0: never wait. Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
-/* A batch with several Systems beyond the one-wavefront kernels runs their host-driven loops (sparse path) on this many
- * host threads, one stream each (default 8; 0 restores the default, 1 = on the caller's thread and the context's stream).
- * Results do not depend on it. (Profilers that intercept launches may not cope with concurrent launching threads:
- * rocprofv3 --kernel-trace crashed inside hipLaunchKernel with 8 — profile with 1.) */
+/* Kept for source compatibility; no effect since round 3. (Round 2 ran one host-driven loop per large System on this many
+ * host threads. Systems beyond the one-wavefront kernels are now grouped by structure and solved by launches that carry a
+ * whole group — fx_sparse_team.h —, on the caller's thread and the context's stream.) */
 int fx_ctx_set_host_threads(fx_ctx* ctx, uint32_t threads);
 int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);

@@ -39,6 +39,14 @@ echo "[collect] K1 store policy A / B"
 python3 tools/k1_stores_ab.py > $OUT/k1_ab_nt.json 2> $OUT/k1_ab.err
 FIKSI_AMD_K1_STORES=plain python3 tools/k1_stores_ab.py > $OUT/k1_ab_plain.json 2>> $OUT/k1_ab.err
 python3 -c "import json,sys; a=json.loads(open('$OUT/k1_ab_nt.json').read().strip().splitlines()[-1]); b=json.loads(open('$OUT/k1_ab_plain.json').read().strip().splitlines()[-1]); json.dump({'source': 'tools/k1_stores_ab.py, one process per policy (FIKSI_AMD_K1_STORES)', 'non_temporal': a, 'plain': b}, open('$OUT/${TAG}_k1_stores_ab.json','w'), indent=1)"
+echo "[collect] host-buffer call, batched RecursiveAssembly, the slow end of a shard, the HBM mix"
+python3 tools/host_path.py 100000 9 > $OUT/hp_chunked.json 2>> $OUT/misc.err
+FIKSI_AMD_HOST_CHUNKS=0 python3 tools/host_path.py 100000 9 > $OUT/hp_plain.json 2>> $OUT/misc.err
+python3 -c "import json; a=json.loads(open('$OUT/hp_chunked.json').read().strip().splitlines()[-1]); b=json.loads(open('$OUT/hp_plain.json').read().strip().splitlines()[-1]); json.dump({'source': 'tools/host_path.py 100000 9; FIKSI_AMD_HOST_CHUNKS=0 for the uncut call', 'two_chunks': a, 'uncut': b}, open('$OUT/${TAG}_host_path.json','w'), indent=1)"
+python3 tools/ra_batch.py 10000 7 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_recursive_assembly_batch.json
+python3 tools/straggler_probe.py 12500 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_straggler_probe.json
+tools/probes/rw_mix_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_hbm_rw_mix.json
+tools/probes/valu_cost_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_valu_cost.json
 echo "[collect] plain bench line"
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/${TAG}_bench.json

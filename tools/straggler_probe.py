@@ -56,6 +56,18 @@ def main():
         db = ctx.upload(rest)
         out[name]["first_4000_fast_ones_ms"] = timed(ctx, db)
         db.free()
+    # where one slow System's cycles go, in either kernel (the diagnostic builds with phase stamps; s_memtime ticks of 100 MHz)
+    one = take(b, slow[np.argsort(res["trials"][slow])[-1:]])
+    for name, grouped in (("grouped_kernel", 1), ("one_per_wavefront_kernel", 0)):
+        ctx.set_routing(grouped, 1)
+        db = ctx.upload(one)
+        ph = db.phase_cycles()
+        db.system_solve()
+        r = db.get_results()
+        tot = float(sum(ph.values()))
+        out[name]["one_slow_system"] = {"trials": int(r["trials"][0]), "accepted": int(r["accepted"][0]),
+                                        "phase_share": {k: round(v / tot, 3) for k, v in ph.items()}, "ticks_100MHz": int(tot)}
+        db.free()
     print(json.dumps(out))
 
 
