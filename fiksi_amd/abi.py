@@ -207,6 +207,10 @@ class Context:
         """Grouped kernel: passes a finished row waits for a second one (fx_ctx_set_hold_passes); results unchanged."""
         check(lib.fx_ctx_set_hold_passes(self._h, passes), "fx_ctx_set_hold_passes")
 
+    def set_wide_routing(self, wide: int = -1):
+        """Components of 65 ... 128 free variables: 1 wide kernel, 0 team kernels, -1 by cost (fx_ctx_set_wide_routing)."""
+        check(lib.fx_ctx_set_wide_routing(self._h, wide), "fx_ctx_set_wide_routing")
+
     def set_host_threads(self, threads: int = 0):
         """Host threads for the sparse path's loops when a batch holds several large Systems (fx_ctx_set_host_threads)."""
         check(lib.fx_ctx_set_host_threads(self._h, threads), "fx_ctx_set_host_threads")

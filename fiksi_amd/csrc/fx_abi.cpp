@@ -32,6 +32,8 @@ namespace {
 thread_local std::string g_last_error;
 // set by fx_cluster_solve_batch while it uploads: the two pose-row tags of fx_expr.h are legal in that batch only
 thread_local bool g_allow_pose = false;
+// fx_ctx_set_wide_routing of the context the running call belongs to (-1 by cost, 0 team kernels, 1 wide kernel)
+thread_local int g_wide_routing = -1;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -528,6 +530,35 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     }
     for (uint32_t s = 0; s < n; ++s)
         if (p.sys_large[s] == 2) p.wide_list.push_back(s);
+    // Components of 65 ... 128 columns have two homes. The wide kernel (fx_wide.hip: one wavefront per System, dense packed
+    // factor in LDS) holds 4 / 2 / 1 Systems per CU and is the faster one for MANY of them; the team kernels (fx_sparse_team.h:
+    // a workgroup of 16 wavefronts per System, sparse factor) finish ONE such System in half the time (66 variables: 0.17
+    // against 0.36 ms) and win at any count from ~112 columns on. By cost, measured on the reference's hinged-triangle
+    // sketches of 66 / 98 / 126 variables, 1 ... 20 000 per batch (tools/hinged_batch.py):
+    //   team  = 0.17 ms + 0.0025 (c - 66)  +  n (1.45 us + 0.0175 (c - 66))
+    //   wide  = ceil(n / (256 CUs x Systems per CU)) x (0.37 ms + 0.0123 (c - 66))
+    // Both follow the reference's iteration path; they sum in different orders, so which one ran shows in the last bits (as it does
+    // for a large System alone / among seven others): fx_ctx_set_wide_routing(ctx, 0 | 1) pins it.
+    if (!p.wide_list.empty()) {
+        bool team = g_wide_routing == 0;
+        if (g_wide_routing < 0) {
+            fx::DeviceBatch probe{};
+            probe.w_max_free = p.w_max_free;
+            probe.w_max_vars = p.w_max_vars;
+            probe.w_max_rows = p.w_max_rows;
+            const size_t lds = fx::wide_lds_bytes(probe);
+            const double per_cu = lds ? std::min<double>(4., std::floor(160. * 1024. / (double)lds)) : 1.;
+            const double c = (double)p.w_max_free - 66., nw = (double)p.wide_list.size();
+            const double team_ms = 0.17 + 0.0025 * c + nw * (1.45e-3 + 1.75e-5 * c);
+            const double wide_ms = std::ceil(nw / (256. * std::max(per_cu, 1.))) * (0.37 + 0.0123 * c);
+            team = team_ms < wide_ms;
+        }
+        if (team) {
+            for (uint32_t s : p.wide_list) p.sys_large[s] = 1;
+            p.wide_list.clear();
+            p.w_max_free = p.w_max_rows = p.w_max_vars = 0;
+        }
+    }
     // Same structure everywhere? (sizes, components, fixed flags, kinds and element fields of System 0.) The
     // grouped kernel then builds its per-System lists once per lane row instead of once per System.
     if (n >= 2) {
@@ -629,6 +660,7 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
+    int wide_routing = -1;                 // fx_ctx_set_wide_routing
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: kept for source compatibility, unused since the team kernels (round 3)
     // Page-locked staging for one-shot solves up to 8 MB of batch (System::solve on one sketch ... some ten thousand small
     // Systems): first half carries the packed upload, second half the read-back — both copies are then truly
@@ -1629,6 +1661,13 @@ int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes) {
     return FX_OK;
 }
 
+int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    if (wide < -1 || wide > 1) return fail(FX_ERR_INVALID, "wide must be -1 (by cost), 0 (team kernels) or 1 (wide kernel)");
+    ctx->wide_routing = wide;
+    return FX_OK;
+}
+
 int fx_ctx_set_host_threads(fx_ctx* ctx, uint32_t threads) {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
     ctx->host_threads = threads ? std::min(threads, 64u) : 8u;
@@ -1932,6 +1971,7 @@ int fx_batch_upload(fx_ctx* ctx, const fx_batch* batch, fx_dbatch** out) {
     if (rc) return rc;
     HostPlan p;
     PhaseTrace tr;
+    g_wide_routing = ctx->wide_routing;
     rc = analyze(batch, &p);
     if (rc) return rc;
     tr.stamp("  analysis", batch->n_systems);
@@ -2279,6 +2319,7 @@ static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts*
     PhaseTrace tr;
     {
         HostPlan p;
+        g_wide_routing = ctx->wide_routing;
         rc = analyze(batch, &p);
         if (rc) return rc;
         tr.stamp("analysis", p.n_systems);

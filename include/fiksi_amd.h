@@ -225,6 +225,12 @@ int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
  * second row to finish, so that the two take their next Systems side by side — the hand-over blocks cost the wavefront
  * the same for one row as for four. 0: never wait. Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
+/* Where components of 65 ... 128 free variables are solved: 1 = the wide kernel (one wavefront per System, dense factor in LDS:
+ * the faster one for thousands of them), 0 = the team kernels (a workgroup per System, sparse factor: half the latency of
+ * one solve, and faster at any count from ~112 columns on), -1 (default) = by the measured cost of either for the batch at
+ * hand. Both follow the reference's iteration path; they add in different orders, so the choice shows in the last bits of
+ * a result — pin it when results must not depend on how many such Systems share a batch. */
+int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide);
 /* Kept for source compatibility; no effect since round 3. (Round 2 ran one host-driven loop per large System on this many
  * host threads. Systems beyond the one-wavefront kernels are now grouped by structure and solved by launches that carry a
  * whole group — fx_sparse_team.h —, on the caller's thread and the context's stream.) */

@@ -6,6 +6,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def wide_kernel(ctx):
+    """These tests are about the wide kernel: pin it (by default a small batch of such Systems goes to the team kernels,
+    which finish one of them in half the time — fx_ctx_set_wide_routing; the last test covers that choice)."""
+    ctx.set_wide_routing(1)
+    yield
+    ctx.set_wide_routing(-1)
+
+
 def _rms(x):
     x = np.asarray(x, dtype=np.float64)
     return float(np.sqrt(np.mean(x * x))) if len(x) else 0.0
@@ -130,3 +139,28 @@ def test_f32_requests_on_medium_and_large_systems_take_the_f64_device_kernels(fi
         assert np.array_equal(v32.view(np.uint64), v64.view(np.uint64)) and r32.tobytes() == r64.tobytes()
         assert np.all(r32["sse_unscaled"] < 1e-4)
         assert dt < 0.5, dt  # the host-driven path took ~1 ms per System
+
+
+@pytest.mark.parametrize("n_tri", [16, 24, 31])
+def test_either_home_of_a_medium_component_follows_the_oracle(fiksi, oracle, ctx, n_tri):
+    """Components of 65 ... 128 columns run on the wide kernel or on the team kernels (fx_ctx_set_wide_routing; by default
+    by measured cost: few of them -> team kernels, thousands -> wide kernel, from ~112 columns on always the team kernels).
+    Either way the oracle's accepted / trial counts and SSE; the two agree to rounding, and each is deterministic."""
+    from fiksi_amd import workloads
+
+    b = workloads.hinged_triangles(12, n_tri)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    got = {}
+    for wide in (1, 0, -1):
+        ctx.set_wide_routing(wide)
+        v, res = ctx.system_solve_batch(b)
+        v2, res2 = ctx.system_solve_batch(b)
+        assert np.array_equal(v.view(np.uint64), v2.view(np.uint64)) and np.array_equal(res, res2)
+        for f in ("scale", "accepted", "trials", "exit"):
+            assert np.array_equal(res[f], res_o[f]), (wide, f)
+        assert np.allclose(res["sse"], res_o["sse"], rtol=1e-6, atol=1e-12)
+        assert np.max(np.abs(v - v_o)) < 1e-8
+        got[wide] = v
+    assert np.max(np.abs(got[1] - got[0])) < 1e-9
+    # twelve such Systems are few: the default took the team kernels
+    assert np.array_equal(got[-1].view(np.uint64), got[0].view(np.uint64))
