@@ -742,8 +742,7 @@ struct fx_ctx {
         if (best != free_blocks.size()) {
             void* p = free_blocks[best].p;
             free_bytes -= free_blocks[best].size;
-            free_blocks[best] = free_blocks.back();
-            free_blocks.pop_back();
+            free_blocks.erase(free_blocks.begin() + (long)best);  // (keeps the list in order of release: give_back evicts from the front)
             return p;
         }
         void* p = nullptr;
@@ -759,9 +758,16 @@ struct fx_ctx {
         return err == hipSuccess ? p : nullptr;
     }
     void give_back(void* p, size_t bytes) {
-        if (free_bytes + bytes > MAX_CACHED_BYTES || free_blocks.size() >= 256) {
+        if (bytes > MAX_CACHED_BYTES) {
             (void)hipFree(p);
             return;
+        }
+        // full: the blocks cached longest go back to the driver, not the one that was in use a moment ago (a list full of
+        // small blocks used to turn every big batch's block into a hipFree + hipMalloc pair per call)
+        while (!free_blocks.empty() && (free_bytes + bytes > MAX_CACHED_BYTES || free_blocks.size() >= 256)) {
+            (void)hipFree(free_blocks.front().p);
+            free_bytes -= free_blocks.front().size;
+            free_blocks.erase(free_blocks.begin());
         }
         free_blocks.push_back({p, bytes});
         free_bytes += bytes;
@@ -1145,12 +1151,26 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
     fx::qr::Symbolic sy;
     if (!fx::qr::analyze(a, true, sy)) return false;
     if (sy.hrows.size() > 0xFFFFu) return false;
-    out.nnzh = (uint32_t)sy.hrows.size();
-    out.u16.reserve(n + (m + n) + (n + 1) + sy.hrows.size());
+    // The rows of every Householder vector below its diagonal entry are padded to a multiple of eight with row m + n — the
+    // row of zeros the kernel keeps under the matrix: its register window then loads, multiplies and stores whole blocks of
+    // eight with no per-entry select (a padded slot adds 0 * x = +0.0 to a sum that is never -0.0, and writes back the
+    // zero it read). hptr counts the padded entries.
+    std::vector<uint16_t> hptr_p(n + 1, 0), hrows_p;
+    for (uint32_t j = 0; j < n; ++j) {
+        hptr_p[j] = (uint16_t)hrows_p.size();
+        const int b = sy.hptr[j], e = sy.hptr[j + 1];
+        for (int q = b; q < e; ++q) hrows_p.push_back((uint16_t)sy.hrows[q]);
+        const int below = e - b - 1;
+        for (int q = below; q < ((below + 7) & ~7); ++q) hrows_p.push_back((uint16_t)(m + n));
+        if (hrows_p.size() > 0xFFFFu) return false;
+    }
+    hptr_p[n] = (uint16_t)hrows_p.size();
+    out.nnzh = (uint32_t)hrows_p.size();
+    out.u16.reserve(n + (m + n) + (n + 1) + hrows_p.size());
     for (uint32_t j = 0; j < n; ++j) out.u16.push_back((uint16_t)sy.col_perm[j]);
     for (uint32_t i = 0; i < m + n; ++i) out.u16.push_back((uint16_t)sy.row_perm[i]);
-    for (uint32_t j = 0; j <= n; ++j) out.u16.push_back((uint16_t)sy.hptr[j]);
-    for (int r : sy.hrows) out.u16.push_back((uint16_t)r);
+    out.u16.insert(out.u16.end(), hptr_p.begin(), hptr_p.end());
+    out.u16.insert(out.u16.end(), hrows_p.begin(), hrows_p.end());
     out.u64.assign(2 * (size_t)n, 0);
     for (uint32_t j = 0; j < n; ++j)
         for (int p = sy.rptr[j]; p < sy.rptr[j + 1] - 1; ++p) {

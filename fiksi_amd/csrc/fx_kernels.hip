@@ -510,7 +510,6 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                 const int my_hptr = (int)q_hptr[lane];          // hptr[0..63], one per lane
                 const uint32_t hptr_end = q_hptr[nfree];
                 constexpr int CHT = 32;  // entries of a Householder vector (below the diagonal) kept in registers
-                const uint32_t zero_row = Mq * LDX;
                 for (uint32_t k = 0; k < nfree; ++k) {
                     const uint32_t hb = (uint32_t)__builtin_amdgcn_readlane(my_hptr, (int)k);
                     const uint32_t he = (k + 1u < nfree) ? (uint32_t)__builtin_amdgcn_readlane(my_hptr, (int)(k + 1u)) : hptr_end;
@@ -519,78 +518,73 @@ __device__ __forceinline__ void lm_solve_body(const DeviceBatch& b, const LmPara
                     const double v0 = QX[k * LDX + k];
                     const bool windowed = len1 <= (uint32_t)CHT;
                     // the whole vector and this lane's column entries under it, fetched once: row offsets, then the two
-                    // columns — two LDS round trips per vector instead of two per entry and pass. (The offset array has CHT
-                    // entries of slack, so the reads past the vector's end stay inside it; their values are never used.)
-                    uint32_t ro[CHT];
-                    double vk[CHT], xj[CHT];
-                    double xk0 = 0.0, sigma = 0.0;
-                    if (windowed) {
-                        xk0 = QX[k * LDX + cx];
-#pragma unroll
-                        for (int blk = 0; blk < CHT / 8; ++blk)
-                            if (len1 > (uint32_t)(8 * blk)) {
-#pragma unroll
-                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) {
-                                    const uint32_t off = q_hoff[hb + 1u + (uint32_t)u];
-                                    ro[u] = ((uint32_t)u < len1) ? off : zero_row;
-                                }
-                            }
-#pragma unroll
-                        for (int blk = 0; blk < CHT / 8; ++blk)
-                            if (len1 > (uint32_t)(8 * blk)) {
-#pragma unroll
-                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) {
-                                    // slots past the vector's end read the row of zeros: their terms add +0.0 to a sum that is
-                                    // never -0.0 (it starts at +0.0), which changes nothing — no select on the dependent chain
-                                    vk[u] = QX[ro[u] + k];
-                                    xj[u] = QX[ro[u] + cx];
-                                }
-                            }
-#pragma unroll
-                        for (int blk = 0; blk < CHT / 8; ++blk)
-                            if (len1 > (uint32_t)(8 * blk)) {
-#pragma unroll
-                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) sigma = sigma + vk[u] * vk[u];
-                            }
-                    } else {
-                        for (uint32_t t = hb + 1u; t < he; ++t) {
-                            const double x = QX[q_hoff[t] + k];
-                            sigma = sigma + x * x;
-                        }
-                    }
+                    // columns — two LDS round trips per vector instead of two per entry and pass. The host pads every
+                    // vector to whole blocks of eight with the row of zeros (build_qr_plan), so a block is loaded,
+                    // multiplied and stored with no per-entry test.
                     // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
-                    double norm = ::fabs(v0), beta = (v0 >= 0.0) ? 0.0 : 2.0, v0n = 1.0;
-                    if (sigma != 0.0) {
-                        norm = ::sqrt(sigma + v0 * v0);
-                        v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
-                        beta = -(1.0 / (norm * v0n));
-                    }
-                    if (windowed) {
+                    auto householder = [&](double sigma, double& norm, double& beta, double& v0n) {
+                        norm = ::fabs(v0);
+                        beta = (v0 >= 0.0) ? 0.0 : 2.0;
+                        v0n = 1.0;
+                        if (sigma != 0.0) {
+                            norm = ::sqrt(sigma + v0 * v0);
+                            v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
+                            beta = -(1.0 / (norm * v0n));
+                        }
+                    };
+                    // a vector of NB blocks of eight entries below the diagonal, start to finish (one copy of the code per
+                    // block count, picked once per vector: the same body with a test in front of every block of every pass
+                    // spent a tenth of the loop's instructions on scalar compares and branches)
+                    double norm = 0.0, beta = 0.0, v0n = 1.0;
+                    auto window = [&](auto nb_c) {
+                        constexpr int NE = 8 * decltype(nb_c)::value;
+                        uint32_t ro[NE > 0 ? NE : 1];
+                        double vk[NE > 0 ? NE : 1], xj[NE > 0 ? NE : 1];
+                        const double xk0 = QX[k * LDX + cx];
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) ro[u] = q_hoff[hb + 1u + (uint32_t)u];
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) {
+                            vk[u] = QX[ro[u] + k];
+                            xj[u] = QX[ro[u] + cx];
+                        }
+                        double sigma = 0.0;
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) sigma = sigma + vk[u] * vk[u];
+                        householder(sigma, norm, beta, v0n);
                         double tau = 0.0;
                         tau = tau + v0n * xk0;
 #pragma unroll
-                        for (int blk = 0; blk < CHT / 8; ++blk)
-                            if (len1 > (uint32_t)(8 * blk)) {
-#pragma unroll
-                                for (int u = 8 * blk; u < 8 * blk + 8; ++u) tau = tau + vk[u] * xj[u];
-                            }
+                        for (int u = 0; u < NE; ++u) tau = tau + vk[u] * xj[u];
                         tau = tau * beta;
                         if (act) {
                             QX[k * LDX + cx] = xk0 - v0n * tau;
 #pragma unroll
-                            for (int blk = 0; blk < CHT / 8; ++blk)
-                                if (len1 > (uint32_t)(8 * blk)) {
-#pragma unroll
-                                    for (int u = 8 * blk; u < 8 * blk + 8; ++u)
-                                        if ((uint32_t)u < len1) QX[ro[u] + cx] = xj[u] - vk[u] * tau;
-                                }
+                            for (int u = 0; u < NE; ++u) QX[ro[u] + cx] = xj[u] - vk[u] * tau;  // (padding: 0 - 0 tau)
                         }
-                    } else if (act) {
-                        apply_h(k, cx, v0n, beta, hb, he);
+                    };
+                    if (windowed) {
+                        switch (len1 >> 3) {  // (the host pads len1 to a multiple of eight)
+                            case 0: window(std::integral_constant<int, 0>{}); break;
+                            case 1: window(std::integral_constant<int, 1>{}); break;
+                            case 2: window(std::integral_constant<int, 2>{}); break;
+                            case 3: window(std::integral_constant<int, 3>{}); break;
+                            default: window(std::integral_constant<int, 4>{}); break;
+                        }
+                    } else {
+                        double sigma = 0.0;
+                        for (uint32_t t = hb + 1u; t < he; ++t) {
+                            const double x = QX[q_hoff[t] + k];
+                            sigma = sigma + x * x;
+                        }
+                        householder(sigma, norm, beta, v0n);
+                        if (act) apply_h(k, cx, v0n, beta, hb, he);
                     }
-                    if (lane == 0) {
-                        QV0[k] = v0n;
-                        QBETA[k] = beta;
+                    if constexpr (N == 64) {  // (kept for the right-hand side's own pass below, which only a 64-column component needs)
+                        if (lane == 0) {
+                            QV0[k] = v0n;
+                            QBETA[k] = beta;
+                        }
                     }
                     __syncthreads();
                     if (lane == 0) QX[k * LDX + k] = norm;  // R's diagonal (qr.rs:319)
