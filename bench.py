@@ -438,13 +438,15 @@ def host_path(ctx, batch, np):
 
     n = len(batch["var_off"]) - 1
     ctx.system_solve_batch(batch)
-    t0 = _t.perf_counter()
-    reps = 3
-    for _ in range(reps):
+    times = []
+    for _ in range(7):  # median of seven calls: a single call now and then takes 20 - 30 ms (a fresh device block, the host's scheduler)
+        t0 = _t.perf_counter()
         v, res = ctx.system_solve_batch(batch)
-    dt = (_t.perf_counter() - t0) / reps
+        times.append(_t.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
-    return {"entry_point": "fx_system_solve_batch", "systems": n, "ms_per_call": dt * 1e3, "converged_systems_per_sec": conv / dt}
+    return {"entry_point": "fx_system_solve_batch", "systems": n, "ms_per_call": dt * 1e3, "ms_per_call_min": min(times) * 1e3,
+            "ms_per_call_max": max(times) * 1e3, "calls": len(times), "converged_systems_per_sec": conv / dt}
 
 
 def other_workloads(ctx, abi, workloads, np, n_sys: int):
