@@ -241,9 +241,16 @@ void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_o
         for (uint32_t blk = b_lo; blk < b_hi; ++blk) {
             const uint32_t r0 = blk * 256u;
             uint32_t nrw = std::min<uint32_t>(256, ne - r0), t = 0;
+            uint8_t sorted[256];
             for (int tag = 0; tag < FX_NTAGS_POSE; ++tag)
                 for (uint32_t i = 0; i < nrw; ++i)
-                    if ((expr_tagx[r0 + i] & 0x7F) == tag) out.row_perm[r0 + t++] = (uint8_t)i;
+                    if ((expr_tagx[r0 + i] & 0x7F) == tag) sorted[t++] = (uint8_t)i;
+            // The sorted order, rotated by a wavefront per block: wavefront w of every workgroup lands on the same SIMD of its
+            // CU, so without the rotation the expensive kinds (the angle rows: two atan2, three times a distance row's
+            // instructions) of all eight resident blocks pile up on one SIMD while the other three idle.
+            static const bool rotate = std::getenv("FIKSI_AMD_K1_ROTATE") == nullptr || std::getenv("FIKSI_AMD_K1_ROTATE")[0] != '0';
+            const uint32_t shift = (nrw == 256u && rotate) ? 64u * (blk & 3u) : 0u;
+            for (uint32_t i = 0; i < nrw; ++i) out.row_perm[r0 + i] = sorted[(i + shift) % nrw];
             fx::BlockInfo bi{};
             bi.sys0 = expr_sys[r0];
             bool simple = true;
