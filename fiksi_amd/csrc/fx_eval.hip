@@ -53,8 +53,13 @@ __device__ __forceinline__ uint32_t compute_slots(int tag, const uint16_t f[4], 
 
 // NT: the results leave with non-temporal stores (the shipped form). NT = false exists for the A / B measurement only
 // (FIKSI_AMD_K1_STORES=plain, tools/k1_stores_ab.py).
+// uni_period: 0, or — for a batch of ONE structure (one sketch, many parameter sets: b.uniform) — the number of blocks after
+// which the tag-sorted order of a block's rows repeats (lcm of the rotation's 4 and u_nexprs / gcd(256, u_nexprs)). Such a
+// batch reads its structure from the first System's rows and the first uni_period blocks' orders: a few hundred bytes that
+// stay in L1, instead of 11 bytes per row streamed from HBM in two more dependent round trips. What is left in front of a
+// block's arithmetic is ONE trip to HBM (parameters and variables, both addressed from the cached structure).
 template <bool WANT_J, bool NT = true>
-__global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x) {
+__global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x, uint32_t uni_period) {
     // Block = 256 consecutive rows. Threads take the block's rows in tag-sorted order (host-built
     // permutation) so that a wavefront sees as few expression kinds as possible (divergence: the
     // angle rows cost ~8x a distance row). Residuals and the block's CSR values (contiguous in the
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
     __shared__ uint32_t swave[4];
     const uint32_t row0 = blockIdx.x * 256u;
     const uint32_t nrows = min(256u, b.n_exprs - row0);
+    const bool uni = uni_period != 0u && nrows == 256u;
     const BlockInfo bi = b.blk_info[blockIdx.x];
     const bool simple = (bi.flags & 1u) != 0;
     const uint32_t jbase = bi.jbase;
@@ -75,14 +81,16 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
     bool dup = false;
     double g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (live) {
-        lrow = b.row_perm[row0 + threadIdx.x];
+        lrow = b.row_perm[(uni ? (blockIdx.x % uni_period) * 256u : row0) + threadIdx.x];
         const uint32_t row = row0 + lrow;
-        const int tagx = b.expr_tag[row];
+        const uint32_t sys = uni ? row / b.u_nexprs : 0u;      // (the System of the row and the row inside it)
+        const uint32_t srow = uni ? row - sys * b.u_nexprs : row;
+        const int tagx = b.expr_tag[srow];
         const int tag = tagx & 0x7F;
         dup = (tagx & 0x80) != 0;
-        ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[row];
+        ushort4 f4 = reinterpret_cast<const ushort4*>(b.expr_idx)[srow];
         uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
-        const uint32_t v0 = simple ? b.var_off[bi.sys0 + b.row_sysoff[row]] : b.expr_var0[row];
+        const uint32_t v0 = uni ? sys * b.u_nvars : simple ? b.var_off[bi.sys0 + b.row_sysoff[row]] : b.expr_var0[row];
         uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         expand_vars(tag, ff, vars8);
         double v[8];
@@ -176,12 +184,27 @@ hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian
         const char* s = getenv("FIKSI_AMD_K1_STORES");
         return s && s[0] == 'p';
     }();
+    static const bool no_uniform = [] {  // (A / B switch of the measurement in DESIGN.md 6)
+        const char* s = getenv("FIKSI_AMD_K1_UNIFORM");
+        return s && s[0] == '0';
+    }();
+    uint32_t period = 0;
+    if (b.uniform && b.u_nexprs && !no_uniform) {
+        uint32_t g = 256u, r = b.u_nexprs;  // gcd
+        while (r) {
+            const uint32_t t = g % r;
+            g = r;
+            r = t;
+        }
+        period = b.u_nexprs / g;
+        while (period % 4u) period *= 2u;  // lcm with the rotation of the sorted order (fx_abi.cpp: build_eval_plan)
+    }
     if (want_jacobian && plain_stores) {
-        hipLaunchKernelGGL((eval_rows_kernel<true, false>), grid, block, 0, stream, b, x);
+        hipLaunchKernelGGL((eval_rows_kernel<true, false>), grid, block, 0, stream, b, x, period);
     } else if (want_jacobian) {
-        hipLaunchKernelGGL(eval_rows_kernel<true>, grid, block, 0, stream, b, x);
+        hipLaunchKernelGGL(eval_rows_kernel<true>, grid, block, 0, stream, b, x, period);
     } else {
-        hipLaunchKernelGGL(eval_rows_kernel<false>, grid, block, 0, stream, b, x);
+        hipLaunchKernelGGL(eval_rows_kernel<false>, grid, block, 0, stream, b, x, period);
     }
     return hipGetLastError();
 }

@@ -4,7 +4,7 @@ perturbation, Jacobian values, non-angle residuals); stated tolerances elsewhere
 import numpy as np
 import pytest
 
-from helpers import mixed_sketch
+from helpers import Lcg, mixed_sketch
 
 pytestmark = pytest.mark.gpu
 
@@ -31,6 +31,45 @@ def test_k1_residual_jacobian_ring16_bit_exact(fiksi, oracle, ctx):
     ang = np.isin(b["expr_tag"], ANGLE_TAGS)
     assert np.array_equal(r[~ang], r_o[~ang])
     assert np.max(np.abs(r[ang] - r_o[ang])) <= 4e-15  # |angle| <= pi, a few ulp of atan2
+
+
+@pytest.mark.parametrize("builder, n", [("ring16", 1500), ("hinged11", 2100), ("hinged3", 5000), ("gauge", 900), ("mixed_copies", 700)])
+def test_k1_one_structure_batches_read_their_structure_from_the_first_system(fiksi, oracle, ctx, builder, n):
+    """A batch of ONE structure (one sketch, many parameter sets) reads kinds, fields and the tag-sorted order of a block
+    from the first System / the first `period` blocks (fx_eval.hip, round 3) instead of streaming them per row. Row counts
+    of 32, 33, 9 and 36 per System against blocks of 256 rows: periods of 4, 132, 36 and 12 blocks, batches several
+    periods long with a partial last block; fixed variables (the gauge) and a mixed sketch with every kind. Bit for bit
+    the oracle's values (angle residuals to 4e-15), residual-only kernel included."""
+    from fiksi_amd import workloads
+
+    if builder == "ring16":
+        b = workloads.ring16(n, seed0=77)
+    elif builder == "gauge":
+        b = workloads.ring16(n, seed0=5, fix_gauge=True)
+    elif builder == "hinged11":
+        b = workloads.hinged_triangles(n, 11)
+    elif builder == "hinged3":
+        b = workloads.hinged_triangles(n, 3)
+    else:
+        one = mixed_sketch(3, fix_some=True).flatten()
+        parts = []
+        g = Lcg(11)
+        for k in range(n):
+            c = {key: val.copy() for key, val in one.items()}
+            c["vars"] = c["vars"] * (1.0 + 0.01 * g.u(-1, 1))
+            parts.append(c)
+        b = workloads.concat(parts)
+    nsys = len(b["var_off"]) - 1
+    assert nsys >= 2 and int(b["expr_off"][-1]) > 3 * 256
+    r, (rp, ci, vals) = ctx.eval_residual_jacobian(b)
+    r_o, (rp_o, ci_o, vals_o) = oracle.eval_batch(b)
+    assert np.array_equal(rp.astype(np.int64), rp_o) and np.array_equal(ci.astype(np.int32), ci_o)
+    assert np.array_equal(vals, vals_o)
+    ang = np.isin(b["expr_tag"], ANGLE_TAGS)
+    assert np.array_equal(r[~ang], r_o[~ang])
+    assert not ang.any() or np.max(np.abs(r[ang] - r_o[ang])) <= 4e-15
+    r2, _ = ctx.eval_residual_jacobian(b, want_jacobian=False)
+    assert np.array_equal(r, r2)
 
 
 def test_k1_all_eleven_expression_kinds(fiksi, oracle, ctx):

@@ -1,4 +1,5 @@
-"""Diagnostic driver for rocprofv3: the Jacobian-assembly kernel (K1) alone on a batch of n ring16 sketches."""
+"""Diagnostic driver for rocprofv3: the Jacobian-assembly kernel (K1) alone on a batch of n ring16 sketches
+(third argument `hinged`: the reference's bench sketch of 11 hinged triangles instead — distance rows only)."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import fiksi_amd
@@ -6,7 +7,8 @@ from fiksi_amd import workloads
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = fiksi_amd.Context(0)
-db = ctx.upload(workloads.ring16(n, seed0=5_000_000))
+hinged = len(sys.argv) > 3 and sys.argv[3] == "hinged"
+db = ctx.upload(workloads.hinged_triangles(n, 11) if hinged else workloads.ring16(n, seed0=5_000_000))
 for _ in range(reps):
     db.eval_residual_jacobian(0)
 ctx.synchronize()
