@@ -261,12 +261,12 @@ def main() -> int:
         out["roofline"] = roof
         out["solve_kernel"].update(sq_counters("lm_solve_grouped_kernel", FLOPS_PER_TRIAL * trials_per_step))
         if world == 1 and not args.quick:
+            out["host_path"] = host_path(ctx, batch, np)
             out["step_solvers"] = step_solvers(ctx, db, abi, np, n_sys, solve_ms)
             out["cfg4_prediction"] = cfg4_prediction(ctx, abi, workloads, batch, solve_ms)
             out["other_workloads"] = other_workloads(ctx, abi, workloads, np, n_sys)
             out["large_systems"] = large_systems(ctx, abi, workloads, np)
             out["reference_bench_group"] = reference_bench_group(ctx, abi, workloads, np)
-            out["host_path"] = host_path(ctx, batch, np)
             out["decomposers_single_triangle"] = decomposers_single_triangle(ctx)
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_sample)

@@ -47,6 +47,7 @@ python3 tools/ra_batch.py 10000 7 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_recu
 python3 tools/straggler_probe.py 12500 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_straggler_probe.json
 tools/probes/rw_mix_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_hbm_rw_mix.json
 tools/probes/valu_cost_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_valu_cost.json
-echo "[collect] plain bench line"
+echo "[collect] plain bench line (it quotes the counter files: this run's go to profiles/ first)"
+cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic_500k.json $OUT/${TAG}_pmc_sq.json $ROOT/profiles/
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/${TAG}_bench.json
