@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
         for (int e = 0; e < 8; ++e) v[e] = x[v0 + vars8[e]];
         rstage[lrow] = eval_expression<double, WANT_J>(tag, v, b.expr_param[row], g);
         if (WANT_J) {
-            if (simple) {
+            if (simple && uni) {
+                // (one structure: the row's place among the block's values from the first System's row pointers — cached
+                // — instead of the scan over the block's row lengths and its four barriers)
+                slots = compute_slots(tag, ff, cnt);
+                base = sys * b.jrow_ptr[b.u_nexprs] + b.jrow_ptr[srow] - jbase;
+            } else if (simple) {
                 slots = compute_slots(tag, ff, cnt);
                 scnt[lrow] = cnt;
             } else {
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const dou
             }
         }
     }
-    if (WANT_J && simple) {
+    if (WANT_J && simple && !uni) {
         // exclusive scan of the row lengths in row order: wave scan + 4 wave totals
         if (!live) scnt[threadIdx.x] = 0;  // rows beyond the batch end
         __syncthreads();
