@@ -32,3 +32,24 @@ def test_sharded_solve_equals_the_single_context_solve(fiksi, ctx):
     finally:
         for c in others:
             c.close()
+
+
+def test_shards_large_enough_to_be_solved_in_chunks(fiksi, ctx):
+    """Each context's shard of 70 000 one-wavefront Systems takes the chunked host path (copy stream + two solve streams
+    of its own context); two contexts, two host threads: the bits of the resident solve."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.concat([workloads.ring16(69000, seed0=31), workloads.hinged_triangles(1000, 5), workloads.ring16(70000, seed0=900000)])
+    assert len(b["var_off"]) - 1 == 140000
+    db = ctx.upload(b)
+    db.system_solve()
+    v1, r1 = db.get_vars(), db.get_results()
+    db.free()
+    others = [fiksi.Context(0) for _ in range(2)]
+    try:
+        v, r, total = abi.Context.system_solve_batch_multi(others, b)
+        assert np.array_equal(v.view(np.uint64), v1.view(np.uint64))
+        assert np.array_equal(r, r1) and total["systems"] == 140000
+    finally:
+        for c in others:
+            c.close()
