@@ -538,11 +538,12 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     for (uint32_t s = 0; s < n; ++s)
         if (p.sys_large[s] == 2) p.wide_list.push_back(s);
     // Components of 65 ... 128 columns have two homes. The wide kernel (fx_wide.hip: one wavefront per System, dense packed
-    // factor in LDS) holds 4 / 2 / 1 Systems per CU and is the faster one for MANY of them; the team kernels (fx_sparse_team.h:
-    // a workgroup of 16 wavefronts per System, sparse factor) finish ONE such System in half the time (66 variables: 0.17
-    // against 0.36 ms) and win at any count from ~112 columns on. By cost, measured on the reference's hinged-triangle
-    // sketches of 66 / 98 / 126 variables, 1 ... 20 000 per batch (tools/hinged_batch.py):
-    //   team  = 0.17 ms + 0.0025 (c - 66)  +  n (1.45 us + 0.0175 (c - 66))
+    // factor in LDS) holds 4 / 2 / 1 Systems per CU; the team kernels (fx_sparse_team.h: a workgroup of 16 wavefronts per
+    // System, sparse factor, the whole solve in one launch) finish ONE such System in half the time (66 variables: 0.17
+    // against 0.36 ms) and cost half a microsecond per System at any size, which only the wide kernel's four-per-CU case
+    // beats, and only from a thousand Systems on. By cost, measured on the reference's hinged-triangle sketches of 66 / 98 /
+    // 126 variables, 1 ... 20 000 per batch (tools/hinged_batch.py):
+    //   team  = max(0.18 ms, n (0.49 us + 0.0011 (c - 66)))
     //   wide  = ceil(n / (256 CUs x Systems per CU)) x (0.37 ms + 0.0123 (c - 66))
     // Both follow the reference's iteration path; they sum in different orders, so which one ran shows in the last bits (as it does
     // for a large System alone / among seven others): fx_ctx_set_wide_routing(ctx, 0 | 1) pins it.
@@ -556,7 +557,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             const size_t lds = fx::wide_lds_bytes(probe);
             const double per_cu = lds ? std::min<double>(4., std::floor(160. * 1024. / (double)lds)) : 1.;
             const double c = (double)p.w_max_free - 66., nw = (double)p.wide_list.size();
-            const double team_ms = 0.17 + 0.0025 * c + nw * (1.45e-3 + 1.75e-5 * c);
+            const double team_ms = std::max(0.18, nw * (0.49e-3 + 1.1e-6 * c));
             const double wide_ms = std::ceil(nw / (256. * std::max(per_cu, 1.))) * (0.37 + 0.0123 * c);
             team = team_ms < wide_ms;
         }
@@ -800,6 +801,15 @@ struct fx_dbatch {
         fx::SparsePlanCache* plan;
     };
     std::multimap<uint64_t, ResidentPlan> sparse_plans;
+    // ... and the grouping of those Systems by structure, per solve mode: it reads structure only, so a resident batch
+    // works it out once (building and hashing a System's key is ~4 us per 258-variable sketch — more than the solve of a
+    // batch of them once that is one launch)
+    struct StructureGroup {
+        std::vector<unsigned char> key;
+        uint64_t hash = 0;
+        std::vector<uint32_t> systems;
+    };
+    std::map<uint32_t, std::vector<StructureGroup>> large_groups;
     // Decomposer::None on large Systems made of small components: the component walk (a DeviceBatch
     // whose unit arrays list whole components), built on first use
     fx::DeviceBatch comp_walk{};
@@ -1522,56 +1532,96 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
             if (e != hipSuccess) return fail(FX_ERR_HIP, "component walk launch failed: %s", hipGetErrorString(e));
         }
     }
-    std::vector<uint32_t> todo;
-    for (uint32_t s = 0; s < db->d.n_systems; ++s) {
-        if (!db->h_sys_large[s]) continue;
-        if (db->h_sys_large[s] == 2 && !pose && wide_kernel_applies(p)) continue;  // done by the wide kernel
-        if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
-        if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
-        todo.push_back(s);
-    }
-    if (todo.empty()) return FX_OK;
     // ---- Systems of one STRUCTURE (fixed flags, tags, fields, components) share a plan and are solved together
     const fx_batch& hb = db->h_batch;
-    auto structure_key = [&](uint32_t s) {
-        const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0, e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
-        std::vector<unsigned char> key;
-        auto put = [&](const void* ptr, size_t bytes) {
-            const unsigned char* c = static_cast<const unsigned char*>(ptr);
-            key.insert(key.end(), c, c + bytes);
+    const bool wide_done = !pose && wide_kernel_applies(p);
+    const uint32_t groups_of = (p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS)) | (wide_done ? 0x100u : 0u) | (device_units ? 0x200u : 0u) |
+                               (comp_walk ? 0x400u : 0u) | (pose ? 0x800u : 0u);
+    std::vector<fx_dbatch::StructureGroup> local_groups;
+    const bool cached = db->resident && db->large_groups.count(groups_of) != 0;
+    std::vector<fx_dbatch::StructureGroup>& groups = db->resident ? db->large_groups[groups_of] : local_groups;
+    if (!cached) {
+        std::vector<uint32_t> todo;
+        for (uint32_t s = 0; s < db->d.n_systems; ++s) {
+            if (!db->h_sys_large[s]) continue;
+            if (db->h_sys_large[s] == 2 && wide_done) continue;                                            // done by the wide kernel
+            if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
+            if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
+            todo.push_back(s);
+        }
+        auto slices = [&](uint32_t s, const void* ptr[5], size_t len[5]) {
+            const uint32_t v0 = hb.var_off[s], nvt = hb.var_off[s + 1] - v0, e0 = hb.expr_off[s], net = hb.expr_off[s + 1] - e0;
+            ptr[0] = hb.var_fixed + v0;                  len[0] = nvt;
+            ptr[1] = hb.expr_tag + e0;                   len[1] = net;
+            ptr[2] = hb.expr_idx + 4 * (size_t)e0;       len[2] = 4 * (size_t)net * sizeof(uint32_t);
+            ptr[3] = hb.var_comp ? hb.var_comp + v0 : nullptr;   len[3] = hb.var_comp ? nvt * sizeof(uint16_t) : 0;
+            ptr[4] = hb.expr_comp ? hb.expr_comp + e0 : nullptr; len[4] = hb.expr_comp ? net * sizeof(uint16_t) : 0;
         };
-        const uint32_t head[4] = {p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS), 0u, nvt, net};
-        put(head, sizeof(head));
-        put(hb.var_fixed + v0, nvt);
-        put(hb.expr_tag + e0, net);
-        put(hb.expr_idx + 4 * (size_t)e0, 4 * (size_t)net * sizeof(uint32_t));
-        if (hb.var_comp) put(hb.var_comp + v0, nvt * sizeof(uint16_t));
-        if (hb.expr_comp) put(hb.expr_comp + e0, net * sizeof(uint16_t));
-        return key;
-    };
-    // groups in order of their first System; a 64-bit hash finds the candidates, the bytes decide
-    struct Group {
-        std::vector<unsigned char> key;
-        std::vector<uint32_t> systems;
-    };
-    std::vector<Group> groups;
-    {
-        std::map<uint64_t, std::vector<size_t>> by_hash;
-        for (uint32_t s : todo) {
-            std::vector<unsigned char> key = structure_key(s);
+        auto structure_key = [&](uint32_t s) {
+            const void* ptr[5];
+            size_t len[5];
+            slices(s, ptr, len);
+            std::vector<unsigned char> key;
+            const uint32_t head[4] = {p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS), 0u, hb.var_off[s + 1] - hb.var_off[s],
+                                      hb.expr_off[s + 1] - hb.expr_off[s]};
+            key.reserve(sizeof(head) + len[0] + len[1] + len[2] + len[3] + len[4]);
+            key.insert(key.end(), reinterpret_cast<const unsigned char*>(head), reinterpret_cast<const unsigned char*>(head) + sizeof(head));
+            for (int k = 0; k < 5; ++k)
+                if (len[k]) key.insert(key.end(), static_cast<const unsigned char*>(ptr[k]), static_cast<const unsigned char*>(ptr[k]) + len[k]);
+            return key;
+        };
+        auto same_structure = [&](uint32_t x, uint32_t y) {  // the raw arrays of two Systems, slice by slice
+            const void *px[5], *py[5];
+            size_t lx[5], ly[5];
+            slices(x, px, lx);
+            slices(y, py, ly);
+            for (int k = 0; k < 5; ++k)
+                if (lx[k] != ly[k] || (lx[k] && memcmp(px[k], py[k], lx[k]) != 0)) return false;
+            return true;
+        };
+        auto hash_of = [](const std::vector<unsigned char>& key) {  // eight bytes at a time
             uint64_t h = 1469598103934665603ull;
-            for (unsigned char c : key) h = (h ^ c) * 1099511628211ull;
+            size_t i = 0;
+            for (; i + 8 <= key.size(); i += 8) {
+                uint64_t w;
+                memcpy(&w, key.data() + i, 8);
+                h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+                h ^= h >> 29;
+            }
+            for (; i < key.size(); ++i) h = (h ^ key[i]) * 1099511628211ull;
+            return h;
+        };
+        // groups in order of their first System; a System with the structure of the one before it joins that one's group
+        // (one sketch, many parameter sets: two memcmp passes instead of a key), otherwise a 64-bit hash finds the candidates
+        // and the bytes decide
+        std::map<uint64_t, std::vector<size_t>> by_hash;
+        size_t last_group = 0;
+        uint32_t last_system = 0;
+        bool have_last = false;
+        for (uint32_t s : todo) {
+            if (have_last && same_structure(s, last_system)) {
+                groups[last_group].systems.push_back(s);
+                continue;
+            }
+            std::vector<unsigned char> key = structure_key(s);
+            const uint64_t h = hash_of(key);
             std::vector<size_t>& cand = by_hash[h];
             size_t g = groups.size();
             for (size_t i : cand)
                 if (groups[i].key == key) g = i;
             if (g == groups.size()) {
                 cand.push_back(g);
-                groups.push_back({std::move(key), {}});
+                groups.emplace_back();
+                groups.back().key = std::move(key);
+                groups.back().hash = h;
             }
             groups[g].systems.push_back(s);
+            last_group = g;
+            last_system = s;
+            have_last = true;
         }
     }
+    if (groups.empty()) return FX_OK;
     // plans: a resident batch keeps its own (per structure and decomposer mode); one-shot calls share the context's
     // (fx_ctx::plan_for — entries this call has touched are never evicted under it). Cluster problems of
     // RecursiveAssembly differ from step to step: nothing to keep.
@@ -1579,8 +1629,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     std::vector<fx::SparsePlanCache*> group_plan(groups.size(), nullptr);
     for (size_t g = 0; g < groups.size(); ++g) {
         if (db->resident) {
-            uint64_t h = (p.mode & fx::MODE_UNITS) ? 0x9E3779B97F4A7C15ull : 0ull;
-            for (unsigned char c : groups[g].key) h = (h ^ c) * 1099511628211ull;
+            const uint64_t h = groups[g].hash ^ ((p.mode & fx::MODE_UNITS) ? 0x9E3779B97F4A7C15ull : 0ull);
             auto range = db->sparse_plans.equal_range(h);
             fx_dbatch::ResidentPlan* found = nullptr;
             for (auto it = range.first; it != range.second; ++it)
