@@ -16,6 +16,8 @@
 // No floating-point work happens on the host. Optimizer::LBfgs keeps its host-side line search
 // (sparse_solve_system: two scalars per evaluation).
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include <algorithm>
@@ -538,12 +540,17 @@ template <bool POSE, bool LDSV, bool BLOB>
 hipError_t launch_team_t(uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l, uint32_t lds_v,
                          const uint32_t* blob, uint32_t blob_words, unsigned long long* prof) {
-    static bool raised = false;  // (per instantiation; the attribute is a property of the function)
-    if (LDSV && !raised) {
+    // (per instantiation AND device: the attribute belongs to the function on the current device; groups of different
+    // structures launch from several host threads)
+    static std::atomic<uint32_t> raised_on{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)TEAM_LDS_VALUES_MAX);
         if (e != hipSuccess) return e;
-        raised = true;
+        raised_on.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV, BLOB>), dim3(n), dim3(TEAM_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
                        lds_l, lds_v, blob, blob_words, prof);
@@ -560,13 +567,16 @@ hipError_t launch_team(bool pose, bool ldsv, bool blob_in_lds, uint32_t n, size_
 
 // the LDS builds of the parts kernels may ask for more than the default 64 KB of dynamic LDS
 hipError_t raise_lds_limits() {
-    static bool raised = false;
-    if (raised) return hipSuccess;
+    static std::atomic<uint32_t> raised_on{0};  // bit d: done on device d
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (raised_on.load(std::memory_order_relaxed) & bit) return hipSuccess;
     hipError_t e = hipSuccess;
     for (const void* f : {reinterpret_cast<const void*>(&sptl_parts_up_kernel<false>), reinterpret_cast<const void*>(&sptl_parts_up_kernel<true>),
                           reinterpret_cast<const void*>(&sptl_parts_down_kernel<false>), reinterpret_cast<const void*>(&sptl_parts_down_kernel<true>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TEAM_LDS_VALUES_MAX);
-    raised = e == hipSuccess;
+    if (e == hipSuccess) raised_on.fetch_or(bit, std::memory_order_relaxed);
     return e;
 }
 

@@ -231,9 +231,10 @@ int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
  * hand. Both follow the reference's iteration path; they add in different orders, so the choice shows in the last bits of
  * a result — pin it when results must not depend on how many such Systems share a batch. */
 int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide);
-/* Kept for source compatibility; no effect since round 3. (Round 2 ran one host-driven loop per large System on this many
- * host threads. Systems beyond the one-wavefront kernels are now grouped by structure and solved by launches that carry a
- * whole group — fx_sparse_team.h —, on the caller's thread and the context's stream.) */
+/* Systems beyond the one-wavefront kernels are grouped by structure, and every launch carries a whole group (fx_sparse_team.h).
+ * A batch with SEVERAL structures solves its groups side by side on this many host threads, a stream each (default 8; 0 restores
+ * the default, 1 = one after the other on the caller's thread and the context's stream). Results do not depend on it.
+ * (Profilers that intercept launches may not cope with concurrent launching threads: profile with 1.) */
 int fx_ctx_set_host_threads(fx_ctx* ctx, uint32_t threads);
 int fx_ctx_synchronize(fx_ctx* ctx);
 int fx_ctx_device_name(fx_ctx* ctx, char* buf, size_t len);
