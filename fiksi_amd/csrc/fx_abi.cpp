@@ -248,8 +248,7 @@ void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_o
             // The sorted order, rotated by a wavefront per block: wavefront w of every workgroup lands on the same SIMD of its
             // CU, so without the rotation the expensive kinds (the angle rows: two atan2, three times a distance row's
             // instructions) of all eight resident blocks pile up on one SIMD while the other three idle.
-            static const bool rotate = std::getenv("FIKSI_AMD_K1_ROTATE") == nullptr || std::getenv("FIKSI_AMD_K1_ROTATE")[0] != '0';
-            const uint32_t shift = (nrw == 256u && rotate) ? 64u * (blk & 3u) : 0u;
+            const uint32_t shift = nrw == 256u ? 64u * (blk & 3u) : 0u;
             for (uint32_t i = 0; i < nrw; ++i) out.row_perm[r0 + i] = sorted[(i + shift) % nrw];
             fx::BlockInfo bi{};
             bi.sys0 = expr_sys[r0];
@@ -1964,8 +1963,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
             at += room_of(r);
         }
     }
-    static const bool host_tail = std::getenv("FIKSI_AMD_UPLOAD_TAIL") != nullptr;  // (A / B switch of the measurement in DESIGN.md)
-    const bool on_device_tail = !host_tail && packed > (size_t(256) << 10);  // vars and results made on the device
+    const bool on_device_tail = packed > (size_t(256) << 10);  // vars and results made on the device
     auto upload = [&]() -> int {
         if (packed <= fx_ctx::PINNED_HALF) {
             db->packed_base = base;
