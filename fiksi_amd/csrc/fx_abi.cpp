@@ -667,6 +667,7 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
+    uint32_t ladder = 1u, ladder_k = 16u, ladder_tail = 0u, ladder_spread = 1u;  // fx_ctx_set_ladder
     int wide_routing = -1;                 // fx_ctx_set_wide_routing
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: groups of large Systems (one structure each) solved side by side
     std::vector<hipStream_t> worker_streams;  // ... a stream per extra host thread
@@ -737,6 +738,10 @@ struct fx_ctx {
         p.route_grouped = route_grouped;
         p.grouped_min_systems = grouped_min_systems;
         p.hold_passes = hold_passes;
+        p.ladder = ladder;
+        p.ladder_k = ladder_k;
+        p.ladder_tail = ladder_tail;
+        p.spread = ladder_spread;
     }
     static constexpr size_t MAX_CACHED_BYTES = size_t(4) << 30;  // beyond this, released blocks go back to the driver
 
@@ -1769,6 +1774,15 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes) {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
     ctx->hold_passes = passes;
+    return FX_OK;
+}
+
+int fx_ctx_set_ladder(fx_ctx* ctx, int enable, uint32_t tail_systems, uint32_t min_trials, int spread) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    ctx->ladder = enable ? 1u : 0u;
+    ctx->ladder_tail = tail_systems;
+    ctx->ladder_k = min_trials;
+    ctx->ladder_spread = spread ? 1u : 0u;
     return FX_OK;
 }
 

@@ -133,6 +133,12 @@ struct LmParams {
     int route_grouped = -1;
     uint32_t grouped_min_systems = 1024u;
     uint32_t hold_passes = 2u;  // grouped kernel: passes a finished row waits for a second one before its set-up blocks (fx_ctx_set_hold_passes)
+    // grouped kernel, the lambda ladder (fx_ctx_set_ladder): rows without a System of their own try the next lambdas of a
+    // running System of their wavefront side by side. ladder_tail / ladder_k: with at most ladder_tail Systems left in the
+    // queue, a wavefront that holds a System past ladder_k trials takes no further Systems (0: rows only help once the
+    // queue is empty). spread: the first 4 * spread tickets of a scheduled hand-out are dealt one per wavefront (set by the
+    // launcher).
+    uint32_t ladder = 1u, ladder_k = 16u, ladder_tail = 0u, spread = 0u;
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

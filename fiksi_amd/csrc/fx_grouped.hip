@@ -282,6 +282,31 @@ __device__ __forceinline__ void group_sync() {
 
 enum GroupPhase : int { GP_NEXT = 0, GP_COMP = 1, GP_RUN = 2, GP_FINISH = 3, GP_EXIT = 4 };
 
+// What one lambda trial found (lm.rs:115-191), before anything of the row's LM state has changed. LC_REJECT is the plain
+// reject — lambda x reject_factor and the next trial — the only verdict after which the loop goes on from the same point
+// with the same Jacobian: the trials that follow a plain reject are independent of it and of each other (the ladder below).
+enum LadderCode : int {
+    LC_REJECT = 0,    // lm.rs:187-190
+    LC_SINGULAR = 1,  // lm.rs:134-137
+    LC_NAN = 2,       // non-finite step (reported as FX_EXIT_NAN; the reference would spin)
+    LC_STEP = 3,      // lm.rs:139-142
+    LC_ACCEPT = 4,    // lm.rs:151-186
+    LC_REJ_NAN = 5,   // rejected with a NaN trial point and lambda past 1e300
+    LC_REJ_FTOL = 6,  // f32 only: rejected within round-off of the current SSE
+    LC_CAP = 7,       // max_trials reached before this trial
+    LC_FRESH = 8      // the component's start point, no trial
+};
+
+// any lane's value (ds_bpermute: the source lane must be active)
+__device__ __forceinline__ int lane_get(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+__device__ __forceinline__ float lane_get(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+__device__ __forceinline__ double lane_get(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 // PROF = true is the diagnostic build (fx_debug_phase_cycles): s_memtime stamps at the phase boundaries, summed
 // per phase over the wavefront (all four rows) into prm.prof — same six phases as lm_solve_kernel's.
 enum GPhase { GH_SETUP = 0, GH_EVAL = 1, GH_FORM = 2, GH_FACTOR = 3, GH_SOLVE = 4, GH_TAIL = 5, GH_COUNT = 6 };
@@ -319,6 +344,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     T* rhsv = reinterpret_cast<T*>(base + L.off_rhs);    // [N] -Jt r
     T* G = reinterpret_cast<T*>(base + L.off_g);         // [mr][8] Jacobian rows of the last evaluated point
     T* R = reinterpret_cast<T*>(base + L.off_r);         // [mr]
+    // (the next five are read-only while a component is solved; a row that helps another row's System on the lambda
+    // ladder reads that row's copies)
     T* P = reinterpret_cast<T*>(base + L.off_p);         // [mr] scaled parameters
     uint16_t* gvar = reinterpret_cast<uint16_t*>(base + L.off_gvar);  // [mr][8]
     uint8_t* rtag = reinterpret_cast<uint8_t*>(base + L.off_rtag);    // [mr]
@@ -357,6 +384,20 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
     bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
     uint32_t held = 0;   // passes this row has waited, done, for company (see FINISH)
+    // The lambda ladder (prm.ladder). The trials that follow a plain reject read the same point, Jacobian and residuals
+    // and differ in lambda only (x reject_factor each, lm.rs:187-190), so they can be made side by side: a row without a
+    // System of its own (the queue is empty, or the wavefront holds a straggler near the end of the queue) joins a
+    // running row of its wavefront as rank 1, 2 or 3 of that System's group and tries lambda x reject_factor^rank in
+    // the same pass. The verdicts are read in rank order and the first that is not a plain reject decides for the whole
+    // group exactly as it would have decided in the sequential loop; `trials` advances by the trials the sequential loop
+    // would have made up to it. Every row of a group holds the same LM state at the top of every pass.
+    constexpr bool LADDER = (NC <= 2) && !PROF;
+    const int myrow = lane / RS;
+    int lad_rank = 0, lad_width = 1, lad_lead = myrow;
+    uint32_t lad_members = (uint32_t)myrow * 0x55u;  // row of rank k at bits 2k, 2k + 1
+    int src_off = 0;      // bytes from this row's Jacobian rows / residuals to those of the row whose trial was accepted
+    bool qdone = false;   // this row has seen the end of the queue
+    uint32_t last_tk = 0; // the last ticket this row drew
     // The product list of a component does not change between its assemblies: the 32-column f64 build (one wavefront
     // per SIMD, registers to spare) keeps each lane's first PWR / PER list words in registers, which takes the list
     // read — one of three dependent LDS round trips per batch of products — out of every assembly.
@@ -449,6 +490,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
     // K3: the lower triangle of Jt J and -Jt r from the packed lists (ds_add_f64 / ds_add_f32)
     auto form_normal = [&]() {
+        // the rows of the accepted point: this row's own, or (ladder) those of the row whose trial was accepted
+        const T* G = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base + L.off_g) + src_off);
+        const T* R = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base + L.off_r) + src_off);
         {  // zero the triangle, 16 bytes per lane and instruction
             using V = typename Vec16<T>::type;
             constexpr uint32_t NV = (uint32_t)(N * (N + 1) / 2) / (uint32_t)Vec16<T>::n;
@@ -547,21 +591,43 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
 
     for (;;) {
+        // Ladder: near the end of the queue a wavefront that holds a straggler — a System past prm.ladder_k trials —
+        // stops taking Systems: its rows go idle as they finish and join the straggler's ladder (below). Without a
+        // straggler a row that went idle that way goes back to the queue.
+        bool park = false;
+        if constexpr (LADDER) {
+            if (prm.ladder) {
+                const bool straggler =
+                    __ballot(phase == GP_RUN && lad_rank == 0 && !fresh && trials >= prm.ladder_k) != 0ull;
+                if (phase == GP_EXIT && !qdone && !straggler) phase = GP_NEXT;
+                park = straggler && prm.ladder_tail != 0u && last_tk < b.n_systems && b.n_systems - last_tk <= prm.ladder_tail;
+            }
+        }
         // ================= NEXT: take a System, scale it, snapshot its variables =================
+        if (phase == GP_NEXT && park) phase = GP_EXIT;
         if (phase == GP_NEXT) {
             uint32_t nxt;
             for (;;) {
                 uint32_t tk = 0;
                 if (hl == 0) {
                     tk = atomicAdd(next_system, 1u);
-                    if (b.order && tk < b.n_systems) tk = b.order[tk];  // a schedule from an earlier solve of this batch
+                    last_tk = tk;
+                    if (b.order && tk < b.n_systems) {  // a schedule: presort, or an earlier solve of this batch
+                        // the first round of tickets transposed, so that the Systems at the head of the schedule — the
+                        // likely stragglers — go to different wavefronts (a straggler's ladder is the rows of ITS wavefront)
+                        uint32_t pos = tk;
+                        if (tk < 4u * prm.spread) pos = (tk & 3u) * prm.spread + (tk >> 2);
+                        tk = b.order[pos];
+                    }
                 }
                 nxt = (uint32_t)__shfl((int)tk, 0, RS);
+                last_tk = (uint32_t)__shfl((int)last_tk, 0, RS);
                 // large Systems belong to the other paths (a batch of one shared structure has none here)
                 if (nxt >= b.n_systems || b.uniform || !b.sys_large[nxt]) break;
             }
             if (nxt >= b.n_systems) {
                 phase = GP_EXIT;
+                qdone = true;
             } else {
                 s = nxt;
                 if (b.uniform) {  // offsets are multiples of the common sizes: one round trip less
@@ -903,6 +969,95 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
         }
 
+        // ================= LADDER: idle rows join a running row of their wavefront =================
+        if constexpr (LADDER) {
+            if (prm.ladder) {
+                const unsigned long long bcand = __ballot(phase == GP_RUN && !fresh && lad_rank == 0);
+                const unsigned long long bidle = __ballot(phase == GP_EXIT);
+                if (bcand != 0ull && bidle != 0ull) {
+                    // wave-uniform bookkeeping over the four rows, packed into words (no indexed arrays: they would live in
+                    // scratch): every idle row goes to the running row with the smallest group so far; rows already helping
+                    // stay where they are. wid: 4 bits per leader row; mem: its members, 8 bits per leader row; newlead /
+                    // newrank: 4 bits per joining row (0xF: does not join)
+                    uint32_t wid = 0, mem = 0, newlead = 0xFFFFu, newrank = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        wid |= ((uint32_t)__builtin_amdgcn_readlane(lad_width, RS * r) & 15u) << (4 * r);
+                        mem |= ((uint32_t)__builtin_amdgcn_readlane((int)lad_members, RS * r) & 255u) << (8 * r);
+                    }
+                    bool anyjoin = false;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (!((bidle >> (RS * r)) & 1ull)) continue;
+                        uint32_t best = 15u, bw = 4u;
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) {
+                            const uint32_t w = (wid >> (4 * l)) & 15u;
+                            if (((bcand >> (RS * l)) & 1ull) && w < bw) {
+                                best = (uint32_t)l;
+                                bw = w;
+                            }
+                        }
+                        if (best != 15u) {
+                            newlead = (newlead & ~(15u << (4 * r))) | (best << (4 * r));
+                            newrank |= bw << (4 * r);
+                            const uint32_t at = 8u * best + 2u * bw;
+                            mem = (mem & ~(3u << at)) | ((uint32_t)r << at);
+                            wid += 1u << (4u * best);
+                            anyjoin = true;
+                        }
+                    }
+                    if (anyjoin) {
+                        const uint32_t nl = (newlead >> (4 * myrow)) & 15u;
+                        const bool joining = nl != 15u;
+                        const int grp = joining ? (int)nl : lad_lead;  // the row whose group this row belongs to from now on
+                        // the leader's registers (every lane runs the shuffles: the source lanes must be active)
+                        const int srcl = grp * RS + hl;
+                        auto cp = [&](auto& v) {
+                            const auto t = lane_get(v, srcl);
+                            if (joining) v = t;
+                        };
+                        cp(nfree); cp(m_rows); cp(n_pw); cp(n_pe); cp(trials); cp(accepted); cp(outer); cp(exit_code);
+                        cp(sse); cp(lambda);
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            cp(my_vi[q]); cp(xc[q]); cp(diag[q]); cp(rhs_l[q]);
+                        }
+                        if constexpr (PWR > 0) {
+#pragma unroll
+                            for (int u = 0; u < PWR; ++u) cp(pw_reg[u]);
+#pragma unroll
+                            for (int u = 0; u < PER; ++u) cp(pe_reg[u]);
+                        }
+                        lad_width = (int)((wid >> (4 * grp)) & 15u);
+                        lad_members = (mem >> (8 * grp)) & 255u;
+                        if (joining) {
+                            lad_lead = (int)nl;
+                            lad_rank = (int)((newrank >> (4 * myrow)) & 15u);
+                            built = false;  // this row's lists in registers are the leader's now
+                            unsigned char* lb = smem + (uint32_t)nl * L.stride;
+                            P = reinterpret_cast<T*>(lb + L.off_p);
+                            gvar = reinterpret_cast<uint16_t*>(lb + L.off_gvar);
+                            rtag = reinterpret_cast<uint8_t*>(lb + L.off_rtag);
+                            PW = reinterpret_cast<uint32_t*>(lb + L.off_pw);
+                            PE = reinterpret_cast<uint16_t*>(lb + L.off_pe);
+                            // its working variables (the fixed ones and other components' are read by the rows) and the
+                            // triangle of Jt J as last assembled (every row writes its own diagonal per trial)
+                            const T* lxs = reinterpret_cast<const T*>(lb + L.off_xs);
+                            for (uint32_t i = hl; i < L.vt; i += RS) XS[i] = lxs[i];
+                            using V = typename Vec16<T>::type;
+                            constexpr uint32_t NV = (uint32_t)(N * (N + 1) / 2) / (uint32_t)Vec16<T>::n;
+                            const V* lat = reinterpret_cast<const V*>(lb + L.off_a);
+                            for (uint32_t i = hl; i < NV; i += RS) reinterpret_cast<V*>(At)[i] = lat[i];
+                            fresh = false;
+                            phase = GP_RUN;
+                        }
+                        group_sync();
+                    }
+                }
+            }
+        }
+
         // the most columns any row of the wavefront factors in this pass (wave-uniform: the four row leaders)
         int kmax;
         {
@@ -914,18 +1069,25 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
         // ================= RUN: one lambda trial (lm.rs:115-191) =================
         if (phase == GP_RUN) {
             stamp(GH_TAIL);
+            // --- the trial: what it finds is written down as a verdict (`code`); the row's LM state is only changed
+            // below, by the verdict that decides (the row's own, or — on the ladder — its group's first decisive one)
+            int code = LC_FRESH;
             bool go = true;
             T delta[NC];
 #pragma unroll
             for (int q = 0; q < NC; ++q) delta[q] = T(0);
             if (!fresh) {
-                if (trials >= o.max_trials) {
-                    exit_code = FX_EXIT_TRIAL_CAP;
-                    phase = GP_FINISH;
+                code = LC_REJECT;
+                // this row's lambda: the group's, after `rank` plain rejects
+                double lam_k = lambda;
+                if constexpr (LADDER) {
+                    for (int k = 0; k < lad_rank; ++k) lam_k *= o.reject_factor;
+                }
+                if (trials + (uint32_t)lad_rank >= o.max_trials) {
+                    code = LC_CAP;
                     go = false;
                 }
                 if (go) {
-                    trials += 1;
                     // K4: factor (JtJ + lambda I) and solve for delta; columns hl and hl + 16 of the symmetric
                     // matrix from the triangle (the lane id goes through an opaque move so that the addresses are
                     // recomputed per trial instead of being hoisted out of the loop into dozens of long-lived
@@ -933,7 +1095,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     int hv = hl;
                     asm volatile("" : "+v"(hv));
 #pragma unroll
-                    for (int q = 0; q < NC; ++q) At[tri_at((uint32_t)(hv + RS * q), (uint32_t)(hv + RS * q))] = diag[q] + (T)lambda;
+                    for (int q = 0; q < NC; ++q) At[tri_at((uint32_t)(hv + RS * q), (uint32_t)(hv + RS * q))] = diag[q] + (T)lam_k;
                     group_sync();
                     // Element (i, j) of the symmetric matrix sits at row max(i, j) of the packed triangle. For a lane's
                     // column j = hv + 16 q that is its own row for i <= j (contiguous: one base register, the element
@@ -963,7 +1125,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     RBlock<NC, T, 0, UNITS>::factor(a, invd, bad, hl, kmax);
                     stamp(GH_FACTOR);
                     if (bad) {  // lm.rs:134-137
-                        lambda *= o.singular_factor;
+                        code = LC_SINGULAR;
                         go = false;
                     } else {
                         T acc[NC], invd2[NC];
@@ -984,12 +1146,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     if constexpr (NC >= 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
                     if constexpr (NC >= 3) dn2 = dn2 + row_sum(delta[2] * delta[2]);
                     if (!(dn2 == dn2)) {
-                        exit_code = FX_EXIT_NAN;
-                        phase = GP_FINISH;
+                        code = LC_NAN;
                         go = false;
                     } else if (dn2 < (T)o.step_tol) {  // lm.rs:139-142
-                        exit_code = FX_EXIT_STEP;
-                        phase = GP_FINISH;
+                        code = LC_STEP;
                         go = false;
                     }
                     stamp(GH_SOLVE);
@@ -1002,59 +1162,135 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     group_sync();
                 }
             }
+            T sse_t = T(0);
             if (go) {
-                const T sse_t = eval_rows();
+                sse_t = eval_rows();
                 stamp(GH_EVAL);
-                bool assemble = false;
-                if (fresh) {  // the component's start point
-                    sse = sse_t;
-                    sse_start = sse_t;
-                    assemble = true;
-                } else if (sse_t < sse) {  // accept, lm.rs:151-186
-                    lambda *= o.accept_factor;
-                    if (lambda < o.lambda_min) lambda = o.lambda_min;
+                if (!fresh) {
+                    if (sse_t < sse) {
+                        code = LC_ACCEPT;  // lm.rs:151-186
+                    } else {               // lm.rs:187-190
+                        double lam_k = lambda;
+                        for (int k = 0; k <= lad_rank; ++k) lam_k *= o.reject_factor;
+                        if (!(sse_t == sse_t) && !(lam_k < 1.0e300)) {
+                            code = LC_REJ_NAN;  // NaN trial point: the reference would double lambda forever
+                        } else if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) {
+                            // f32 only (fx_lm_opts_default_f32): a rejected trial whose SSE is within ftol of the current one
+                            // is round-off, not a worse point — the solve has stagnated at what f32 can resolve. Without this
+                            // exit such Systems double lambda dozens of times until |delta|^2 < step_tol, and a batch waits
+                            // for them.
+                            code = LC_REJ_FTOL;
+                        }
+                    }
+                }
+            }
+            // --- the verdict that decides. Alone: the row's own. On the ladder: the verdicts of the group in rank order,
+            // the first that is not a plain reject — what the sequential loop would have met first.
+            int kw = (code != LC_REJECT) ? 0 : 1;  // plain rejects in front of the deciding trial (== width: all of them)
+            int code_w = code;
+            T sse_w = sse_t;
+            T delta_w[NC];
 #pragma unroll
-                    for (int q = 0; q < NC; ++q)
-                        if ((uint32_t)(hl + RS * q) < nfree) xc[q] = xc[q] + delta[q];
-                    accepted += 1;
-                    const T rel = (sse - sse_t) / sse;
-                    sse = sse_t;  // the returned point's SSE (the reference leaves it stale, quirk Q9)
-                    if (rel <= (T)o.ftol) {
-                        exit_code = FX_EXIT_FTOL;
-                        phase = GP_FINISH;
-                    } else {
-                        assemble = true;
-                        outer += 1;
+            for (int q = 0; q < NC; ++q) delta_w[q] = delta[q];
+            src_off = 0;
+            if constexpr (LADDER) {
+                if (__ballot(lad_width > 1) != 0ull) {
+                    int ck[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ck[k] = lane_get(code, (int)((lad_members >> (2 * k)) & 3u) * RS + hl);
+                    kw = lad_width;
+                    code_w = LC_REJECT;
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) {
+                        if (k < lad_width && ck[k] != LC_REJECT) {
+                            kw = k;
+                            code_w = ck[k];
+                        }
                     }
-                } else {  // reject, lm.rs:187-190
-                    lambda *= o.reject_factor;
-                    if (!(sse_t == sse_t) && !(lambda < 1.0e300)) {
-                        exit_code = FX_EXIT_NAN;  // NaN trial point: the reference would double lambda forever
-                        phase = GP_FINISH;
-                    } else if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) {
-                        // f32 only (fx_lm_opts_default_f32): a rejected trial whose SSE is within ftol of the current one
-                        // is round-off, not a worse point — the solve has stagnated at what f32 can resolve. Without this
-                        // exit such Systems double lambda dozens of times until |delta|^2 < step_tol, and a batch waits
-                        // for them.
-                        exit_code = FX_EXIT_FTOL;
-                        phase = GP_FINISH;
-                    }
+                    const int wrow = (int)((lad_members >> (2 * (kw < lad_width ? kw : 0))) & 3u);
+                    const int wl = wrow * RS + hl;
+                    sse_w = lane_get(sse_t, wl);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) delta_w[q] = lane_get(delta[q], wl);
+                    src_off = (wrow - myrow) * (int)L.stride;
                 }
-                if (assemble) {
-                    form_normal();
-                    stamp(GH_FORM);
-                    // top of the next outer iteration (lm.rs:108-112)
-                    if (fresh && (!(sse == sse) || !(sse < Lim<T>::huge()))) {
+            }
+            bool assemble = false, fin = false;
+            if (fresh) {  // the component's start point
+                sse = sse_t;
+                sse_start = sse_t;
+                assemble = true;
+            } else {
+                for (int k = 0; k < kw; ++k) lambda *= o.reject_factor;  // the plain rejects in front (lm.rs:189)
+                if (kw == lad_width) {
+                    trials += (uint32_t)kw;  // nothing but plain rejects: on with the next lambdas
+                } else {
+                    trials += (uint32_t)kw + (code_w != LC_CAP ? 1u : 0u);
+                    if (code_w == LC_CAP) {
+                        exit_code = FX_EXIT_TRIAL_CAP;
+                        fin = true;
+                    } else if (code_w == LC_SINGULAR) {  // lm.rs:134-137
+                        lambda *= o.singular_factor;
+                    } else if (code_w == LC_NAN) {
                         exit_code = FX_EXIT_NAN;
-                        phase = GP_FINISH;
-                    } else if (outer >= o.max_outer) {
-                        phase = GP_FINISH;  // exit_code is still FX_EXIT_MAX_OUTER
-                    } else if (sse < (T)o.sse_tol) {
-                        exit_code = FX_EXIT_SSE;
-                        phase = GP_FINISH;
+                        fin = true;
+                    } else if (code_w == LC_STEP) {  // lm.rs:139-142
+                        exit_code = FX_EXIT_STEP;
+                        fin = true;
+                    } else if (code_w == LC_ACCEPT) {  // lm.rs:151-186
+                        lambda *= o.accept_factor;
+                        if (lambda < o.lambda_min) lambda = o.lambda_min;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q)
+                            if ((uint32_t)(hl + RS * q) < nfree) xc[q] = xc[q] + delta_w[q];
+                        accepted += 1;
+                        const T rel = (sse - sse_w) / sse;
+                        sse = sse_w;  // the returned point's SSE (the reference leaves it stale, quirk Q9)
+                        if (rel <= (T)o.ftol) {
+                            exit_code = FX_EXIT_FTOL;
+                            fin = true;
+                        } else {
+                            assemble = true;
+                            outer += 1;
+                        }
+                    } else {  // a reject that ends the solve
+                        lambda *= o.reject_factor;
+                        exit_code = (code_w == LC_REJ_NAN) ? FX_EXIT_NAN : FX_EXIT_FTOL;
+                        fin = true;
                     }
                 }
-                fresh = false;
+            }
+            if (assemble) {
+                form_normal();
+                stamp(GH_FORM);
+                // top of the next outer iteration (lm.rs:108-112)
+                if (fresh && (!(sse == sse) || !(sse < Lim<T>::huge()))) {
+                    exit_code = FX_EXIT_NAN;
+                    fin = true;
+                } else if (outer >= o.max_outer) {
+                    fin = true;  // exit_code is still FX_EXIT_MAX_OUTER
+                } else if (sse < (T)o.sse_tol) {
+                    exit_code = FX_EXIT_SSE;
+                    fin = true;
+                }
+            }
+            fresh = false;
+            if (fin) {
+                phase = GP_FINISH;
+                if constexpr (LADDER) {
+                    if (lad_rank > 0) {  // a helper goes back to being an idle row; the leader writes the System back
+                        phase = GP_EXIT;
+                        P = reinterpret_cast<T*>(base + L.off_p);
+                        gvar = reinterpret_cast<uint16_t*>(base + L.off_gvar);
+                        rtag = reinterpret_cast<uint8_t*>(base + L.off_rtag);
+                        PW = reinterpret_cast<uint32_t*>(base + L.off_pw);
+                        PE = reinterpret_cast<uint16_t*>(base + L.off_pe);
+                    }
+                    lad_rank = 0;
+                    lad_width = 1;
+                    lad_lead = myrow;
+                    lad_members = (uint32_t)myrow * 0x55u;
+                }
             }
         }
 
@@ -1140,7 +1376,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 stamp(GH_SETUP);
         }
 
-        if (__ballot(phase != GP_EXIT) == 0ull) break;
+        // (a row that went idle for a straggler's sake has not seen the end of the queue: it is sent back to it above)
+        if (__ballot(phase != GP_EXIT || (LADDER && prm.ladder && !qdone)) == 0ull) break;
     }
     if (PROF) {
         stamp(GH_TAIL);
@@ -1190,10 +1427,22 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     uint32_t waves = (b.n_systems + groups - 1u) / groups;
     const uint32_t cap = 256u * 16u;
     if (waves > cap) waves = cap;
+    // the wavefronts that are resident at once draw the first tickets: with a schedule (longest first) those are dealt
+    // one per wavefront — the likely stragglers then sit in different wavefronts, whose other rows can help them
+    LmParams pl = p;
+    pl.spread = 0u;
+    if (b.order && p.ladder && p.spread) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t by_lds = (160u * 1024u) / (per_wave ? per_wave : 1u), by_simd = one_wave ? 4u : 8u;
+        uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
+        if (resident > waves) resident = waves;
+        pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
+    }
     if constexpr (one_wave) {
-        hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, pl, L, counter);
     } else {
-        hipLaunchKernelGGL((lm_solve_grouped_kernel_w2<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, p, L, counter);
+        hipLaunchKernelGGL((lm_solve_grouped_kernel_w2<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, pl, L, counter);
     }
     return hipGetLastError();
 }

@@ -225,6 +225,17 @@ int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
  * second row to finish, so that the two take their next Systems side by side — the hand-over blocks cost the wavefront
  * the same for one row as for four. 0: never wait. Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
+/* Grouped kernel, the lambda ladder. The trials that follow a rejected trial of the reference's loop (lm.rs:187-190) read
+ * the same point, Jacobian and residuals and differ in lambda only (x 2 each), so a row of a wavefront that has no System
+ * of its own tries the next lambda of a System that is still running in its wavefront, in the same pass: up to four
+ * lambdas side by side. The verdicts are read in the loop's order and the first one that is not a plain reject decides, as it
+ * would have in the sequential loop; `trials` counts what that loop would have counted. enable = 0: off. Rows help once
+ * the queue of Systems is empty; with tail_systems > 0 a wavefront that holds a System past min_trials trials also stops
+ * taking new Systems when at most tail_systems are left in the queue (its rows go over to the straggler as they finish).
+ * spread != 0: with a scheduled hand-out (presort, fx_batch_schedule_by_last_solve) the first round of Systems is dealt one
+ * per wavefront instead of four, so that the likely stragglers do not share a wavefront. Defaults: on, 0, 16, on.
+ * Scheduling only: every System's result is the same bits either way (tests/test_gpu_grouped.py). */
+int fx_ctx_set_ladder(fx_ctx* ctx, int enable, uint32_t tail_systems, uint32_t min_trials, int spread);
 /* Where components of 65 ... 128 free variables are solved: 1 = the wide kernel (one wavefront per System, dense factor in LDS:
  * the faster one for thousands of them), 0 = the team kernels (a workgroup per System, sparse factor: half the latency of
  * one solve, and faster at any count from ~112 columns on), -1 (default) = by the measured cost of either for the batch at

@@ -397,3 +397,72 @@ def test_holding_a_finished_row_changes_the_order_not_the_results(fiksi, ctx):
         for other in out[1:]:
             assert np.array_equal(_bits(out[0][0]), _bits(other[0]))
             assert out[0][1].tobytes() == other[1].tobytes()
+
+
+def _ladder_variants():
+    # (enable, tail_systems, min_trials, spread)
+    return [(False, 0, 16, False), (True, 0, 16, False), (True, 0, 16, True), (True, 4096, 8, True), (True, 1 << 30, 0, True)]
+
+
+def test_the_lambda_ladder_changes_the_order_not_the_results(fiksi, ctx, routing):
+    """fx_ctx_set_ladder: rows of a wavefront without a System of their own try lambda x 2, x 4, x 8 of a System that is still
+    running beside its own lambda; the first verdict in the loop's order that is not a plain reject decides (lm.rs:114-190).
+    Every variable, `accepted`, `trials`, `exit` and SSE of every System is the same bits with the ladder off, with rows
+    helping at the end of the queue, with wavefronts leaving the queue early for a straggler, and with a straggler threshold
+    of zero and no end to the tail (every wavefront becomes one ladder as soon as any of its rows runs): uniform batches,
+    f32 (its stagnation exit is one of the verdicts), inconsistent targets, mixed structures with several components,
+    SinglePass blocks, the trial cap."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import mixed_sketch, random_sketch
+
+    routing("1")
+    mixed = workloads.concat([workloads.ring16(1500), workloads.concat([random_sketch(s).flatten() for s in range(300)]),
+                              workloads.concat([mixed_sketch(s, fix_some=bool(s & 1)).flatten() for s in range(100)]),
+                              workloads.hinged_triangles(1000, 4)])
+    cases = [(workloads.ring16(12500), {}), (workloads.ring16(4099, fix_gauge=True), {}),
+             (workloads.ring16(9000, inconsistent=True), {"f32": True}), (workloads.ring16(5000, inconsistent=True), {}),
+             (mixed, {}), (workloads.hinged_triangles(3000, 5), {"decomposer": 1}), (workloads.ring16(3000), {"decomposer": 1}),
+             (workloads.ring16(3000), {"max_trials": 21}), (workloads.hinged_triangles(2000, 3), {})]
+    try:
+        for b, kw in cases:
+            o = abi.solving_opts(**kw)
+            out = []
+            for en, tail, k, spread in _ladder_variants():
+                ctx.set_ladder(en, tail, k, spread)
+                out.append(ctx.system_solve_batch(b, o))
+            for other in out[1:]:
+                assert np.array_equal(_bits(out[0][0]), _bits(other[0]))
+                assert out[0][1].tobytes() == other[1].tobytes()
+            if "max_trials" in kw:
+                assert int(out[0][1]["trials"].max()) == 21
+    finally:
+        ctx.set_ladder()
+
+
+def test_the_ladder_on_the_slowest_systems_of_a_shard(fiksi, oracle, ctx, routing):
+    """The 192 Systems of a 12 500-System shard that take the most trials (34 ... 97), as a batch of their own: 48 wavefronts
+    of four stragglers each, so every ladder that forms is a partial one (two rows, then three, then four as the
+    neighbours finish). Same bits as the sequential loop, and the oracle's counters."""
+    from fiksi_amd import workloads
+
+    full = workloads.ring16(12500)
+    routing("1")
+    ctx.set_ladder(False)
+    try:
+        _, r = ctx.system_solve_batch(full)
+        slow = np.argsort(-r["trials"].astype(np.int64), kind="stable")[:192]
+        sb = workloads.concat([workloads.shard(full, int(s), 12500) for s in slow])
+        v0, r0 = ctx.system_solve_batch(sb)
+        assert np.array_equal(r0["trials"], r["trials"][slow]) and int(r0["trials"].min()) >= 30
+        for variant in _ladder_variants()[1:]:
+            ctx.set_ladder(*variant)
+            v1, r1 = ctx.system_solve_batch(sb)
+            assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
+        sub = workloads.shard(sb, 0, 8)
+        n = len(sub["var_off"]) - 1
+        _, res_o = oracle.solve_batch(sub, mode=3, nthreads=8)
+        same = (r0["accepted"][:n] == res_o["accepted"]) & (r0["trials"][:n] == res_o["trials"])
+        assert same.mean() >= 0.9  # the normal-equation step against the oracle's QR step (DESIGN section 5)
+    finally:
+        ctx.set_ladder()
