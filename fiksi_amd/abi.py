@@ -203,10 +203,10 @@ class Context:
         """Most-work-first hand-out of big batches from a scout pass (fx_ctx_set_presort); results unchanged."""
         check(lib.fx_ctx_set_presort(self._h, 1 if enable else 0, min_systems), "fx_ctx_set_presort")
 
-    def set_ladder(self, enable: bool = True, tail_systems: int = 0, min_trials: int = 16, spread: bool = True):
+    def set_ladder(self, enable: bool = True, tail_systems: int = 0xFFFFFFFF, min_trials: int = 8, spread: bool = True):
         """Grouped kernel: idle rows of a wavefront try the next lambdas of a running System side by side
         (fx_ctx_set_ladder); results unchanged."""
-        check(lib.fx_ctx_set_ladder(self._h, 1 if enable else 0, tail_systems, min_trials, 1 if spread else 0), "fx_ctx_set_ladder")
+        check(lib.fx_ctx_set_ladder(self._h, 1 if enable else 0, tail_systems, min_trials, int(spread)), "fx_ctx_set_ladder")
 
     def set_hold_passes(self, passes: int = 2):
         """Grouped kernel: passes a finished row waits for a second one (fx_ctx_set_hold_passes); results unchanged."""

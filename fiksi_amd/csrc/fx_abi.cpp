@@ -667,7 +667,7 @@ struct fx_ctx {
     uint32_t grouped_min_systems = 1024u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
-    uint32_t ladder = 1u, ladder_k = 16u, ladder_tail = 0u, ladder_spread = 1u;  // fx_ctx_set_ladder
+    uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, ladder_spread = 1u;  // fx_ctx_set_ladder
     int wide_routing = -1;                 // fx_ctx_set_wide_routing
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: groups of large Systems (one structure each) solved side by side
     std::vector<hipStream_t> worker_streams;  // ... a stream per extra host thread

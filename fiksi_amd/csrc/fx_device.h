@@ -136,9 +136,9 @@ struct LmParams {
     // grouped kernel, the lambda ladder (fx_ctx_set_ladder): rows without a System of their own try the next lambdas of a
     // running System of their wavefront side by side. ladder_tail / ladder_k: with at most ladder_tail Systems left in the
     // queue, a wavefront that holds a System past ladder_k trials takes no further Systems (0: rows only help once the
-    // queue is empty). spread: the first 4 * spread tickets of a scheduled hand-out are dealt one per wavefront (set by the
-    // launcher).
-    uint32_t ladder = 1u, ladder_k = 16u, ladder_tail = 0u, spread = 0u;
+    // queue is empty; 0xFFFFFFFF: the launcher's default, eight Systems per resident row). spread: nonzero = the first round
+    // of tickets of a scheduled hand-out is dealt one per wavefront (the launcher puts the number of wavefronts there).
+    uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, spread = 1u;
 };
 
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.

@@ -32,6 +32,10 @@
 #include "fx_expr.h"
 #include "fx_wave.h"
 
+#ifndef FX_GROUPED_LADDER
+#define FX_GROUPED_LADDER 1  // 0: a build without the lambda ladder (A/B measurements, tools/ab_build.sh)
+#endif
+
 namespace fx {
 
 constexpr int RS = 16;  // lanes per System: one DPP row
@@ -344,8 +348,6 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     T* rhsv = reinterpret_cast<T*>(base + L.off_rhs);    // [N] -Jt r
     T* G = reinterpret_cast<T*>(base + L.off_g);         // [mr][8] Jacobian rows of the last evaluated point
     T* R = reinterpret_cast<T*>(base + L.off_r);         // [mr]
-    // (the next five are read-only while a component is solved; a row that helps another row's System on the lambda
-    // ladder reads that row's copies)
     T* P = reinterpret_cast<T*>(base + L.off_p);         // [mr] scaled parameters
     uint16_t* gvar = reinterpret_cast<uint16_t*>(base + L.off_gvar);  // [mr][8]
     uint8_t* rtag = reinterpret_cast<uint8_t*>(base + L.off_rtag);    // [mr]
@@ -391,11 +393,11 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     // the same pass. The verdicts are read in rank order and the first that is not a plain reject decides for the whole
     // group exactly as it would have decided in the sequential loop; `trials` advances by the trials the sequential loop
     // would have made up to it. Every row of a group holds the same LM state at the top of every pass.
-    constexpr bool LADDER = (NC <= 2) && !PROF;
+    constexpr bool LADDER = (NC <= 2) && !PROF && FX_GROUPED_LADDER;
     const int myrow = lane / RS;
     int lad_rank = 0, lad_width = 1, lad_lead = myrow;
     uint32_t lad_members = (uint32_t)myrow * 0x55u;  // row of rank k at bits 2k, 2k + 1
-    int src_off = 0;      // bytes from this row's Jacobian rows / residuals to those of the row whose trial was accepted
+    int win_row = myrow;  // the row whose trial decided this pass (its Jacobian rows are the accepted point's)
     bool qdone = false;   // this row has seen the end of the queue
     uint32_t last_tk = 0; // the last ticket this row drew
     // The product list of a component does not change between its assemblies: the 32-column f64 build (one wavefront
@@ -490,9 +492,6 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
     // K3: the lower triangle of Jt J and -Jt r from the packed lists (ds_add_f64 / ds_add_f32)
     auto form_normal = [&]() {
-        // the rows of the accepted point: this row's own, or (ladder) those of the row whose trial was accepted
-        const T* G = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base + L.off_g) + src_off);
-        const T* R = reinterpret_cast<const T*>(reinterpret_cast<const unsigned char*>(base + L.off_r) + src_off);
         {  // zero the triangle, 16 bytes per lane and instruction
             using V = typename Vec16<T>::type;
             constexpr uint32_t NV = (uint32_t)(N * (N + 1) / 2) / (uint32_t)Vec16<T>::n;
@@ -596,11 +595,11 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
         // straggler a row that went idle that way goes back to the queue.
         bool park = false;
         if constexpr (LADDER) {
-            if (prm.ladder) {
+            if (prm.ladder && prm.ladder_tail != 0u) {
                 const bool straggler =
                     __ballot(phase == GP_RUN && lad_rank == 0 && !fresh && trials >= prm.ladder_k) != 0ull;
                 if (phase == GP_EXIT && !qdone && !straggler) phase = GP_NEXT;
-                park = straggler && prm.ladder_tail != 0u && last_tk < b.n_systems && b.n_systems - last_tk <= prm.ladder_tail;
+                park = straggler && last_tk < b.n_systems && b.n_systems - last_tk <= prm.ladder_tail;
             }
         }
         // ================= NEXT: take a System, scale it, snapshot its variables =================
@@ -1035,20 +1034,12 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             lad_lead = (int)nl;
                             lad_rank = (int)((newrank >> (4 * myrow)) & 15u);
                             built = false;  // this row's lists in registers are the leader's now
-                            unsigned char* lb = smem + (uint32_t)nl * L.stride;
-                            P = reinterpret_cast<T*>(lb + L.off_p);
-                            gvar = reinterpret_cast<uint16_t*>(lb + L.off_gvar);
-                            rtag = reinterpret_cast<uint8_t*>(lb + L.off_rtag);
-                            PW = reinterpret_cast<uint32_t*>(lb + L.off_pw);
-                            PE = reinterpret_cast<uint16_t*>(lb + L.off_pe);
-                            // its working variables (the fixed ones and other components' are read by the rows) and the
-                            // triangle of Jt J as last assembled (every row writes its own diagonal per trial)
-                            const T* lxs = reinterpret_cast<const T*>(lb + L.off_xs);
-                            for (uint32_t i = hl; i < L.vt; i += RS) XS[i] = lxs[i];
+                            // ... and its LDS block: working variables, the triangle of Jt J as last assembled (every row
+                            // writes its own diagonal per trial), right-hand side, row lists, parameters, product lists
                             using V = typename Vec16<T>::type;
-                            constexpr uint32_t NV = (uint32_t)(N * (N + 1) / 2) / (uint32_t)Vec16<T>::n;
-                            const V* lat = reinterpret_cast<const V*>(lb + L.off_a);
-                            for (uint32_t i = hl; i < NV; i += RS) reinterpret_cast<V*>(At)[i] = lat[i];
+                            const V* lb = reinterpret_cast<const V*>(smem + (uint32_t)nl * L.stride);
+                            V* mine = reinterpret_cast<V*>(base);
+                            for (uint32_t i = hl; i < L.stride / 16u; i += RS) mine[i] = lb[i];
                             fresh = false;
                             phase = GP_RUN;
                         }
@@ -1081,7 +1072,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 // this row's lambda: the group's, after `rank` plain rejects
                 double lam_k = lambda;
                 if constexpr (LADDER) {
-                    for (int k = 0; k < lad_rank; ++k) lam_k *= o.reject_factor;
+                    if (lad_rank > 0)
+                        for (int k = 0; k < lad_rank; ++k) lam_k *= o.reject_factor;
                 }
                 if (trials + (uint32_t)lad_rank >= o.max_trials) {
                     code = LC_CAP;
@@ -1170,8 +1162,11 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     if (sse_t < sse) {
                         code = LC_ACCEPT;  // lm.rs:151-186
                     } else {               // lm.rs:187-190
-                        double lam_k = lambda;
-                        for (int k = 0; k <= lad_rank; ++k) lam_k *= o.reject_factor;
+                        double lam_k = lambda * o.reject_factor;
+                        if constexpr (LADDER) {
+                            if (lad_rank > 0)
+                                for (int k = 0; k < lad_rank; ++k) lam_k *= o.reject_factor;
+                        }
                         if (!(sse_t == sse_t) && !(lam_k < 1.0e300)) {
                             code = LC_REJ_NAN;  // NaN trial point: the reference would double lambda forever
                         } else if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) {
@@ -1192,7 +1187,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             T delta_w[NC];
 #pragma unroll
             for (int q = 0; q < NC; ++q) delta_w[q] = delta[q];
-            src_off = 0;
+            win_row = myrow;
             if constexpr (LADDER) {
                 if (__ballot(lad_width > 1) != 0ull) {
                     int ck[4];
@@ -1212,7 +1207,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     sse_w = lane_get(sse_t, wl);
 #pragma unroll
                     for (int q = 0; q < NC; ++q) delta_w[q] = lane_get(delta[q], wl);
-                    src_off = (wrow - myrow) * (int)L.stride;
+                    win_row = wrow;
                 }
             }
             bool assemble = false, fin = false;
@@ -1221,7 +1216,11 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 sse_start = sse_t;
                 assemble = true;
             } else {
-                for (int k = 0; k < kw; ++k) lambda *= o.reject_factor;  // the plain rejects in front (lm.rs:189)
+                if (kw > 0) {  // the plain rejects in front (lm.rs:189)
+                    lambda *= o.reject_factor;
+                    if constexpr (LADDER)
+                        for (int k = 1; k < kw; ++k) lambda *= o.reject_factor;
+                }
                 if (kw == lad_width) {
                     trials += (uint32_t)kw;  // nothing but plain rejects: on with the next lambdas
                 } else {
@@ -1261,6 +1260,19 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 }
             }
             if (assemble) {
+                if constexpr (LADDER) {
+                    if (win_row != myrow) {  // the accepted point's Jacobian rows and residuals are another row's
+                        using V = typename Vec16<T>::type;
+                        const unsigned char* wb = smem + (uint32_t)win_row * L.stride;
+                        const V* gs = reinterpret_cast<const V*>(wb + L.off_g);
+                        V* gd = reinterpret_cast<V*>(G);
+                        const uint32_t ng = m_rows * 8u / (uint32_t)Vec16<T>::n;
+                        for (uint32_t i = hl; i < ng; i += RS) gd[i] = gs[i];
+                        const T* rs = reinterpret_cast<const T*>(wb + L.off_r);
+                        for (uint32_t i = hl; i < m_rows; i += RS) R[i] = rs[i];
+                        group_sync();
+                    }
+                }
                 form_normal();
                 stamp(GH_FORM);
                 // top of the next outer iteration (lm.rs:108-112)
@@ -1280,11 +1292,6 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 if constexpr (LADDER) {
                     if (lad_rank > 0) {  // a helper goes back to being an idle row; the leader writes the System back
                         phase = GP_EXIT;
-                        P = reinterpret_cast<T*>(base + L.off_p);
-                        gvar = reinterpret_cast<uint16_t*>(base + L.off_gvar);
-                        rtag = reinterpret_cast<uint8_t*>(base + L.off_rtag);
-                        PW = reinterpret_cast<uint32_t*>(base + L.off_pw);
-                        PE = reinterpret_cast<uint16_t*>(base + L.off_pe);
                     }
                     lad_rank = 0;
                     lad_width = 1;
@@ -1431,13 +1438,15 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     // one per wavefront — the likely stragglers then sit in different wavefronts, whose other rows can help them
     LmParams pl = p;
     pl.spread = 0u;
-    if (b.order && p.ladder && p.spread) {
+    if (p.ladder) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t by_lds = (160u * 1024u) / (per_wave ? per_wave : 1u), by_simd = one_wave ? 4u : 8u;
         uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
         if (resident > waves) resident = waves;
-        pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
+        if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
+        // the default tail: eight Systems per resident row (measured on ring16 shards of 12 500 ... 100 000, tools/ladder_probe.py)
+        if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
     }
     if constexpr (one_wave) {
         hipLaunchKernelGGL((lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>), dim3(waves), dim3(64), per_wave, stream, b, pl, L, counter);

@@ -1,12 +1,16 @@
 // Longest-first hand-out for the grouped kernel (fx_grouped.hip) without any history: a scout pass computes, per System,
 // the sum of squared residuals at the start values over the mean square of its variables — on the headline batch the
 // logarithm of that number correlates 0.89 with the number of LM trials the System is going to take, and 93 % of the
-// Systems that take more than 20 trials lie in its top quarter — and a radix sort turns it into the order in which
-// rows take Systems from the queue. A batch is as slow as its slowest System plus the time before that System was
-// started; the order changes WHEN a System is solved, never its result (Systems are independent).
-// Nothing here needs to be exact: the key is a float, summed in whatever order is fastest.
+// Systems that take more than 20 trials lie in its top quarter — and the Systems are handed out in (nearly) descending
+// order of it. A batch is as slow as its slowest System plus the time before that System was started; the order changes
+// WHEN a System is solved, never its result (Systems are independent).
+// Nothing here needs to be exact, so there is no global sort (round 3: a library radix sort, eleven launches and 0.1 ms per
+// solve — a tenth of a 12 500-System shard's time): the Systems are dealt into chunks of at most 512 with a stride
+// (chunk c holds Systems c, c + nc, c + 2 nc, ...: every chunk is a sample of the whole batch), each chunk is ranked by
+// one workgroup in LDS, and position p of the order is entry p / nc of chunk p mod nc — the k-th largest keys of all
+// chunks side by side. Two launches, no atomics (a histogram over the keys was tried first: 100 000 atomics on the ~60
+// buckets the headline batch's keys fall into took 133 us).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
 #include "fx_device.h"
@@ -14,6 +18,11 @@
 #include "fx_wave.h"
 
 namespace fx {
+
+#ifndef FX_PS_CHUNK
+#define FX_PS_CHUNK 512
+#endif
+constexpr uint32_t PS_CHUNK = FX_PS_CHUNK;
 
 __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_move<0xB1>(v);
@@ -24,7 +33,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 
 // one row of 16 lanes per System
-__global__ __launch_bounds__(256) void presort_scout_kernel(DeviceBatch b, float* __restrict__ keys, uint32_t* __restrict__ ids) {
+__global__ __launch_bounds__(256) void presort_scout_kernel(DeviceBatch b, float* __restrict__ keys) {
     const uint32_t s = (blockIdx.x * 256u + threadIdx.x) >> 4;
     const uint32_t hl = threadIdx.x & 15u;
     if (s >= b.n_systems) return;
@@ -55,25 +64,43 @@ __global__ __launch_bounds__(256) void presort_scout_kernel(DeviceBatch b, float
         double key = se / (sv / (double)(nvt ? nvt : 1u) + 1e-300);
         if (!(key == key) || key > 3.0e38) key = 3.0e38;  // non-finite residuals: first
         keys[s] = (float)key;
-        ids[s] = s;
     }
 }
 
-size_t presort_temp_bytes(uint32_t n) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, (const float*)nullptr, (float*)nullptr, (const uint32_t*)nullptr,
-                                                       (uint32_t*)nullptr, (int)n, 0, 32, (hipStream_t) nullptr);
-    return bytes;
+// workgroup c ranks chunk c (Systems c, c + nc, ...; at most 512) by descending key — every thread counts the entries
+// in front of its own, four per LDS read — and writes the entry of rank i to position i * nc + c of the order
+__global__ __launch_bounds__(PS_CHUNK) void presort_chunk_kernel(uint32_t n, uint32_t nc, const float* __restrict__ keys,
+                                                                 uint32_t* __restrict__ order) {
+    __shared__ float4 k4[PS_CHUNK / 4];
+    float* k = reinterpret_cast<float*>(k4);
+    const uint32_t t = threadIdx.x, c = blockIdx.x;
+    const uint32_t s = c + t * nc;
+    const float mine = s < n ? keys[s] : -1.0f;  // keys are >= 0: the padding ranks last
+    k[t] = mine;
+    __syncthreads();
+    uint32_t rank = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < PS_CHUNK / 4u; ++j) {
+        const float4 v = k4[j];
+        const uint32_t j0 = 4u * j;
+        rank += (v.x > mine || (v.x == mine && j0 < t)) ? 1u : 0u;
+        rank += (v.y > mine || (v.y == mine && j0 + 1u < t)) ? 1u : 0u;
+        rank += (v.z > mine || (v.z == mine && j0 + 2u < t)) ? 1u : 0u;
+        rank += (v.w > mine || (v.w == mine && j0 + 3u < t)) ? 1u : 0u;
+    }
+    if (s < n) order[rank * nc + c] = s;
 }
 
-// keys / ids: [2][n] each (in, out); on return ids + n holds the order
-hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void* temp, size_t temp_bytes, hipStream_t stream) {
+size_t presort_temp_bytes(uint32_t) { return 16; }
+
+// keys: [n] floats; ids: [2][n], on return ids + n holds the order
+hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void*, size_t, hipStream_t stream) {
     const uint32_t n = b.n_systems;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(presort_scout_kernel, dim3((n * 16u + 255u) / 256u), dim3(256), 0, stream, b, keys, ids);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return hipcub::DeviceRadixSort::SortPairsDescending(temp, temp_bytes, keys, keys + n, ids, ids + n, (int)n, 0, 32, stream);
+    const uint32_t nc = (n + PS_CHUNK - 1u) / PS_CHUNK;
+    hipLaunchKernelGGL(presort_scout_kernel, dim3((n * 16u + 255u) / 256u), dim3(256), 0, stream, b, keys);
+    hipLaunchKernelGGL(presort_chunk_kernel, dim3(nc), dim3(PS_CHUNK), 0, stream, n, nc, keys, ids + n);
+    return hipGetLastError();
 }
 
 }  // namespace fx

@@ -120,11 +120,34 @@ RING16_NNZ = 24 * 4 + 8 * 6  # 144
 RING16_K1_BYTES = 8 * 32 + 28 * 32 + 8 * 32 + 8 * RING16_NNZ  # 2560
 
 
-def k1_algorithmic_bytes(batch: Dict[str, np.ndarray], nnz: int) -> int:
-    """SURVEY.md §8d formula for any batch: 8*n_vars + 28*n_exprs + 8*n_exprs + 8*nnz."""
+def k1_algorithmic_bytes(batch: Dict[str, np.ndarray], nnz: int, one_structure: bool = False) -> int:
+    """Bytes one Jacobian-assembly pass (K1) has to move. SURVEY.md §8d's formula for any batch:
+    8*n_vars + 28*n_exprs (tag 4 + fields 16 + parameter 8) + 8*n_exprs + 8*nnz — 2560 B per ring16 System.
+    ``one_structure``: a batch whose Systems all share one structure (one sketch, many parameter sets) reads kinds and
+    fields from its first System only (fx_eval.hip), so per row only the 8-byte parameter is left of the 28:
+    8*n_vars + 8*n_exprs + 8*n_exprs + 8*nnz — 1920 B per ring16 System. That is the figure the counters confirm
+    (1936 B per System, profiles/round3_pmc_traffic_500k.json) and the one a roofline fraction may be quoted on."""
     nv = int(batch["var_off"][-1])
     ne = int(batch["expr_off"][-1])
-    return 8 * nv + 28 * ne + 8 * ne + 8 * int(nnz)
+    per_row = 8 if one_structure else 28
+    return 8 * nv + per_row * ne + 8 * ne + 8 * int(nnz)
+
+
+def ring16_two_structures(n_systems: int, seed0: int = 1000) -> Dict[str, np.ndarray]:
+    """cfg3 sketches of two structures, interleaved: every odd System lists its first ring distance and its last angle in
+    each other's place (rows 0 and 31 swapped, parameters with them). Same geometry, same solution, same Jacobian
+    non-zeros — but no longer ONE structure: the batch takes the paths that stream every System's structure."""
+    b = ring16(n_systems, seed0=seed0)
+    n, m = int(n_systems), 32
+    tag = b["expr_tag"].reshape(n, m)
+    idx = b["expr_idx"].reshape(n, m, 4)
+    par = b["expr_param"].reshape(n, m)
+    odd = np.arange(n) % 2 == 1
+    for arr in (tag, idx, par):
+        tmp = arr[odd, 0].copy()
+        arr[odd, 0] = arr[odd, 31]
+        arr[odd, 31] = tmp
+    return b
 
 
 def hinged_triangles(n_systems: int, n_triangles: int = 11) -> Dict[str, np.ndarray]:

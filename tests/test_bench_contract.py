@@ -27,5 +27,12 @@ def test_bench_json_contract(built):
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    # the fraction is quoted on bytes that move: it cannot exceed what a streaming copy reaches on this part, and it agrees
+    # with the counters' bytes over the same time
+    assert r["frac_of_streaming_copy_rate"] <= 1.0
+    assert r["algorithmic_bytes_per_system"] == 1920 and r["by_survey_8d_bytes"]["bytes_per_system"] == 2560
+    if r["traffic"] is not None:
+        assert abs(r["frac"] - r["frac_by_counter_bytes"]) <= 0.05 * r["frac_by_counter_bytes"]
+    assert r["mixed_structure"]["algorithmic_bytes_per_system"] == 2560 and r["mixed_structure"]["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): the rocprofv3 passes whose summaries are committed under profiles/.
-#   tools/collect_profiles.sh <tag>        e.g. round3
+#   tools/collect_profiles.sh <tag>        e.g. round4
 # One workload per run, so that every row of a summary is one workload (round 2's bench CSV mixed batch sizes).
 # Kernel timing and the PMC counters are separate runs (never --pmc together with other trace domains); the program
 # itself follows `--` (no env / bash -c hop).
 set -e
-TAG=${1:-round3}
+TAG=${1:-round4}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -16,8 +16,12 @@ stats() {  # stats <name> <program args...>: kernel-trace + stats of one workloa
     cp $(find $OUT/$name -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_$name.csv
 }
 echo "[collect] K1 alone, 100k and 500k Systems"
-stats k1_100k python3 tools/k1_once.py 100000 20
-stats k1_500k python3 tools/k1_once.py 500000 12
+stats k1_100k python3 tools/k1_once.py 100000 51
+stats k1_500k python3 tools/k1_once.py 500000 51
+stats k1_500k_mixed python3 tools/k1_once.py 500000 51 mixed
+# (the --stats average holds the cold first launch: the per-dispatch summary reports it apart)
+python3 tools/k1_trace_summary.py $OUT/k1_500k "eval_rows_kernel<true" $OUT/${TAG}_k1_500k_launches.json > /dev/null
+python3 tools/k1_trace_summary.py $OUT/k1_500k_mixed "eval_rows_kernel<true" $OUT/${TAG}_k1_500k_mixed_launches.json > /dev/null
 echo "[collect] the headline: 100k ring16 solves only"
 stats headline_kernel_stats python3 tools/solve_only.py 100000 10
 echo "[collect] cfg2 resident, the reference's 64-triangle sketch x 256"
@@ -30,6 +34,9 @@ python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traff
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch5 -- python3 tools/k1_once.py 500000 3 > $OUT/pmc_fetch5.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write5 -- python3 tools/k1_once.py 500000 3 > $OUT/pmc_write5.log 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_fetch5 $OUT/pmc_write5 $OUT/${TAG}_pmc_traffic_500k.json 500000 > /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch5m -- python3 tools/k1_once.py 500000 3 mixed > $OUT/pmc_fetch5m.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write5m -- python3 tools/k1_once.py 500000 3 mixed > $OUT/pmc_write5m.log 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_fetch5m $OUT/pmc_write5m $OUT/${TAG}_pmc_traffic_500k_mixed.json 500000 > /dev/null
 echo "[collect] SQ counters of the solve kernels"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 tools/solve_only.py 100000 2 > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/${TAG}_pmc_sq.json 100000 "tools/solve_only.py 100000 2" > /dev/null
@@ -45,9 +52,11 @@ FIKSI_AMD_HOST_CHUNKS=0 python3 tools/host_path.py 100000 9 > $OUT/hp_plain.json
 python3 -c "import json; a=json.loads(open('$OUT/hp_chunked.json').read().strip().splitlines()[-1]); b=json.loads(open('$OUT/hp_plain.json').read().strip().splitlines()[-1]); json.dump({'source': 'tools/host_path.py 100000 9; FIKSI_AMD_HOST_CHUNKS=0 for the uncut call', 'two_chunks': a, 'uncut': b}, open('$OUT/${TAG}_host_path.json','w'), indent=1)"
 python3 tools/ra_batch.py 10000 7 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_recursive_assembly_batch.json
 python3 tools/straggler_probe.py 12500 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_straggler_probe.json
+python3 tools/shard_times.py 100000 off:0 default 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_cfg4_shard_times.json
+python3 tools/ladder_probe.py 100000 full 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_ladder_probe.json
 tools/probes/rw_mix_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_hbm_rw_mix.json
 tools/probes/valu_cost_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_valu_cost.json
 echo "[collect] plain bench line (it quotes the counter files: this run's go to profiles/ first)"
-cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic_500k.json $OUT/${TAG}_pmc_sq.json $ROOT/profiles/
+cp $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_traffic_500k.json $OUT/${TAG}_pmc_traffic_500k_mixed.json $OUT/${TAG}_pmc_sq.json $ROOT/profiles/
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/${TAG}_bench.json

@@ -2,7 +2,7 @@
 time per solve with the ladder off / on (rows help once the queue is empty) / on with a wavefront that holds a straggler
 leaving the queue early, the first round of tickets dealt one per wavefront or not — and that every variant returns the
 bits of the ladder-free solve.
-    python3 tools/ladder_probe.py [n_systems] [quick]
+    python3 tools/ladder_probe.py [n_systems] [quick|full] [tail:k,tail:k,...]
 Prints one JSON line."""
 import json
 import sys
@@ -27,13 +27,17 @@ def timed(ctx, db, reps=7):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
-    quick = len(sys.argv) > 2
+    quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
     ctx = abi.Context(0)
     full = workloads.ring16(n)
     variants = [("off", dict(enable=False)),
                 ("tail_only_no_spread", dict(enable=True, tail_systems=0, spread=False)),
                 ("tail_only", dict(enable=True, tail_systems=0, spread=True))]
-    if not quick:
+    if len(sys.argv) > 3:  # "tail:k,tail:k,..."
+        for tk in sys.argv[3].split(","):
+            tail, k, sp = (int(x) for x in (tk + ":1").split(":")[:3])
+            variants.append(("park_tail%d_k%d_s%d" % (tail, k, sp), dict(enable=True, tail_systems=tail, min_trials=k, spread=sp)))
+    elif not quick:
         for tail in (2048, 4096, 8192, 16384):
             for k in (8, 16, 24):
                 variants.append(("park_tail%d_k%d" % (tail, k), dict(enable=True, tail_systems=tail, min_trials=k, spread=True)))
