@@ -34,6 +34,8 @@ thread_local std::string g_last_error;
 thread_local bool g_allow_pose = false;
 // fx_ctx_set_wide_routing of the context the running call belongs to (-1 by cost, 0 team kernels, 1 wide kernel)
 thread_local int g_wide_routing = -1;
+// fx_system_solve_batch_multi: the choice made once on the whole batch, for every shard (-2: none)
+thread_local int g_wide_routing_pinned = -2;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -95,6 +97,7 @@ struct HostPlan {
     uint32_t n_large = 0;            // Systems with sys_large != 0
     std::vector<uint32_t> wide_list;
     uint32_t w_max_free = 0, w_max_vars = 0, w_max_rows = 0;
+    int wide_decision = -1;  // the batch holds components of 65 ... 128 columns and they go to: 0 the team kernels, 1 the wide kernel
     RawVec<uint16_t> var_info;
     RawVec<uint16_t> expr_comp;
     RawVec<uint16_t> expr_idx16;
@@ -547,8 +550,9 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     // Both follow the reference's iteration path; they sum in different orders, so which one ran shows in the last bits (as it does
     // for a large System alone / among seven others): fx_ctx_set_wide_routing(ctx, 0 | 1) pins it.
     if (!p.wide_list.empty()) {
-        bool team = g_wide_routing == 0;
-        if (g_wide_routing < 0) {
+        const int routing = g_wide_routing_pinned != -2 ? g_wide_routing_pinned : g_wide_routing;
+        bool team = routing == 0;
+        if (routing < 0) {
             fx::DeviceBatch probe{};
             probe.w_max_free = p.w_max_free;
             probe.w_max_vars = p.w_max_vars;
@@ -560,6 +564,7 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             const double wide_ms = std::ceil(nw / (256. * std::max(per_cu, 1.))) * (0.37 + 0.0123 * c);
             team = team_ms < wide_ms;
         }
+        p.wide_decision = team ? 0 : 1;
         if (team) {
             for (uint32_t s : p.wide_list) p.sys_large[s] = 1;
             p.wide_list.clear();
@@ -2497,11 +2502,35 @@ int fx_system_solve_batch_multi(fx_ctx* const* ctxs, uint32_t n_ctx, const fx_ba
         local.resize(n);
         results = local.data();
     }
+    // Components of 65 ... 128 columns go to the wide kernel or to the team kernels by the cost of the batch at hand
+    // (analyze), and the two add in different orders: decided per shard, a result's last bits would depend on the number of
+    // contexts. The choice is made ONCE, on the whole batch, and pinned for every shard. (Only batches that can hold such a
+    // component — a System of more than 64 variables — pay for the extra analysis.)
+    int pinned = -2;
+    {
+        uint32_t biggest = 0;
+        for (uint32_t s = 0; s < n; ++s) biggest = std::max(biggest, batch->var_off[s + 1] - batch->var_off[s]);
+        if (biggest > 64u) {
+            int routing = ctxs[0]->wide_routing;
+            for (uint32_t r = 1; r < n_ctx; ++r)
+                if (ctxs[r]->wide_routing != routing)
+                    return fail(FX_ERR_INVALID, "contexts 0 and %u differ in fx_ctx_set_wide_routing: results would depend on the shard", r);
+            if (routing < 0) {
+                HostPlan whole;
+                g_wide_routing = -1;
+                g_wide_routing_pinned = -2;
+                rc = analyze(batch, &whole);
+                if (rc) return rc;
+                if (whole.wide_decision >= 0) pinned = whole.wide_decision;
+            }
+        }
+    }
     std::vector<int> codes(n_ctx, FX_OK);
     std::vector<std::string> messages(n_ctx);
     std::vector<std::thread> workers;
     for (uint32_t r = 0; r < n_ctx; ++r) {
         workers.emplace_back([&, r] {
+            g_wide_routing_pinned = pinned;  // (thread-local; the thread ends with the call)
             const uint32_t lo = (uint32_t)((uint64_t)n * r / n_ctx), hi = (uint32_t)((uint64_t)n * (r + 1) / n_ctx);
             if (hi == lo) return;
             const uint32_t v0 = batch->var_off[lo], e0 = batch->expr_off[lo];
@@ -2764,6 +2793,11 @@ int fx_qr_symbolic(int32_t nrows, int32_t ncols, const int32_t* colptr, const in
     for (int32_t j = 0; j < ncols; ++j)
         if (colptr[j + 1] < colptr[j]) return fail(FX_ERR_INVALID, "colptr must not decrease (column %d)", j);
     if (colptr[ncols] > 0 && !rowidx) return fail(FX_ERR_INVALID, "rowidx is NULL");
+    for (int32_t j = 0; j < ncols; ++j)
+        for (int32_t p = colptr[j]; p < colptr[j + 1]; ++p) {
+            if (rowidx[p] < 0 || rowidx[p] >= nrows) return fail(FX_ERR_INVALID, "column %d: row %d outside 0 .. %d", j, rowidx[p], nrows - 1);
+            if (p > colptr[j] && rowidx[p] <= rowidx[p - 1]) return fail(FX_ERR_INVALID, "column %d: rows must ascend strictly", j);
+        }
     fx::qr::Csc a;
     a.nrows = nrows;
     a.ncols = ncols;

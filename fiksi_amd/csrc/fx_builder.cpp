@@ -68,7 +68,7 @@ struct fxs_system {
     // graph.rs:135-147
     std::vector<int32_t> element_component;  // 1-based index into `components`, 0 = None
     std::vector<Component> components;
-    uint32_t listed = 0;  // scratch of fxs_systems_solve: the group of the current call this System already belongs to, + 1
+    uint32_t listed = 0;  // scratch of fxs_systems_solve: how often the current call has listed this System so far
 };
 
 struct fxs_flat {
@@ -767,10 +767,12 @@ int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const
         if (n && !systems) return FX_ERR_INVALID;
         for (uint32_t k = 0; k < n; ++k)
             if (!systems[k]) return FX_ERR_INVALID;
-        // (a hash of the structure finds the candidates, same_structure() decides; a System listed twice is solved once
-        // per listing: the second listing opens a group of its own)
+        // (a hash of the structure finds the candidates, same_structure() decides; a System listed several times is solved
+        // once per listing, each starting from the result before: its j-th listing joins a group of j-th listings only, so
+        // no group ever holds a System twice — and the groups run in the order they were opened)
         struct Group {
             uint64_t hash;
+            uint32_t listing;  // the group holds Systems listed for the (listing + 1)-th time
             std::vector<fxs_system*> systems;
             std::vector<uint32_t> members;
         };
@@ -782,18 +784,18 @@ int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const
             size_t at = groups.size();
             auto range = by_hash.equal_range(h);
             for (auto it = range.first; it != range.second; ++it) {
-                if (systems[k]->listed != it->second + 1u && same_structure(groups[it->second].systems[0], systems[k])) {
+                if (groups[it->second].listing == systems[k]->listed && same_structure(groups[it->second].systems[0], systems[k])) {
                     at = it->second;
                     break;
                 }
             }
             if (at == groups.size()) {
-                groups.push_back(Group{h, {}, {}});
+                groups.push_back(Group{h, systems[k]->listed, {}, {}});
                 by_hash.emplace(h, at);
             }
             groups[at].systems.push_back(systems[k]);
             groups[at].members.push_back(k);
-            systems[k]->listed = (uint32_t)at + 1u;
+            systems[k]->listed += 1u;
         }
         for (Group& g : groups) {
             std::vector<fx_result> r(g.systems.size());

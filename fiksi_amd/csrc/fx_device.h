@@ -141,6 +141,21 @@ struct LmParams {
     uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, spread = 1u;
 };
 
+#ifndef FX_HOST_ONLY
+// A kernel's dynamic-LDS limit raised to the 160 KB any layout may ask for, once per kernel and device: a set per launch with
+// the launch's own size costs a small solve microseconds, and two host threads on one device (several contexts, the sparse
+// path's workers) could interleave set(X), set(Y < X), launch(X). One slot per call site (`done`: bit d = device d).
+inline hipError_t raise_lds_limit_once(const void* fn, unsigned int* done_bits) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned int bit = 1u << (dev & 31);
+    if (__atomic_load_n(done_bits, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) __atomic_fetch_or(done_bits, bit, __ATOMIC_RELEASE);
+    return e;
+}
+#endif
+
 // Kernel launchers (fx_kernels.hip). All asynchronous on `stream`.
 hipError_t launch_solve(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian, hipStream_t stream);

@@ -1426,7 +1426,9 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     const void* fn;
     if constexpr (one_wave) fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w1<NC, T, PROF, UNITS>);
     else fn = reinterpret_cast<const void*>(&lm_solve_grouped_kernel_w2<NC, T, PROF, UNITS>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave);
+    if (per_wave > 160u * 1024u) return hipErrorInvalidValue;
+    static unsigned int raised = 0;  // (one per instantiation of this template)
+    hipError_t e = raise_lds_limit_once(fn, &raised);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -1477,7 +1479,7 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     // created): 0 keeps every batch on the one-System-per-wavefront kernel, 1 sends every batch that qualifies here
     // (tests, A/B measurements). By default a batch must be big enough to fill the chip four Systems per wavefront:
     // below that one wavefront per System finishes sooner.
-    if (p.route_grouped == 0) return false;
+    if (p.route_grouped == 0 || b.has_pose) return false;  // (cluster problems: the pose builds of the one-wavefront kernel)
     if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     const bool units = (p.mode & MODE_UNITS) != 0;

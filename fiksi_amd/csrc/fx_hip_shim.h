@@ -5,6 +5,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 
 #define __host__
 #define __device__
@@ -18,28 +20,53 @@ enum : int { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, 
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 enum : unsigned { hipStreamNonBlocking = 1 };
 struct hipDeviceProp_t {
-    char name[256];
-    char gcnArchName[256];
+    char name[128];
+    char gcnArchName[64];
 };
+// FIKSI_AMD_SHIM_FAKE_DEVICE=1 (tools/abi_fuzz.py): one make-believe device whose memory is the host heap — allocations,
+// copies and fills really happen (so the sanitizers check every upload's index arithmetic and sizes), streams and events are
+// inert, and every KERNEL launcher still answers "no device" (fx_host_only.cpp): a call runs its host analysis and its
+// uploads for real and then fails with FX_ERR_HIP where the first kernel would start.
+inline bool fx_shim_fake() {
+    static const bool on = [] { const char* e = std::getenv("FIKSI_AMD_SHIM_FAKE_DEVICE"); return e && e[0] == '1'; }();
+    return on;
+}
 inline const char* hipGetErrorString(hipError_t) { return "no HIP runtime in the host-only build"; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 0; return hipErrorNoDevice; }
-inline hipError_t hipSetDevice(int) { return hipErrorNoDevice; }
-inline hipError_t hipGetDeviceProperties(hipDeviceProp_t*, int) { return hipErrorNoDevice; }
-inline hipError_t hipMalloc(void** p, size_t) { *p = nullptr; return hipErrorNoDevice; }
-inline hipError_t hipFree(void*) { return hipSuccess; }
-inline hipError_t hipHostMalloc(void** p, size_t, unsigned) { *p = nullptr; return hipErrorNoDevice; }
-inline hipError_t hipHostFree(void*) { return hipSuccess; }
-inline hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind) { return hipErrorNoDevice; }
-inline hipError_t hipMemcpyAsync(void*, const void*, size_t, hipMemcpyKind, hipStream_t) { return hipErrorNoDevice; }
-inline hipError_t hipMemsetAsync(void*, int, size_t, hipStream_t) { return hipErrorNoDevice; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipErrorNoDevice; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t*, unsigned) { return hipErrorNoDevice; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = fx_shim_fake() ? 1 : 0; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipSetDevice(int d) { return fx_shim_fake() && d == 0 ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    if (!fx_shim_fake()) return hipErrorNoDevice;
+    std::memset(p, 0, sizeof(*p));
+    std::strcpy(p->name, "host-only shim");
+    std::strcpy(p->gcnArchName, "gfx950");
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = fx_shim_fake() ? std::malloc(n ? n : 1) : nullptr;
+    return *p ? hipSuccess : (fx_shim_fake() ? hipErrorOutOfMemory : hipErrorNoDevice);
+}
+inline hipError_t hipFree(void* p) { if (fx_shim_fake()) std::free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    if (!fx_shim_fake()) return hipErrorNoDevice;
+    if (n) std::memmove(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+    if (!fx_shim_fake()) return hipErrorNoDevice;
+    if (n) std::memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t*) { return hipErrorNoDevice; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
 constexpr unsigned hipEventDisableTiming = 2u;
-inline hipError_t hipEventCreateWithFlags(hipEvent_t*, unsigned) { return hipErrorNoDevice; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipErrorNoDevice; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipErrorNoDevice; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipErrorNoDevice; }
-inline hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t) { return hipErrorNoDevice; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }

@@ -1246,8 +1246,9 @@ hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_va
     if (b.n_systems == 0) return hipSuccess;
     uint32_t ld_n = (max_vars + 3u) & ~3u, ld_m = max_exprs;
     size_t lds = (size_t)ld_m * ld_n * 8u + (size_t)ld_n * 2u + ld_m + 64u;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&analyze_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    static unsigned int raised = 0;
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&analyze_kernel), &raised);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(analyze_kernel, dim3(b.n_systems), dim3(64), lds, stream, b, x, ld_m, ld_n, dependent);
     return hipGetLastError();
@@ -1260,8 +1261,8 @@ hipError_t launch_analyze(const DeviceBatch& b, const double* x, uint32_t max_va
 template <int N>
 static hipError_t launch_solve_global_n(const DeviceBatch& b, const LmParams& p, const SolveLayout& L, hipStream_t stream) {
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_kernel<N, double, false, true, 0, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    static unsigned int raised = 0;  // (one per N: this is a template)
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_kernel<N, double, false, true, 0, true>), &raised);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((lm_solve_kernel<N, double, false, true, 0, true>), dim3(b.n_g), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();
@@ -1361,7 +1362,8 @@ static hipError_t launch_solve_pose(const DeviceBatch& b, const LmParams& p, hip
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
     void (*fn)(DeviceBatch, LmParams, SolveLayout) = qr ? &lm_solve_pose_kernel<true> : n == 16u ? &lm_solve_pose_kernel<false, 16> :
                                                      n == 32u ? &lm_solve_pose_kernel<false, 32> : &lm_solve_pose_kernel<false, 64>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    static unsigned int raised[4] = {0, 0, 0, 0};  // one slot per pose build
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(fn), &raised[qr ? 0 : n == 16u ? 1 : n == 32u ? 2 : 3]);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fn, dim3(b.n_systems), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();

@@ -277,6 +277,18 @@ struct Arena {
     }
     Mark mark() const { return {cur, used}; }
     void reset(Mark m) { cur = m.cur; used = m.used; }
+    size_t bytes() const {
+        size_t t = 0;
+        for (const Chunk& c : chunks) t += c.size;
+        return t;
+    }
+    // nothing of the arena is in use (the stream is synced, every Pool has ended): memory beyond `keep` goes back to the driver
+    void trim(size_t keep) {
+        if (bytes() <= keep) return;
+        for (auto& c : chunks) (void)hipFree(c.base);
+        chunks.clear();
+        cur = used = 0;
+    }
     ~Arena() {
         for (auto& c : chunks) (void)hipFree(c.base);
     }
@@ -811,6 +823,9 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the slice's slab is handed to the next one
         if (e != hipSuccess) return e;
     }
+    // the slab stays with the plan for the next solve of this structure — up to a bound: one big group must not pin a
+    // gigabyte of HBM per cached structure until the context goes
+    cache->values.trim(size_t(256) << 20);
     return hipSuccess;
 }
 

@@ -557,8 +557,8 @@ hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_
     if (b.n_wide == 0) return hipSuccess;
     WideLayout L = make_wide_layout(b.w_max_free, b.w_max_vars, b.w_max_rows);
     if (L.total > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lm_solve_wide_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+    static unsigned int raised = 0;
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_wide_kernel), &raised);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lm_solve_wide_kernel, dim3(b.n_wide), dim3(64), L.total, stream, b, p, L);
     return hipGetLastError();

@@ -53,3 +53,35 @@ def test_shards_large_enough_to_be_solved_in_chunks(fiksi, ctx):
     finally:
         for c in others:
             c.close()
+
+
+def test_medium_components_take_one_route_for_every_shard(fiksi, ctx):
+    """Components of 65 ... 128 columns go to the wide kernel or to the team kernels by the cost of the batch at hand, and the
+    two add in different orders: 2 000 of the reference's 16-triangle sketches (66 variables) go wide as a whole and would go
+    to the team kernels in three shards of 667. fx_system_solve_batch_multi decides once, on the whole batch — the bits do not
+    depend on the number of contexts."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.hinged_triangles(2000, 16)
+    assert int(b["var_off"][1]) == 66
+    v1, r1 = ctx.system_solve_batch(b)
+    others = [fiksi.Context(0) for _ in range(3)]
+    try:
+        for n_ctx in (1, 2, 3):
+            v, r, _ = abi.Context.system_solve_batch_multi(others[:n_ctx], b)
+            assert np.array_equal(v.view(np.uint64), v1.view(np.uint64)), n_ctx
+            assert np.array_equal(r, r1), n_ctx
+        # a pinned route is honoured (and must be the same in every context)
+        for c in others:
+            c.set_wide_routing(0)
+        ctx.set_wide_routing(0)
+        v0, r0 = ctx.system_solve_batch(b)
+        v, r, _ = abi.Context.system_solve_batch_multi(others, b)
+        assert np.array_equal(v.view(np.uint64), v0.view(np.uint64)) and np.array_equal(r, r0)
+        others[1].set_wide_routing(1)
+        with pytest.raises(Exception):
+            abi.Context.system_solve_batch_multi(others, b)
+    finally:
+        ctx.set_wide_routing(-1)
+        for c in others:
+            c.close()

@@ -34,3 +34,30 @@ def test_host_logic_under_asan_and_ubsan():
     out = p.stdout + p.stderr
     assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
     assert p.returncode == 0, out[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_mutation_fuzz_of_the_entry_points_under_asan_and_ubsan():
+    """tools/abi_fuzz.py, 300 iterations from a fixed seed, against the sanitizer build with its make-believe device
+    (fx_hip_shim.h: allocations and copies are real, kernel launches answer "no device"): corrupted batches, column patterns,
+    plan capacities and index arguments through fx_batch_validate, fx_jacobian_structure, fx_single_pass_blocks,
+    fx_qr_symbolic, fxs_recursive_plan and — as far as their host analysis and uploads go — fx_batch_upload,
+    fx_system_solve_batch, fx_system_solve_batch_multi, fx_system_prepare_batch, fx_cluster_solve_batch,
+    fx_pose_transform_points, fx_unscale_vars_strided. Error codes only: no sanitizer report, no crash."""
+    csrc = os.path.join(ROOT, "fiksi_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "-s", "asan"])
+    lib = os.path.join(ROOT, "fiksi_amd", "libfiksi_host_asan.so")
+    pre = []
+    for name in ("libasan.so", "libubsan.so"):
+        path = subprocess.check_output(["gcc", f"-print-file-name={name}"], text=True).strip()
+        if not os.path.isabs(path):
+            pytest.skip(f"{name} not installed")
+        pre.append(path)
+    env = dict(os.environ, LD_PRELOAD=" ".join(pre), ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1",
+               FIKSI_AMD_LIBRARY=lib, FIKSI_AMD_HIP_RUNTIME="system", FIKSI_AMD_SHIM_FAKE_DEVICE="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "abi_fuzz.py"), "300", "20261004"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1500)
+    out = p.stdout + p.stderr
+    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out, out[-4000:]
+    assert p.returncode == 0, out[-4000:]
+    assert "contexts: 3" in out and "'fx_qr_symbolic'" in out and "'fx_system_solve_batch_multi'" in out

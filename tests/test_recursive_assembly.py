@@ -345,3 +345,32 @@ def test_batched_arm_equals_one_system_at_a_time(fiksi, ctx):
         for f in ("scale", "sse0", "sse", "sse_unscaled"):
             assert res[f][k] == s.last_result[f], (k, f)
     assert np.all(res["sse_unscaled"] < 1e-6) and np.all(res["ncomp"] >= 3)
+
+
+@pytest.mark.gpu
+def test_a_system_listed_several_times_is_solved_once_per_listing(fiksi, ctx):
+    """fxs_systems_solve under RecursiveAssembly groups Systems by structure; a System that the caller lists three times is
+    solved three times, each from the result before (its j-th listing only ever shares a group with other j-th listings) —
+    the same as three calls in a row, also when other Systems of its structure sit between the listings."""
+    from fiksi_amd.system import solve_systems
+
+    F = fiksi
+    P, D = F.elements.Point.create, F.constraints.PointPointDistance.create
+    RA = F.SolvingOptions(decomposer=F.Decomposer.RecursiveAssembly)
+
+    def sketch(off):
+        s = F.System()
+        a, b, c = P(s, 0. + off, 0.1), P(s, 1.2, 0.05 * off), P(s, 0.4, 0.9 + off)
+        D(s, a, b, 1.); D(s, b, c, 1.); D(s, c, a, 1.)
+        return s
+
+    x, y = sketch(0.02), sketch(0.07)
+    res = solve_systems([x, y, x, y, x], RA, ctx=ctx)
+    x1, y1 = sketch(0.02), sketch(0.07)
+    for _ in range(3):
+        x1.solve(RA, ctx=ctx)
+    for _ in range(2):
+        y1.solve(RA, ctx=ctx)
+    assert np.array_equal(x.flatten()["vars"].view(np.uint64), x1.flatten()["vars"].view(np.uint64))
+    assert np.array_equal(y.flatten()["vars"].view(np.uint64), y1.flatten()["vars"].view(np.uint64))
+    assert res["sse_unscaled"][4] == x1.last_result["sse_unscaled"] and res["sse_unscaled"][3] == y1.last_result["sse_unscaled"]
