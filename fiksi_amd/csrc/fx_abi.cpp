@@ -730,6 +730,18 @@ struct fx_ctx {
         for (PlanEntry& e : plan_cache) fx::sparse_cache_free(e.plan);
         plan_cache.clear();
     }
+    // One-shot solves of a handful of small Systems (System::solve on one sketch): the batch's one block lives in
+    // host-coherent page-locked memory that the kernel reads and writes directly — no copy call either way, one launch
+    // and one wait on the stream per call (a copy call costs more than such a kernel runs).
+    unsigned char* zc = nullptr;
+    static constexpr size_t ZC_BYTES = size_t(64) << 10;
+    bool ensure_zc() {
+        if (zc) return true;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, ZC_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return false;
+        zc = static_cast<unsigned char*>(p);
+        return true;
+    }
     bool ensure_pinned() {
         if (pinned) return true;
         void* p = nullptr;
@@ -835,6 +847,9 @@ struct fx_dbatch {
     unsigned char* packed_base = nullptr;  // small batches: the one block all arrays live in
     size_t packed_bytes = 0;
     bool upload_pending = false;           // ... and its copy from the context's page-locked staging was not waited for
+    bool zero_copy = false;                // one-shot solves of a few small Systems: the host writes the block's image into the context's
+    unsigned char* zc_image = nullptr;     // host-coherent region, a kernel pulls it over, another pushes vars / results (the block's end,
+    size_t zc_front = 0;                   // from zc_front on) back
     bool resident = false;  // uploaded by the caller (plans are worth keeping); false for the one-shot host entry points
     std::vector<uint16_t> h_var_comp, h_expr_comp;
     fx_batch h_batch{};
@@ -953,11 +968,12 @@ int ensure_units(fx_ctx* ctx, fx_dbatch* db) {
     std::vector<uint16_t> var_info(d.n_vars), expr_idx(4 * (size_t)d.n_exprs);
     std::vector<uint8_t> expr_tag(d.n_exprs), sys_large(n);
     std::vector<uint16_t> sys_ncomp(n);
-    if (db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
+    if (db->packed_base && (ctx->pinned || db->zero_copy) && db->packed_bytes <= fx_ctx::PINNED_HALF) {
         // a small batch is one block on the device: one copy of it (page-locked, second half of the staging area) instead
         // of seven small ones — the structure arrays are then taken from that image
-        unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
-        FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        // (a zero-copy block is host memory already)
+        unsigned char* img = db->zero_copy ? db->zc_image : ctx->pinned + fx_ctx::PINNED_HALF;
+        if (!db->zero_copy) FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipStreamSynchronize(ctx->stream));
         ctx->stream_synced();
         auto grab = [&](void* dst, const void* dev, size_t bytes) {
@@ -1223,10 +1239,11 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     std::vector<fx::UnitDesc> unit_desc;
     std::vector<uint16_t> unit_vars;
     if (d.sys_class && !units) sys_class.resize(n);
-    if (db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
+    if (db->packed_base && (ctx->pinned || db->zero_copy) && db->packed_bytes <= fx_ctx::PINNED_HALF) {
         // a small batch is one block on the device: its image in one page-locked copy instead of nine small ones
-        unsigned char* img = ctx->pinned + fx_ctx::PINNED_HALF;
-        FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        // (a zero-copy block is host memory already)
+        unsigned char* img = db->zero_copy ? db->zc_image : ctx->pinned + fx_ctx::PINNED_HALF;
+        if (!db->zero_copy) FX_HIP(hipMemcpyAsync(img, db->packed_base, db->packed_bytes, hipMemcpyDeviceToHost, ctx->stream));
         FX_HIP(hipStreamSynchronize(ctx->stream));
         ctx->stream_synced();
         auto grab = [&](void* dst, const void* dev, size_t bytes) {
@@ -1765,6 +1782,7 @@ void fx_ctx_destroy(fx_ctx* ctx) {
     ctx->drop_plans();
     ctx->drop_cache();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->zc) (void)hipHostFree(ctx->zc);
     delete ctx;
 }
 
@@ -1879,7 +1897,8 @@ int fx_jacobian_structure(const fx_batch* batch, uint64_t* nnz, uint32_t* row_pt
 
 // Systems [s0, s1) of an analysed batch onto the device (the whole batch, or one chunk of solve_host_chunked: the limits
 // that size kernels and LDS are the whole batch's either way, so a chunk runs the very kernels the whole batch would).
-static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out) {
+static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out,
+                          bool one_shot = false) {
     *out = nullptr;
     int rc = FX_OK;
     const bool whole = s0 == 0 && s1 == p.n_systems;
@@ -1969,21 +1988,48 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
         if (i + 1 == n_front) front = packed;
     }
     hipError_t e1 = hipSuccess;
+    // A one-shot solve of a few small Systems (System::solve on one sketch) makes no copy call: the host writes the block's
+    // image into the context's host-coherent region, one small kernel pulls it over in a burst and another pushes `vars` and
+    // `results` back when the solve is done (2 us each; a solve kernel working on the region in place pays a PCIe round trip
+    // per dependent load, and waits for its stores: 40 / 30 us instead of 10 — both measured).
+    const bool zero_copy = one_shot && whole && packed <= fx_ctx::ZC_BYTES && p.n_large == 0 && p.wide_list.empty() && ctx->ensure_zc();
     unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
     if (!base) {
         fx_batch_free(ctx, db);
         return fail(e1 == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipMalloc(%zu): %s", packed, hipGetErrorString(e1));
     }
     db->allocations.push_back({base, packed});
+    db->zero_copy = zero_copy;
+    db->zc_image = zero_copy ? ctx->zc : nullptr;
     {
         size_t at = 0;
-        for (const Req& r : reqs) {
-            *r.dst = base + at;
-            at += room_of(r);
+        for (size_t i = 0; i < reqs.size(); ++i) {
+            *reqs[i].dst = base + at;
+            at += room_of(reqs[i]);
         }
     }
-    const bool on_device_tail = packed > (size_t(256) << 10);  // vars and results made on the device
+    const bool on_device_tail = !zero_copy && packed > (size_t(256) << 10);  // vars and results made on the device
     auto upload = [&]() -> int {
+        if (zero_copy) {
+            db->packed_base = base;
+            db->packed_bytes = packed;
+            unsigned char* img = ctx->zc;
+            size_t at = 0;
+            for (const Req& r : reqs) {
+                const size_t room = room_of(r);
+                if (r.src && r.bytes) {
+                    memcpy(img + at, r.src, r.bytes);
+                    memset(img + at + r.bytes, 0, room - r.bytes);
+                } else {
+                    memset(img + at, 0, room);
+                }
+                at += room;
+            }
+            FX_HIP(fx::launch_pull(base, img, packed, ctx->stream));
+            db->zc_front = front;
+            db->upload_pending = true;  // (the image outlives this frame: nothing to wait for below)
+            return FX_OK;
+        }
         if (packed <= fx_ctx::PINNED_HALF) {
             db->packed_base = base;
             db->packed_bytes = packed;
@@ -2357,6 +2403,22 @@ int fx_timer_end(fx_ctx* ctx, float* milliseconds) {
 // one block on the device: both come back in ONE copy through the page-locked staging area and the call waits on the
 // stream once.
 static int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch, fx_result* results, int rc) {
+    if (db->zero_copy) {  // vars and results, the end of the block, pushed into the host-coherent image by one small kernel
+        if (!rc) {
+            hipError_t e = fx::launch_pull(db->zc_image + db->zc_front, db->packed_base + db->zc_front, db->packed_bytes - db->zc_front, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = fail(FX_ERR_HIP, "solve failed: %s", hipGetErrorString(e));
+            else ctx->stream_synced();
+        }
+        if (!rc && batch->n_systems) {
+            const unsigned char* dev0 = db->packed_base;
+            memcpy(batch->vars, db->zc_image + (reinterpret_cast<const unsigned char*>(db->d.vars) - dev0), (size_t)db->d.n_vars * sizeof(double));
+            if (results)
+                memcpy(results, db->zc_image + (reinterpret_cast<const unsigned char*>(db->d.results) - dev0), (size_t)db->d.n_systems * sizeof(fx_result));
+        }
+        free_batch(ctx, db, /*stream_idle=*/rc == FX_OK);
+        return rc;
+    }
     if (!rc && batch->n_systems && db->packed_base && ctx->pinned && db->packed_bytes <= fx_ctx::PINNED_HALF) {
         const unsigned char* lo = reinterpret_cast<const unsigned char*>(db->d.vars);
         const unsigned char* hi = reinterpret_cast<const unsigned char*>(db->d.results + db->d.n_systems);
@@ -2462,7 +2524,7 @@ static int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts*
             (ctx->stream3 || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) == hipSuccess) &&
             (ctx->ev_chunk || hipEventCreateWithFlags(&ctx->ev_chunk, hipEventDisableTiming) == hipSuccess))
             return solve_host_chunked(ctx, batch, p, n_chunks, sopts, lopts, system_level, results);
-        rc = upload_planned(ctx, batch, p, 0, p.n_systems, &db);
+        rc = upload_planned(ctx, batch, p, 0, p.n_systems, &db, /*one_shot=*/true);
     }
     if (rc) return rc;
     tr.stamp("upload", batch->n_systems);

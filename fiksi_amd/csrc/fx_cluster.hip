@@ -122,4 +122,16 @@ hipError_t launch_unscale(double scale, const double* scaled, const uint8_t* mas
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void pull_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, uint32_t n16) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+hipError_t launch_pull(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    const uint32_t n16 = (uint32_t)(bytes / 16u);
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(pull_kernel, dim3((n16 + 255u) / 256u), dim3(256), 0, stream, static_cast<uint4*>(dst), static_cast<const uint4*>(src), n16);
+    return hipGetLastError();
+}
+
 }  // namespace fx

@@ -18,7 +18,7 @@ typedef struct fx_fake_stream* hipStream_t;
 typedef struct fx_fake_event* hipEvent_t;
 enum : int { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
-enum : unsigned { hipStreamNonBlocking = 1 };
+enum : unsigned { hipStreamNonBlocking = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 struct hipDeviceProp_t {
     char name[128];
     char gcnArchName[64];

@@ -16,6 +16,7 @@ hipError_t launch_solve_grouped(const DeviceBatch&, const LmParams&, hipStream_t
 size_t grouped_lds_bytes(const DeviceBatch&, uint32_t, bool) { return 0; }
 hipError_t launch_solve_walk(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t presort_temp_bytes(uint32_t) { return 0; }
+hipError_t launch_pull(void*, const void*, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_presort(const DeviceBatch&, float*, uint32_t*, void*, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_prepare(const DeviceBatch&, uint32_t, double*, double*, double*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_unscale(double, const double*, const uint8_t*, double*, uint32_t, hipStream_t) { return hipErrorNoDevice; }

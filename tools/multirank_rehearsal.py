@@ -24,8 +24,9 @@ def run(n, scaling, backend, port):
         return None, "timed out after 600 s"
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     if p.returncode or not lines:
-        tail = [ln for ln in (p.stderr or "").splitlines() if ln.strip()][-6:]
-        return None, " | ".join(tail)[-600:]
+        lines = [ln.strip() for ln in (p.stderr or "").splitlines() if ln.strip()]
+        hits = [ln for ln in lines if any(w in ln for w in ("NCCL", "nccl", "Duplicate", "Error:", "error:"))]
+        return None, " | ".join((hits or lines)[-4:])[-800:]
     d = json.loads(lines[0])
     return {"n_gpus": d["n_gpus"], "scaling": d["scaling"], "backend": backend, "value": d["value"], "unit": d["unit"],
             "ms_per_step": d["ms_per_step"], "steps": d["steps"], "converged_fraction": d["converged_fraction"],
