@@ -1225,6 +1225,151 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
     return true;
 }
 
+// The same analysis compiled into a table-driven program for the grouped FX_STEP_QR build (fx_grouped.hip: four Systems per
+// wavefront, one per row of 16 lanes; batches of ONE structure, so one program serves every System). The permuted augmented
+// matrix [J | -r; sqrt(lambda) I | 0] is stored by its symbolic patterns — per column position j the rows of R(:, j) above the
+// diagonal and of the Householder vector H(:, j) from it down — plus the dense right-hand side and one slot of zero for the
+// padding. Every access of the factorisation is then an offset from a table: per Householder step k its active columns
+// (those with k in R's pattern, and the right-hand side), one lane each, and per (active column, vector entry) one word
+// holding both offsets of the multiply-add. The arithmetic and its order are the one-wavefront QR kernel's (fx_kernels.hip).
+// Words: [0] n [1] m [2] nx (doubles per System, even) [3] zero slot [4] scat (u16 [m][8], 0xFFFF = dropped) [5] rhs_off (u16 [m])
+// [6] damp_off (u16 [n]) [7] cpos (u16 [n]: free column -> position) [8] steps ([n][3]: diag | len << 16, entries' first word,
+// active columns) [9] bptr (u16 [n + 1]) [10] bent (row << 16 | offset of R(row, i)) [11] words in all [12] first right-hand
+// side entry [13] longest vector (entries below the diagonal, padded to fours).
+struct QrgHostProgram {
+    std::vector<uint32_t> words;
+    uint32_t n = 0, m = 0, nx = 0;
+    bool ok = false;
+};
+bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, const uint32_t* rows, uint32_t m, const uint32_t* free_,
+                       uint32_t n, uint32_t nvt, QrgHostProgram& out) {
+    out = QrgHostProgram();
+    out.n = n;
+    out.m = m;
+    if (n == 0 || n > 32u || m == 0 || m > 64u) return false;
+    std::vector<int32_t> colof(nvt, -1);
+    for (uint32_t c = 0; c < n; ++c) colof[free_[c]] = (int32_t)c;
+    std::vector<std::vector<int>> cols(n);
+    std::vector<int32_t> gcol((size_t)m * 8, -1);
+    for (uint32_t r = 0; r < m; ++r) {
+        uint32_t vars8[8];
+        const int k = fx::expand_vars<true>((int)(expr_tag[rows[r]] & 0x7F), expr_idx16 + 4 * (size_t)rows[r], vars8);
+        for (int q = 0; q < k; ++q) {
+            const int32_t c = vars8[q] < nvt ? colof[vars8[q]] : -1;
+            gcol[(size_t)r * 8 + q] = c;
+            if (c >= 0 && (cols[c].empty() || cols[c].back() != (int)r)) cols[c].push_back((int)r);
+        }
+    }
+    fx::qr::Csc a;
+    a.nrows = (int)(m + n);
+    a.ncols = (int)n;
+    a.ptr.assign(1, 0);
+    for (uint32_t c = 0; c < n; ++c) {
+        a.idx.insert(a.idx.end(), cols[c].begin(), cols[c].end());
+        a.idx.push_back((int)(m + c));
+        a.ptr.push_back((int)a.idx.size());
+    }
+    fx::qr::Symbolic sy;
+    if (!fx::qr::analyze(a, true, sy)) return false;
+    const uint32_t Mq = m + n;
+    std::vector<uint32_t> cpos(n, 0);
+    for (uint32_t j = 0; j < n; ++j) cpos[(uint32_t)sy.col_perm[j]] = j;
+    // storage: column position j holds the rows of R(:, j) above the diagonal, then those of H(:, j) (j first)
+    std::vector<std::vector<int>> prow(n);
+    std::vector<uint32_t> cbase(n + 1, 0);
+    for (uint32_t j = 0; j < n; ++j) {
+        for (int p = sy.rptr[j]; p < sy.rptr[j + 1] - 1; ++p) prow[j].push_back(sy.rrows[p]);
+        for (int p = sy.hptr[j]; p < sy.hptr[j + 1]; ++p) prow[j].push_back(sy.hrows[p]);
+        if (!std::is_sorted(prow[j].begin(), prow[j].end()) || std::adjacent_find(prow[j].begin(), prow[j].end()) != prow[j].end()) return false;
+        cbase[j + 1] = cbase[j] + (uint32_t)prow[j].size();
+    }
+    const uint32_t rhsbase = cbase[n];
+    uint32_t nx = rhsbase + Mq + 1u;
+    const uint32_t zero = nx - 1u;
+    nx = (nx + 1u) & ~1u;
+    if (nx > 0xFFF0u) return false;
+    bool bad = false;
+    auto at = [&](int r, uint32_t j) -> uint32_t {  // offset of entry (permuted row r, column position j; j == n: right-hand side)
+        if (j == n) return rhsbase + (uint32_t)r;
+        auto it = std::lower_bound(prow[j].begin(), prow[j].end(), r);
+        if (it == prow[j].end() || *it != r) {
+            bad = true;
+            return zero;
+        }
+        return cbase[j] + (uint32_t)(it - prow[j].begin());
+    };
+    std::vector<uint16_t> scat((size_t)m * 8, 0xFFFFu), rhs_off(m), damp(n), cpos16(n), bptr(n + 1, 0);
+    for (uint32_t r = 0; r < m; ++r) {
+        for (int q = 0; q < 8; ++q)
+            if (gcol[(size_t)r * 8 + q] >= 0) scat[(size_t)r * 8 + q] = (uint16_t)at(sy.row_perm[r], cpos[(uint32_t)gcol[(size_t)r * 8 + q]]);
+        rhs_off[r] = (uint16_t)at(sy.row_perm[r], n);
+    }
+    for (uint32_t c = 0; c < n; ++c) {
+        damp[c] = (uint16_t)at(sy.row_perm[m + c], cpos[c]);
+        cpos16[c] = (uint16_t)cpos[c];
+    }
+    std::vector<uint32_t> steps(3 * (size_t)n, 0), ent, bent;
+    uint32_t max_len = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const int hb = sy.hptr[k], he = sy.hptr[k + 1];
+        if (he <= hb || sy.hrows[hb] != (int)k) return false;
+        const uint32_t below = (uint32_t)(he - hb - 1), len = (below + 3u) & ~3u;
+        max_len = std::max(max_len, len);
+        std::vector<uint32_t> active;  // column positions the vector is applied to, ascending, then the right-hand side
+        for (uint32_t j = k + 1; j < n; ++j)
+            if (std::binary_search(sy.rrows.begin() + sy.rptr[j], sy.rrows.begin() + sy.rptr[j + 1] - 1, (int)k)) active.push_back(j);
+        active.push_back(n);
+        const uint32_t na = (uint32_t)active.size();
+        steps[3 * k] = at((int)k, k) | (len << 16);
+        steps[3 * k + 1] = (uint32_t)ent.size();
+        steps[3 * k + 2] = na;
+        const size_t e0 = ent.size();
+        ent.resize(e0 + (size_t)(len + 1u) * na, zero | (zero << 16));
+        for (uint32_t i = 0; i < na; ++i) {
+            ent[e0 + i] = at((int)k, active[i]);
+            for (uint32_t u = 0; u < below; ++u) {
+                const int r = sy.hrows[hb + 1 + (int)u];
+                ent[e0 + (size_t)(1u + u) * na + i] = at(r, active[i]) | (at(r, k) << 16);
+            }
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        bptr[i] = (uint16_t)bent.size();
+        for (int p = sy.rptr[i]; p < sy.rptr[i + 1] - 1; ++p) bent.push_back(((uint32_t)sy.rrows[p] << 16) | at(sy.rrows[p], i));
+    }
+    bptr[n] = (uint16_t)bent.size();
+    if (bad || max_len > 32u) return false;
+    std::vector<uint32_t>& w = out.words;
+    w.assign(16, 0);
+    auto put16 = [&](const std::vector<uint16_t>& v) -> uint32_t {
+        const uint32_t o = (uint32_t)w.size();
+        w.resize(o + (v.size() + 1) / 2, 0);
+        memcpy(w.data() + o, v.data(), v.size() * 2);
+        return o;
+    };
+    auto put32 = [&](const std::vector<uint32_t>& v) -> uint32_t {
+        const uint32_t o = (uint32_t)w.size();
+        w.insert(w.end(), v.begin(), v.end());
+        return o;
+    };
+    w[0] = n; w[1] = m; w[2] = nx; w[3] = zero;
+    w[4] = put16(scat); w[5] = put16(rhs_off); w[6] = put16(damp); w[7] = put16(cpos16);
+    const uint32_t o_ent_rel = 0;
+    (void)o_ent_rel;
+    w[8] = put32(steps);
+    w[9] = put16(bptr);
+    w[10] = put32(bent);
+    const uint32_t o_ent = put32(ent);
+    for (uint32_t k = 0; k < n; ++k) w[w[8] + 3 * k + 1] += o_ent;  // entries' first word, from the start of the program
+    w.resize((w.size() + 3u) & ~size_t(3), 0);
+    w[11] = (uint32_t)w.size();
+    w[12] = rhsbase;
+    w[13] = max_len;
+    out.nx = nx;
+    out.ok = true;
+    return true;
+}
+
 // Builds (once per resident batch and decomposer) the QR plans of every System the one-wavefront kernel takes.
 // Systems of one structure share a plan: a batch of one sketch with many parameter sets is analysed once.
 int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
@@ -1400,8 +1545,26 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
                         need);
         }
     }
+    // a batch of ONE structure with a single component of at most 32 columns: the program of the grouped build as well
+    QrgHostProgram prog;
+    if (!units && d.uniform && d.u_ncomp == 1u && n >= 1 && !sys_large[0] && sys_ncomp[0] == 1u) {
+        const uint32_t nvt = var_off[1] - var_off[0], net = expr_off[1] - expr_off[0];
+        std::vector<uint32_t> rows, free_;
+        for (uint32_t i = 0; i < nvt; ++i)
+            if ((var_info[i] & fx::VAR_COMP_MASK) == 0 && !(var_info[i] & fx::VAR_FIXED_BIT)) free_.push_back(i);
+        for (uint32_t i = 0; i < net; ++i)
+            if (expr_comp[i] == 0) rows.push_back(i);
+        (void)build_qrg_program(expr_tag.data(), expr_idx.data(), rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), nvt, prog);
+    }
     unsigned long long* d64 = nullptr;
     int rc = dev_alloc_copy(ctx, db, &q.u16, u16.data(), u16.size());
+    if (!rc && prog.ok) {
+        rc = dev_alloc_copy(ctx, db, &q.qrg, prog.words.data(), prog.words.size());
+        q.qrg_words = (uint32_t)prog.words.size();
+        q.qrg_nx = prog.nx;
+        q.qrg_n = prog.n;
+        q.qrg_m = prog.m;
+    }
     if (!rc) rc = dev_alloc_copy(ctx, db, &d64, reinterpret_cast<const unsigned long long*>(u64.data()), u64.size());
     if (!rc) rc = dev_alloc_copy(ctx, db, &q.index, index.data(), index.size());
     fx::QrDesc* ddesc = nullptr;

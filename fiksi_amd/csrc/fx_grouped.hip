@@ -46,10 +46,13 @@ struct GroupLayout {
     uint32_t off_colof, off_gcol, off_fidx;  // set-up scratch inside the triangle's bytes
     uint32_t pw_cap, pe_cap;
     uint32_t stride;  // bytes per System
+    // the FX_STEP_QR build: the program of the batch's one structure (shared by the wavefront, at the start of its LDS) and a
+    // System's matrix stored by its symbolic patterns
+    uint32_t tab_bytes, off_qx;
 };
 
 static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max_rows, uint32_t es, uint32_t max_pairs_tri,
-                                     uint32_t max_ents) {
+                                     uint32_t max_ents, uint32_t qrg_words = 0, uint32_t qrg_nx = 0) {
     GroupLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -59,15 +62,17 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
     auto al = [](uint32_t bytes) { return (bytes + 15u) & ~15u; };
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += al(bytes); return at; };
     L.off_xs = take(L.vt * es);
-    const uint32_t tri = n * (n + 1u) / 2u * es;
+    const uint32_t tri = qrg_words ? 0u : n * (n + 1u) / 2u * es;  // (the QR build forms no normal equations)
     const uint32_t scratch = al(L.vt * 2u) + al(L.mr * 8u) + al(n * 2u);
     L.off_a = take(tri > scratch ? tri : scratch);
     L.off_colof = L.off_a;
     L.off_gcol = L.off_colof + al(L.vt * 2u);
     L.off_fidx = L.off_gcol + al(L.mr * 8u);
     L.off_rhs = take(n * es);
-    L.off_g = take(L.mr * 8u * es);
-    L.off_r = take(L.mr * es);
+    // (the QR build keeps the rows of the current point beside those of the trial point: its step reads J and r at every
+    // trial, not only after an accepted one)
+    L.off_g = take(L.mr * 8u * es * (qrg_words ? 2u : 1u));
+    L.off_r = take(L.mr * es * (qrg_words ? 2u : 1u));
     L.off_p = take(L.mr * es);
     L.off_gvar = take(L.mr * 16u);
     L.off_rtag = take(L.mr);
@@ -76,6 +81,8 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
     L.pe_cap = (max_ents + 7u) & ~7u;
     L.off_pw = take(L.pw_cap * 4u);
     L.off_pe = take(L.pe_cap * 2u);
+    L.off_qx = take(qrg_nx * 8u);
+    L.tab_bytes = al(qrg_words * 4u);
     L.stride = o;
     return L;
 }
@@ -318,7 +325,13 @@ enum GPhase { GH_SETUP = 0, GH_EVAL = 1, GH_FORM = 2, GH_FACTOR = 3, GH_SOLVE = 
 // UNITS = true is `Decomposer::SinglePass` (assemble/mod.rs:169-210), as in lm_solve_kernel: the loop runs over the
 // blocks of the host decomposition (fx_decompose.h), a component is perturbed before its first block, and a solved
 // block is written through to the working vector so later blocks see it.
-template <int NC, typename T, bool PROF, bool UNITS>
+// QRG = true is FX_STEP_QR for batches of one structure (one component of at most 32 columns): the LM step is the
+// reference's Householder QR of [J; sqrt(lambda) I] (solvi/src/decomposition/sparse/qr.rs:226-356) with the operations and
+// their order of the one-wavefront QR kernel (fx_kernels.hip: qr_step), driven by the host's program (build_qrg_program) —
+// the lanes of a row are the ACTIVE columns of the Householder step at hand (about seven of 33 for the headline shape), and
+// the wavefront serves four Systems. Sums are the reference's sequential ones, the angle residuals use the correctly rounded
+// atan2: every bit is that kernel's, and the oracle's.
+template <int NC, typename T, bool PROF, bool UNITS, bool QRG = false>
 __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParams& prm, const GroupLayout& L,
                                              uint32_t* __restrict__ next_system, unsigned char* smem) {
     unsigned long long ph[GH_COUNT] = {0, 0, 0, 0, 0, 0};
@@ -341,7 +354,17 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
     const uint32_t below = (1u << hl) - 1u;
-    unsigned char* base = smem + (uint32_t)(lane / RS) * L.stride;
+    unsigned char* const rows0 = smem + L.tab_bytes;  // the four Systems' blocks, behind the shared program of the QR build
+    unsigned char* base = rows0 + (uint32_t)(lane / RS) * L.stride;
+    if constexpr (QRG) {  // the program of the batch's one structure, once per wavefront
+        const uint32_t nw = b.qr_none.qrg_words;
+        const uint4* src = reinterpret_cast<const uint4*>(b.qr_none.qrg);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = lane; i < nw / 4u; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     T* XS = reinterpret_cast<T*>(base + L.off_xs);       // [vt] working variables: snapshot, trial point on the free ones
     T* At = reinterpret_cast<T*>(base + L.off_a);        // packed lower triangle of JtJ (+ lambda on the diagonal per trial)
@@ -384,6 +407,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     T sse = T(0), sse_start = T(0);
     double lambda = 0.0;
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
+    uint32_t cur = 0;    // QR build: which of the two row buffers holds the current point's Jacobian rows and residuals
     bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
     uint32_t held = 0;   // passes this row has waited, done, for company (see FINISH)
     // The lambda ladder (prm.ladder). The trials that follow a plain reject read the same point, Jacobian and residuals
@@ -472,13 +496,15 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
         }
     };
 
-    auto eval_rows = [&]() -> T {
+    auto eval_rows = [&](uint32_t buf) -> T {
+        T* G = reinterpret_cast<T*>(base + L.off_g) + (QRG ? buf * L.mr * 8u : 0u);
+        T* R = reinterpret_cast<T*>(base + L.off_r) + (QRG ? buf * L.mr : 0u);
         T part[4] = {T(0), T(0), T(0), T(0)};
         for (uint32_t row = hl; row < m_rows; row += RS) {
             T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = XS[gvar[row * 8 + e]];
-            T r = eval_expression<T, true>(rtag[row], v, P[row], g);
+            T r = eval_expression<T, true, QRG>(rtag[row], v, P[row], g);  // (QR build: the correctly rounded atan2)
             R[row] = r;
 #pragma unroll
             for (int e = 0; e < 8; ++e) G[row * 8 + e] = g[e];
@@ -488,7 +514,154 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : T(0);
         }
         group_sync();
-        return block_sum4(part);
+        if constexpr (QRG) {  // the reference's sum of squares, in index order (lm.rs:195-197)
+            double acc = 0.0;
+            for (uint32_t at = 0; at < m_rows; at += RS) {
+                const uint32_t row = at + (uint32_t)hl;
+                const double r = row < m_rows ? (double)R[row] : 0.0;  // (+ 0.0: exact)
+                seq_add(acc, r * r);
+            }
+            return (T)acc;
+        } else {
+            return block_sum4(part);
+        }
+    };
+    // One LM trial's step by the reference's QR, table-driven (build_qrg_program). Returns false when R has an exactly zero
+    // diagonal entry (sparse_col_mat.rs:800-810); delta: this lane's free columns hl, hl + 16.
+    auto qr_step = [&](double lam, T (&delta)[NC], uint32_t buf) -> bool {
+        bool ok = true;
+        if constexpr (QRG) {
+            const T* G = reinterpret_cast<const T*>(base + L.off_g) + buf * L.mr * 8u;
+            const T* R = reinterpret_cast<const T*>(base + L.off_r) + buf * L.mr;
+            const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
+            const uint32_t qn = TB[0], qm = TB[1], nx = TB[2], rhsbase = TB[12];
+            const uint16_t* scat = reinterpret_cast<const uint16_t*>(TB + TB[4]);
+            const uint16_t* rhs_off = reinterpret_cast<const uint16_t*>(TB + TB[5]);
+            const uint16_t* damp = reinterpret_cast<const uint16_t*>(TB + TB[6]);
+            const uint16_t* cposT = reinterpret_cast<const uint16_t*>(TB + TB[7]);
+            const uint32_t* stepT = TB + TB[8];
+            const uint16_t* bptr = reinterpret_cast<const uint16_t*>(TB + TB[9]);
+            const uint32_t* bent = TB + TB[10];
+            double* X = reinterpret_cast<double*>(base + L.off_qx);
+            const double sl = ::sqrt(lam);  // lm.rs:119
+            {
+                double2 z;
+                z.x = z.y = 0.0;
+                for (uint32_t i = hl; i < nx / 2u; i += RS) reinterpret_cast<double2*>(X)[i] = z;
+            }
+            group_sync();
+            // J (duplicates of a row summed in gradient order, sparse_col_mat.rs:710-711) and b = -r (lm.rs:86-91,130);
+            // the damping entry of every column (lm.rs:92-96,119-125)
+            for (uint32_t row = hl; row < qm; row += RS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t off = scat[row * 8 + e];
+                    if (off != 0xFFFFu) lds_add(&X[off], (double)G[row * 8 + e]);
+                }
+                X[rhs_off[row]] = -(double)R[row];
+            }
+            for (uint32_t c = hl; c < qn; c += RS) X[damp[c]] = sl;
+            group_sync();
+            for (uint32_t k = 0; k < qn; ++k) {
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k]);
+                const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k + 1]);
+                const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k + 2]);
+                const uint32_t vdiag = w0 & 0xFFFFu, len = w0 >> 16;
+                const double v0 = X[vdiag];
+                double norm = 0.0, beta = 0.0, v0n = 1.0;
+                // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
+                auto householder = [&](double sigma) {
+                    norm = ::fabs(v0);
+                    beta = (v0 >= 0.0) ? 0.0 : 2.0;
+                    v0n = 1.0;
+                    if (sigma != 0.0) {
+                        norm = ::sqrt(sigma + v0 * v0);
+                        v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
+                        beta = -(1.0 / (norm * v0n));
+                    }
+                };
+                for (uint32_t i0 = 0; i0 < nact; i0 += RS) {
+                    const bool act = i0 + (uint32_t)hl < nact;
+                    const uint32_t* e = TB + ent + (act ? i0 + (uint32_t)hl : 0u);  // (idle lanes follow column 0 and store nothing)
+                    // the vector and this lane's column under it, NB blocks of four entries, fetched once (one copy of the
+                    // body per block count, picked once per vector)
+                    auto window = [&](auto nb_c) {
+                        constexpr int NE = 4 * decltype(nb_c)::value;
+                        uint32_t w[NE > 0 ? NE : 1];
+                        double vk[NE > 0 ? NE : 1], xj[NE > 0 ? NE : 1];
+                        const uint32_t wk0 = e[0];
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) w[u] = e[(uint32_t)(1 + u) * nact];
+                        const double xk0 = X[wk0];
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) {
+                            vk[u] = X[w[u] >> 16];
+                            xj[u] = X[w[u] & 0xFFFFu];
+                        }
+                        double sigma = 0.0;
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) sigma = sigma + vk[u] * vk[u];
+                        householder(sigma);
+                        // apply_householder (qr.rs:226-240)
+                        double tau = 0.0;
+                        tau = tau + v0n * xk0;
+#pragma unroll
+                        for (int u = 0; u < NE; ++u) tau = tau + vk[u] * xj[u];
+                        tau = tau * beta;
+                        if (act) {
+                            X[wk0] = xk0 - v0n * tau;
+#pragma unroll
+                            for (int u = 0; u < NE; ++u) X[w[u] & 0xFFFFu] = xj[u] - vk[u] * tau;  // (padding: 0 - 0 tau into the zero slot)
+                        }
+                    };
+                    switch (len >> 2) {
+                        case 0: window(std::integral_constant<int, 0>{}); break;
+                        case 1: window(std::integral_constant<int, 1>{}); break;
+                        case 2: window(std::integral_constant<int, 2>{}); break;
+                        case 3: window(std::integral_constant<int, 3>{}); break;
+                        case 4: window(std::integral_constant<int, 4>{}); break;
+                        case 5: window(std::integral_constant<int, 5>{}); break;
+                        case 6: window(std::integral_constant<int, 6>{}); break;
+                        case 7: window(std::integral_constant<int, 7>{}); break;
+                        default: window(std::integral_constant<int, 8>{}); break;
+                    }
+                    group_sync();
+                }
+                if (hl == 0) X[vdiag] = norm;  // R's diagonal (qr.rs:319)
+                group_sync();
+            }
+            // back substitution with R (sparse_col_mat.rs:788-826), in place on the right-hand side: column i of R from the
+            // last to the first, one lane per entry above the diagonal
+            {
+                bool zero_diag = false;
+                for (uint32_t c = hl; c < qn; c += RS) zero_diag = zero_diag || X[stepT[3 * c] & 0xFFFFu] == 0.0;
+                ok = gballot(zero_diag) == 0u;
+            }
+            if (ok) {
+                for (uint32_t ii = qn; ii > 0; --ii) {
+                    const uint32_t i = ii - 1u;
+                    const uint32_t dgo = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * i]) & 0xFFFFu;
+                    const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane((int)bptr[i]);
+                    const uint32_t ee = (uint32_t)__builtin_amdgcn_readfirstlane((int)bptr[i + 1]);
+                    const double coeff = X[rhsbase + i] / X[dgo];
+                    for (uint32_t t = eb + (uint32_t)hl; t < ee; t += RS) {
+                        const uint32_t wv = bent[t];
+                        const uint32_t yo = rhsbase + (wv >> 16);
+                        X[yo] = X[yo] - coeff * X[wv & 0xFFFFu];
+                    }
+                    if (hl == 0) X[rhsbase + i] = coeff;
+                    group_sync();
+                }
+            }
+            // undo the column permutation (qr.rs:354): delta[colperm[j]] = x_j
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const uint32_t c = (uint32_t)(hl + RS * q);
+                delta[q] = (ok && c < qn) ? (T)X[rhsbase + cposT[c < qn ? c : 0u]] : T(0);
+            }
+            group_sync();
+        }
+        return ok;
     };
     // K3: the lower triangle of Jt J and -Jt r from the packed lists (ds_add_f64 / ds_add_f32)
     auto form_normal = [&]() {
@@ -886,7 +1059,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     // symmetric assembly does.
                     n_pw = 0;
                     n_pe = 0;
-                    for (uint32_t at = 0; at < m_rows; at += RS) {
+                    for (uint32_t at = 0; !QRG && at < m_rows; at += RS) {
                         const uint32_t row = at + (uint32_t)hl;
                         uint32_t mask = 0;
                         uint64_t cols = 0;
@@ -1016,7 +1189,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             const auto t = lane_get(v, srcl);
                             if (joining) v = t;
                         };
-                        cp(nfree); cp(m_rows); cp(n_pw); cp(n_pe); cp(trials); cp(accepted); cp(outer); cp(exit_code);
+                        cp(nfree); cp(m_rows); cp(n_pw); cp(n_pe); cp(trials); cp(accepted); cp(outer); cp(exit_code); cp(cur);
                         cp(sse); cp(lambda);
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
@@ -1037,7 +1210,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             // ... and its LDS block: working variables, the triangle of Jt J as last assembled (every row
                             // writes its own diagonal per trial), right-hand side, row lists, parameters, product lists
                             using V = typename Vec16<T>::type;
-                            const V* lb = reinterpret_cast<const V*>(smem + (uint32_t)nl * L.stride);
+                            const V* lb = reinterpret_cast<const V*>(rows0 + (uint32_t)nl * L.stride);
                             V* mine = reinterpret_cast<V*>(base);
                             for (uint32_t i = hl; i < L.stride / 16u; i += RS) mine[i] = lb[i];
                             fresh = false;
@@ -1079,7 +1252,13 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     code = LC_CAP;
                     go = false;
                 }
-                if (go) {
+                if constexpr (QRG) {
+                    if (go && !qr_step(lam_k, delta, cur)) {  // lm.rs:134-137
+                        code = LC_SINGULAR;
+                        go = false;
+                    }
+                }
+                if (!QRG && go) {
                     // K4: factor (JtJ + lambda I) and solve for delta; columns hl and hl + 16 of the symmetric
                     // matrix from the triangle (the lane id goes through an opaque move so that the addresses are
                     // recomputed per trial instead of being hoisted out of the loop into dozens of long-lived
@@ -1133,10 +1312,19 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     }
                 }
                 if (go) {
-                    // |delta|^2 block by block of 16 columns, as wave_sum adds it
-                    T dn2 = row_sum(delta[0] * delta[0]);
-                    if constexpr (NC >= 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
-                    if constexpr (NC >= 3) dn2 = dn2 + row_sum(delta[2] * delta[2]);
+                    // |delta|^2 block by block of 16 columns, as wave_sum adds it (QR build: in index order, lm.rs:195-197)
+                    T dn2;
+                    if constexpr (QRG) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < NC; ++q)
+                            if ((uint32_t)(RS * q) < nfree) seq_add(acc, (double)delta[q] * (double)delta[q]);
+                        dn2 = (T)acc;
+                    } else {
+                        dn2 = row_sum(delta[0] * delta[0]);
+                        if constexpr (NC >= 2) dn2 = dn2 + row_sum(delta[1] * delta[1]);
+                        if constexpr (NC >= 3) dn2 = dn2 + row_sum(delta[2] * delta[2]);
+                    }
                     if (!(dn2 == dn2)) {
                         code = LC_NAN;
                         go = false;
@@ -1156,7 +1344,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
             T sse_t = T(0);
             if (go) {
-                sse_t = eval_rows();
+                sse_t = eval_rows(fresh ? cur : cur ^ 1u);
                 stamp(GH_EVAL);
                 if (!fresh) {
                     if (sse_t < sse) {
@@ -1263,17 +1451,21 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 if constexpr (LADDER) {
                     if (win_row != myrow) {  // the accepted point's Jacobian rows and residuals are another row's
                         using V = typename Vec16<T>::type;
-                        const unsigned char* wb = smem + (uint32_t)win_row * L.stride;
-                        const V* gs = reinterpret_cast<const V*>(wb + L.off_g);
-                        V* gd = reinterpret_cast<V*>(G);
+                        const unsigned char* wb = rows0 + (uint32_t)win_row * L.stride;
+                        const uint32_t tb = QRG ? (cur ^ 1u) : 0u;  // (QR build: the trial buffer, the same one in every row of a group)
+                        const V* gs = reinterpret_cast<const V*>(reinterpret_cast<const T*>(wb + L.off_g) + tb * L.mr * 8u);
+                        V* gd = reinterpret_cast<V*>(G + tb * L.mr * 8u);
                         const uint32_t ng = m_rows * 8u / (uint32_t)Vec16<T>::n;
                         for (uint32_t i = hl; i < ng; i += RS) gd[i] = gs[i];
-                        const T* rs = reinterpret_cast<const T*>(wb + L.off_r);
-                        for (uint32_t i = hl; i < m_rows; i += RS) R[i] = rs[i];
+                        const T* rs = reinterpret_cast<const T*>(wb + L.off_r) + tb * L.mr;
+                        for (uint32_t i = hl; i < m_rows; i += RS) R[tb * L.mr + i] = rs[i];
                         group_sync();
                     }
                 }
-                form_normal();
+                if constexpr (QRG) {
+                    if (!fresh) cur ^= 1u;  // the trial point's rows are the current point's from now on
+                }
+                if constexpr (!QRG) form_normal();  // (the QR step takes J and r as they are)
                 stamp(GH_FORM);
                 // top of the next outer iteration (lm.rs:108-112)
                 if (fresh && (!(sse == sse) || !(sse < Lim<T>::huge()))) {
@@ -1358,7 +1550,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         double v[8], g[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
-                        const double r = eval_expression<double, false>(tag, v, param, g);
+                        const double r = eval_expression<double, false, QRG>(tag, v, param, g);
                         const double r2 = r * r;
                         const uint32_t blk = (i >> 4) & 3u;
 #pragma unroll
@@ -1401,6 +1593,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
     grouped_body<NC, T, PROF, UNITS>(b, prm, L, next_system, smem);
+}
+// FX_STEP_QR, batches of one structure
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_qr_kernel(
+    DeviceBatch b, LmParams prm, GroupLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_body<2, double, false, false, true>(b, prm, L, next_system, smem);
 }
 template <int NC, typename T, bool PROF, bool UNITS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void lm_solve_grouped_kernel_w2(
@@ -1458,6 +1656,44 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
     return hipGetLastError();
 }
 
+// FX_STEP_QR on a batch of one structure: the program of ensure_qr_plans is there, and four Systems fit a wavefront's LDS
+static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLayout* out) {
+    const QrPlans& Q = b.qr_none;
+    if (p.lm.solver != FX_STEP_QR || !Q.qrg || !b.uniform || b.u_ncomp != 1u || p.lm.precision == 32 || p.prof) return false;
+    if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 32u || b.max_rows > 64u || b.max_vars > 64u || !b.work_counter) return false;
+    if (Q.qrg_n != b.max_free || Q.qrg_m != b.max_rows) return false;
+    const GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_words, Q.qrg_nx);
+    if ((size_t)L.tab_bytes + 4u * (size_t)L.stride > 160u * 1024u / 2u) return false;  // two wavefronts per CU at least
+    if (out) *out = L;
+    return true;
+}
+
+static hipError_t launch_grouped_qr(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    GroupLayout L;
+    if (!grouped_qr_applies(b, p, &L)) return hipErrorInvalidValue;
+    const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
+    static unsigned int raised = 0;
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_qr_kernel), &raised);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    uint32_t waves = (b.n_systems + 3u) / 4u;
+    if (waves > 256u * 16u) waves = 256u * 16u;
+    LmParams pl = p;
+    pl.spread = 0u;
+    if (p.ladder) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint32_t by_lds = (160u * 1024u) / per_wave;
+        uint32_t resident = (uint32_t)cus * (by_lds < 4u ? by_lds : 4u);
+        if (resident > waves) resident = waves;
+        if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
+        if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
+    }
+    hipLaunchKernelGGL(lm_solve_grouped_qr_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    return hipGetLastError();
+}
+
 static uint32_t grouped_columns(const DeviceBatch& b, bool units) {
     const uint32_t f = units ? b.max_unit_free : b.max_free;
     return f <= 16u ? 1u : f <= 32u ? 2u : 3u;
@@ -1481,6 +1717,7 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     // below that one wavefront per System finishes sooner.
     if (p.route_grouped == 0 || b.has_pose) return false;  // (cluster problems: the pose builds of the one-wavefront kernel)
     if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
+    if (p.lm.solver == FX_STEP_QR) return grouped_qr_applies(b, p, nullptr);
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     const bool units = (p.mode & MODE_UNITS) != 0;
     if (units && (!b.sys_unit_off || p.prof)) return false;
@@ -1495,6 +1732,7 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
 
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
+    if (p.lm.solver == FX_STEP_QR) return launch_grouped_qr(b, p, stream);
     const bool units = (p.mode & MODE_UNITS) != 0;
     const uint32_t nc = grouped_columns(b, units);
     const bool f32 = p.lm.precision == 32;

@@ -182,3 +182,44 @@ def test_two_runs_are_bit_identical_on_mixed_and_random_batches(fiksi, ctx, solv
         assert np.array_equal(_bits(a[0]), _bits(c[0])), grouped
         assert a[1].tobytes() == c[1].tobytes(), grouped
         runs.append(a)
+
+
+@pytest.mark.parametrize("shape", ["ring16", "ring16_gauge", "ring16_inconsistent", "hinged5", "hinged7", "mixed11"])
+def test_four_systems_per_wavefront_is_the_same_bits(fiksi, oracle, ctx, shape):
+    """Batches of ONE structure run FX_STEP_QR four Systems to a wavefront (fx_grouped.hip: lm_solve_grouped_qr_kernel, the
+    program of fx_abi.cpp: build_qrg_program — lanes over the active columns of each Householder step, the matrix stored by its
+    symbolic patterns): the same operations in the same order as the one-wavefront QR kernel, so every variable and every
+    result field is that kernel's bits (routing 0 / 1), with the lambda ladder on and off, and the oracle's on a sample (the
+    correctly rounded atan2 on both sides)."""
+    import helpers
+    from fiksi_amd import abi, workloads
+
+    b = {"ring16": lambda: workloads.ring16(2050), "ring16_gauge": lambda: workloads.ring16(1500, fix_gauge=True),
+         "ring16_inconsistent": lambda: workloads.ring16(1500, inconsistent=True), "hinged5": lambda: workloads.hinged_triangles(1100, 5),
+         "hinged7": lambda: workloads.hinged_triangles(1100, 7),
+         "mixed11": lambda: workloads.concat([helpers.mixed_sketch(3, fix_some=True).flatten()] * 1100)}[shape]()
+    o = abi.solving_opts(solver=2)
+    out = {}
+    try:
+        for tag, ladder in (("1", True), ("1", False), ("0", True)):
+            ctx.set_routing(int(tag))
+            ctx.set_ladder(ladder, 1 << 30, 4, True)
+            db = ctx.upload(b)
+            db.system_solve(o)
+            if shape != "mixed11":
+                assert db.solve_route(o) == int(tag)
+            out[(tag, ladder)] = (db.get_vars().copy(), db.get_results().copy())
+            db.free()
+    finally:
+        ctx.set_routing(-1)
+        ctx.set_ladder()
+    v0, r0 = out[("0", True)]
+    for key in (("1", True), ("1", False)):
+        v1, r1 = out[key]
+        assert np.array_equal(_bits(v1), _bits(v0)), key
+        assert r1.tobytes() == r0.tobytes(), key
+    sub = workloads.shard(b, 0, 64)
+    n = len(sub["var_off"]) - 1
+    with oracle.atan2_mode("correctly_rounded"):
+        v_o, res_o = oracle.solve_batch(sub, mode=3, nthreads=8)
+    _assert_identical(sub, out[("1", True)][0][: len(v_o)], out[("1", True)][1][:n], v_o, res_o)
