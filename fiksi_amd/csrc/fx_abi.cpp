@@ -1238,7 +1238,7 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 // side entry [13] longest vector (entries below the diagonal, padded to fours).
 struct QrgHostProgram {
     std::vector<uint32_t> words;
-    uint32_t n = 0, m = 0, nx = 0;
+    uint32_t n = 0, m = 0, nx = 0, ng = 0;
     bool ok = false;
 };
 bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, const uint32_t* rows, uint32_t m, const uint32_t* free_,
@@ -1287,7 +1287,7 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
     uint32_t nx = rhsbase + Mq + 1u;
     const uint32_t zero = nx - 1u;
     nx = (nx + 1u) & ~1u;
-    if (nx > 0xFFF0u) return false;
+    if (8u * nx > 0xFFF0u) return false;
     bool bad = false;
     auto at = [&](int r, uint32_t j) -> uint32_t {  // offset of entry (permuted row r, column position j; j == n: right-hand side)
         if (j == n) return rhsbase + (uint32_t)r;
@@ -1298,14 +1298,15 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
         }
         return cbase[j] + (uint32_t)(it - prow[j].begin());
     };
+    auto atb = [&](int r, uint32_t j) -> uint32_t { return 8u * at(r, j); };  // ... in bytes, as the kernel takes them
     std::vector<uint16_t> scat((size_t)m * 8, 0xFFFFu), rhs_off(m), damp(n), cpos16(n), bptr(n + 1, 0);
     for (uint32_t r = 0; r < m; ++r) {
         for (int q = 0; q < 8; ++q)
-            if (gcol[(size_t)r * 8 + q] >= 0) scat[(size_t)r * 8 + q] = (uint16_t)at(sy.row_perm[r], cpos[(uint32_t)gcol[(size_t)r * 8 + q]]);
-        rhs_off[r] = (uint16_t)at(sy.row_perm[r], n);
+            if (gcol[(size_t)r * 8 + q] >= 0) scat[(size_t)r * 8 + q] = (uint16_t)atb(sy.row_perm[r], cpos[(uint32_t)gcol[(size_t)r * 8 + q]]);
+        rhs_off[r] = (uint16_t)atb(sy.row_perm[r], n);
     }
     for (uint32_t c = 0; c < n; ++c) {
-        damp[c] = (uint16_t)at(sy.row_perm[m + c], cpos[c]);
+        damp[c] = (uint16_t)atb(sy.row_perm[m + c], cpos[c]);
         cpos16[c] = (uint16_t)cpos[c];
     }
     std::vector<uint32_t> steps(3 * (size_t)n, 0), ent, bent;
@@ -1320,22 +1321,22 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
             if (std::binary_search(sy.rrows.begin() + sy.rptr[j], sy.rrows.begin() + sy.rptr[j + 1] - 1, (int)k)) active.push_back(j);
         active.push_back(n);
         const uint32_t na = (uint32_t)active.size();
-        steps[3 * k] = at((int)k, k) | (len << 16);
+        steps[3 * k] = atb((int)k, k) | (len << 16);
         steps[3 * k + 1] = (uint32_t)ent.size();
         steps[3 * k + 2] = na;
         const size_t e0 = ent.size();
-        ent.resize(e0 + (size_t)(len + 1u) * na, zero | (zero << 16));
+        ent.resize(e0 + (size_t)(len + 1u) * na, (8u * zero) | ((8u * zero) << 16));
         for (uint32_t i = 0; i < na; ++i) {
-            ent[e0 + i] = at((int)k, active[i]);
+            ent[e0 + i] = atb((int)k, active[i]);
             for (uint32_t u = 0; u < below; ++u) {
                 const int r = sy.hrows[hb + 1 + (int)u];
-                ent[e0 + (size_t)(1u + u) * na + i] = at(r, active[i]) | (at(r, k) << 16);
+                ent[e0 + (size_t)(1u + u) * na + i] = atb(r, active[i]) | (atb(r, k) << 16);
             }
         }
     }
     for (uint32_t i = 0; i < n; ++i) {
         bptr[i] = (uint16_t)bent.size();
-        for (int p = sy.rptr[i]; p < sy.rptr[i + 1] - 1; ++p) bent.push_back(((uint32_t)sy.rrows[p] << 16) | at(sy.rrows[p], i));
+        for (int p = sy.rptr[i]; p < sy.rptr[i + 1] - 1; ++p) bent.push_back(((8u * (uint32_t)sy.rrows[p]) << 16) | atb(sy.rrows[p], i));
     }
     bptr[n] = (uint16_t)bent.size();
     if (bad || max_len > 32u) return false;
@@ -1359,11 +1360,23 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
     w[8] = put32(steps);
     w[9] = put16(bptr);
     w[10] = put32(bent);
+    {  // the Jacobian rows are kept compact: row r's entries start at gbase[r], one per variable of its expression kind
+        std::vector<uint16_t> gbase(m);
+        uint32_t ng = 0;
+        for (uint32_t r = 0; r < m; ++r) {
+            gbase[r] = (uint16_t)ng;
+            ng += (uint32_t)fx::tag_nvars<true>((int)(expr_tag[rows[r]] & 0x7F));
+        }
+        w[15] = put16(gbase);
+        out.ng = (ng + 1u) & ~1u;
+    }
+    w.resize((w.size() + 3u) & ~size_t(3), 0);
+    w[14] = (uint32_t)w.size();  // the small tables end here (the kernel keeps them in LDS); the per-entry words stay in global memory
     const uint32_t o_ent = put32(ent);
     for (uint32_t k = 0; k < n; ++k) w[w[8] + 3 * k + 1] += o_ent;  // entries' first word, from the start of the program
     w.resize((w.size() + 3u) & ~size_t(3), 0);
     w[11] = (uint32_t)w.size();
-    w[12] = rhsbase;
+    w[12] = 8u * rhsbase;
     w[13] = max_len;
     out.nx = nx;
     out.ok = true;
@@ -1561,6 +1574,8 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
     if (!rc && prog.ok) {
         rc = dev_alloc_copy(ctx, db, &q.qrg, prog.words.data(), prog.words.size());
         q.qrg_words = (uint32_t)prog.words.size();
+        q.qrg_small = prog.words[14];
+        q.qrg_ng = prog.ng;
         q.qrg_nx = prog.nx;
         q.qrg_n = prog.n;
         q.qrg_m = prog.m;

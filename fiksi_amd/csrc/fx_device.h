@@ -54,7 +54,7 @@ struct QrPlans {
     uint32_t max_h = 0;         // entries of the largest Householder structure
     // the grouped build's program (fx_abi.cpp: build_qrg_program), for a batch of one structure; null otherwise
     uint32_t* qrg = nullptr;
-    uint32_t qrg_words = 0, qrg_nx = 0, qrg_n = 0, qrg_m = 0;
+    uint32_t qrg_words = 0, qrg_small = 0, qrg_nx = 0, qrg_n = 0, qrg_m = 0, qrg_ng = 0;
 };
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt

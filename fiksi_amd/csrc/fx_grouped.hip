@@ -26,6 +26,8 @@
 // on the ring16 and hinged-triangle shapes (tests/test_gpu_grouped.py). DESIGN.md section 3.1a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 #include "fx_device.h"
@@ -52,7 +54,7 @@ struct GroupLayout {
 };
 
 static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max_rows, uint32_t es, uint32_t max_pairs_tri,
-                                     uint32_t max_ents, uint32_t qrg_words = 0, uint32_t qrg_nx = 0) {
+                                     uint32_t max_ents, uint32_t qrg_words = 0, uint32_t qrg_nx = 0, uint32_t qrg_ng = 0) {
     GroupLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -62,17 +64,18 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
     auto al = [](uint32_t bytes) { return (bytes + 15u) & ~15u; };
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += al(bytes); return at; };
     L.off_xs = take(L.vt * es);
-    const uint32_t tri = qrg_words ? 0u : n * (n + 1u) / 2u * es;  // (the QR build forms no normal equations)
+    // (the QR build forms no normal equations: no triangle, no right-hand side vector; its set-up scratch lies in the bytes of
+    // the matrix, which is written for the first time after the set-up)
+    const uint32_t tri = qrg_words ? qrg_nx * 8u : n * (n + 1u) / 2u * es;
     const uint32_t scratch = al(L.vt * 2u) + al(L.mr * 8u) + al(n * 2u);
     L.off_a = take(tri > scratch ? tri : scratch);
+    L.off_qx = L.off_a;
     L.off_colof = L.off_a;
     L.off_gcol = L.off_colof + al(L.vt * 2u);
     L.off_fidx = L.off_gcol + al(L.mr * 8u);
-    L.off_rhs = take(n * es);
-    // (the QR build keeps the rows of the current point beside those of the trial point: its step reads J and r at every
-    // trial, not only after an accepted one)
-    L.off_g = take(L.mr * 8u * es * (qrg_words ? 2u : 1u));
-    L.off_r = take(L.mr * es * (qrg_words ? 2u : 1u));
+    L.off_rhs = take(qrg_words ? 0u : n * es);
+    L.off_g = take(qrg_words ? qrg_ng * es : L.mr * 8u * es);  // (QR build: compact rows, one entry per variable of the kind)
+    L.off_r = take(L.mr * es);
     L.off_p = take(L.mr * es);
     L.off_gvar = take(L.mr * 16u);
     L.off_rtag = take(L.mr);
@@ -81,7 +84,6 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
     L.pe_cap = (max_ents + 7u) & ~7u;
     L.off_pw = take(L.pw_cap * 4u);
     L.off_pe = take(L.pe_cap * 2u);
-    L.off_qx = take(qrg_nx * 8u);
     L.tab_bytes = al(qrg_words * 4u);
     L.stride = o;
     return L;
@@ -357,7 +359,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     unsigned char* const rows0 = smem + L.tab_bytes;  // the four Systems' blocks, behind the shared program of the QR build
     unsigned char* base = rows0 + (uint32_t)(lane / RS) * L.stride;
     if constexpr (QRG) {  // the program of the batch's one structure, once per wavefront
-        const uint32_t nw = b.qr_none.qrg_words;
+        const uint32_t nw = b.qr_none.qrg_small;  // (the per-entry offsets of the steps stay in global memory: 13 KB, read by every
+                                                    // wavefront of the device and so at home in the L1 / L2 caches)
         const uint4* src = reinterpret_cast<const uint4*>(b.qr_none.qrg);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = lane; i < nw / 4u; i += 64) dst[i] = src[i];
@@ -407,7 +410,6 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     T sse = T(0), sse_start = T(0);
     double lambda = 0.0;
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
-    uint32_t cur = 0;    // QR build: which of the two row buffers holds the current point's Jacobian rows and residuals
     bool fresh = false;  // RUN evaluates the component's start point instead of a trial point
     uint32_t held = 0;   // passes this row has waited, done, for company (see FINISH)
     // The lambda ladder (prm.ladder). The trials that follow a plain reject read the same point, Jacobian and residuals
@@ -496,31 +498,42 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
         }
     };
 
-    auto eval_rows = [&](uint32_t buf) -> T {
-        T* G = reinterpret_cast<T*>(base + L.off_g) + (QRG ? buf * L.mr * 8u : 0u);
-        T* R = reinterpret_cast<T*>(base + L.off_r) + (QRG ? buf * L.mr : 0u);
+    // FULL: residuals and Jacobian rows of the point in XS, stored (a component's start point; in the QR build also the point
+    // of an accepted trial, evaluated a second time — its trial only needed the residuals, and so the rows of the CURRENT
+    // point, which every one of the QR step's trials reads, are never overwritten by a rejected one)
+    auto eval_rows = [&](auto full_c) -> T {
+        constexpr bool FULL = decltype(full_c)::value;
         T part[4] = {T(0), T(0), T(0), T(0)};
         for (uint32_t row = hl; row < m_rows; row += RS) {
             T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = XS[gvar[row * 8 + e]];
-            T r = eval_expression<T, true, QRG>(rtag[row], v, P[row], g);  // (QR build: the correctly rounded atan2)
-            R[row] = r;
+            T r = eval_expression<T, FULL, QRG>(rtag[row], v, P[row], g);  // (QR build: the correctly rounded atan2)
+            if constexpr (FULL) {
+                R[row] = r;
+                if constexpr (QRG) {  // compact: the entries of the row's kind only (the program's gbase)
+                    const uint32_t* TBq = reinterpret_cast<const uint32_t*>(smem);
+                    const uint32_t gb = reinterpret_cast<const uint16_t*>(TBq + TBq[15])[row];
+                    const int kk = tag_nvars<true>((int)rtag[row]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) G[row * 8 + e] = g[e];
+                    for (int e = 0; e < 8; ++e)
+                        if (e < kk) G[gb + (uint32_t)e] = g[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) G[row * 8 + e] = g[e];
+                }
+            }
             const T r2 = r * r;
             const uint32_t blk = (row >> 4) & 3u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) part[q] += (blk == (uint32_t)q) ? r2 : T(0);
         }
         group_sync();
-        if constexpr (QRG) {  // the reference's sum of squares, in index order (lm.rs:195-197)
+        if constexpr (QRG) {  // the reference's sum of squares, in index order (lm.rs:195-197): row 16 q + lane of block q
             double acc = 0.0;
-            for (uint32_t at = 0; at < m_rows; at += RS) {
-                const uint32_t row = at + (uint32_t)hl;
-                const double r = row < m_rows ? (double)R[row] : 0.0;  // (+ 0.0: exact)
-                seq_add(acc, r * r);
-            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((uint32_t)(RS * q) < m_rows) seq_add(acc, (double)part[q]);  // (rows past the end: + 0.0, exact)
             return (T)acc;
         } else {
             return block_sum4(part);
@@ -528,21 +541,20 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     };
     // One LM trial's step by the reference's QR, table-driven (build_qrg_program). Returns false when R has an exactly zero
     // diagonal entry (sparse_col_mat.rs:800-810); delta: this lane's free columns hl, hl + 16.
-    auto qr_step = [&](double lam, T (&delta)[NC], uint32_t buf) -> bool {
+    auto qr_step = [&](double lam, T (&delta)[NC]) -> bool {
         bool ok = true;
         if constexpr (QRG) {
-            const T* G = reinterpret_cast<const T*>(base + L.off_g) + buf * L.mr * 8u;
-            const T* R = reinterpret_cast<const T*>(base + L.off_r) + buf * L.mr;
             const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
-            const uint32_t qn = TB[0], qm = TB[1], nx = TB[2], rhsbase = TB[12];
+            const uint32_t qn = TB[0], qm = TB[1], nx = TB[2], rhsbase = TB[12];  // (offsets into the matrix are in BYTES)
             const uint16_t* scat = reinterpret_cast<const uint16_t*>(TB + TB[4]);
             const uint16_t* rhs_off = reinterpret_cast<const uint16_t*>(TB + TB[5]);
             const uint16_t* damp = reinterpret_cast<const uint16_t*>(TB + TB[6]);
-            const uint16_t* cposT = reinterpret_cast<const uint16_t*>(TB + TB[7]);
             const uint32_t* stepT = TB + TB[8];
             const uint16_t* bptr = reinterpret_cast<const uint16_t*>(TB + TB[9]);
             const uint32_t* bent = TB + TB[10];
-            double* X = reinterpret_cast<double*>(base + L.off_qx);
+            const uint32_t* ENT = b.qr_none.qrg;  // global
+            unsigned char* X = base + L.off_qx;
+            auto xat = [&](uint32_t byte_off) -> double& { return *reinterpret_cast<double*>(X + byte_off); };
             const double sl = ::sqrt(lam);  // lm.rs:119
             {
                 double2 z;
@@ -552,22 +564,24 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             group_sync();
             // J (duplicates of a row summed in gradient order, sparse_col_mat.rs:710-711) and b = -r (lm.rs:86-91,130);
             // the damping entry of every column (lm.rs:92-96,119-125)
+            const uint16_t* gbaseT = reinterpret_cast<const uint16_t*>(TB + TB[15]);
             for (uint32_t row = hl; row < qm; row += RS) {
+                const uint32_t gb = gbaseT[row];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t off = scat[row * 8 + e];
-                    if (off != 0xFFFFu) lds_add(&X[off], (double)G[row * 8 + e]);
+                    if (off != 0xFFFFu) lds_add(&xat(off), (double)G[gb + (uint32_t)e]);
                 }
-                X[rhs_off[row]] = -(double)R[row];
+                xat(rhs_off[row]) = -(double)R[row];
             }
-            for (uint32_t c = hl; c < qn; c += RS) X[damp[c]] = sl;
+            for (uint32_t c = hl; c < qn; c += RS) xat(damp[c]) = sl;
             group_sync();
             for (uint32_t k = 0; k < qn; ++k) {
                 const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k]);
                 const uint32_t ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k + 1]);
                 const uint32_t nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * k + 2]);
                 const uint32_t vdiag = w0 & 0xFFFFu, len = w0 >> 16;
-                const double v0 = X[vdiag];
+                const double v0 = xat(vdiag);
                 double norm = 0.0, beta = 0.0, v0n = 1.0;
                 // calculate_householder (qr.rs:244-275) on column k below the diagonal; every lane computes it
                 auto householder = [&](double sigma) {
@@ -582,7 +596,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 };
                 for (uint32_t i0 = 0; i0 < nact; i0 += RS) {
                     const bool act = i0 + (uint32_t)hl < nact;
-                    const uint32_t* e = TB + ent + (act ? i0 + (uint32_t)hl : 0u);  // (idle lanes follow column 0 and store nothing)
+                    const uint32_t* e = ENT + ent + (act ? i0 + (uint32_t)hl : 0u);  // (idle lanes follow column 0 and store nothing)
                     // the vector and this lane's column under it, NB blocks of four entries, fetched once (one copy of the
                     // body per block count, picked once per vector)
                     auto window = [&](auto nb_c) {
@@ -592,11 +606,11 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         const uint32_t wk0 = e[0];
 #pragma unroll
                         for (int u = 0; u < NE; ++u) w[u] = e[(uint32_t)(1 + u) * nact];
-                        const double xk0 = X[wk0];
+                        const double xk0 = xat(wk0);
 #pragma unroll
                         for (int u = 0; u < NE; ++u) {
-                            vk[u] = X[w[u] >> 16];
-                            xj[u] = X[w[u] & 0xFFFFu];
+                            vk[u] = xat(w[u] >> 16);
+                            xj[u] = xat(w[u] & 0xFFFFu);
                         }
                         double sigma = 0.0;
 #pragma unroll
@@ -609,9 +623,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                         for (int u = 0; u < NE; ++u) tau = tau + vk[u] * xj[u];
                         tau = tau * beta;
                         if (act) {
-                            X[wk0] = xk0 - v0n * tau;
+                            xat(wk0) = xk0 - v0n * tau;
 #pragma unroll
-                            for (int u = 0; u < NE; ++u) X[w[u] & 0xFFFFu] = xj[u] - vk[u] * tau;  // (padding: 0 - 0 tau into the zero slot)
+                            for (int u = 0; u < NE; ++u) xat(w[u] & 0xFFFFu) = xj[u] - vk[u] * tau;  // (padding: 0 - 0 tau into the zero slot)
                         }
                     };
                     switch (len >> 2) {
@@ -627,14 +641,14 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     }
                     group_sync();
                 }
-                if (hl == 0) X[vdiag] = norm;  // R's diagonal (qr.rs:319)
+                if (hl == 0) xat(vdiag) = norm;  // R's diagonal (qr.rs:319)
                 group_sync();
             }
             // back substitution with R (sparse_col_mat.rs:788-826), in place on the right-hand side: column i of R from the
             // last to the first, one lane per entry above the diagonal
             {
                 bool zero_diag = false;
-                for (uint32_t c = hl; c < qn; c += RS) zero_diag = zero_diag || X[stepT[3 * c] & 0xFFFFu] == 0.0;
+                for (uint32_t c = hl; c < qn; c += RS) zero_diag = zero_diag || xat(stepT[3 * c] & 0xFFFFu) == 0.0;
                 ok = gballot(zero_diag) == 0u;
             }
             if (ok) {
@@ -643,13 +657,13 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     const uint32_t dgo = (uint32_t)__builtin_amdgcn_readfirstlane((int)stepT[3 * i]) & 0xFFFFu;
                     const uint32_t eb = (uint32_t)__builtin_amdgcn_readfirstlane((int)bptr[i]);
                     const uint32_t ee = (uint32_t)__builtin_amdgcn_readfirstlane((int)bptr[i + 1]);
-                    const double coeff = X[rhsbase + i] / X[dgo];
+                    const double coeff = xat(rhsbase + 8u * i) / xat(dgo);
                     for (uint32_t t = eb + (uint32_t)hl; t < ee; t += RS) {
                         const uint32_t wv = bent[t];
                         const uint32_t yo = rhsbase + (wv >> 16);
-                        X[yo] = X[yo] - coeff * X[wv & 0xFFFFu];
+                        xat(yo) = xat(yo) - coeff * xat(wv & 0xFFFFu);
                     }
-                    if (hl == 0) X[rhsbase + i] = coeff;
+                    if (hl == 0) xat(rhsbase + 8u * i) = coeff;
                     group_sync();
                 }
             }
@@ -657,7 +671,8 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 const uint32_t c = (uint32_t)(hl + RS * q);
-                delta[q] = (ok && c < qn) ? (T)X[rhsbase + cposT[c < qn ? c : 0u]] : T(0);
+                const uint16_t* cposT = reinterpret_cast<const uint16_t*>(TB + TB[7]);
+                delta[q] = (ok && c < qn) ? (T)xat(rhsbase + 8u * (uint32_t)cposT[c < qn ? c : 0u]) : T(0);
             }
             group_sync();
         }
@@ -1189,7 +1204,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                             const auto t = lane_get(v, srcl);
                             if (joining) v = t;
                         };
-                        cp(nfree); cp(m_rows); cp(n_pw); cp(n_pe); cp(trials); cp(accepted); cp(outer); cp(exit_code); cp(cur);
+                        cp(nfree); cp(m_rows); cp(n_pw); cp(n_pe); cp(trials); cp(accepted); cp(outer); cp(exit_code);
                         cp(sse); cp(lambda);
 #pragma unroll
                         for (int q = 0; q < NC; ++q) {
@@ -1253,7 +1268,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                     go = false;
                 }
                 if constexpr (QRG) {
-                    if (go && !qr_step(lam_k, delta, cur)) {  // lm.rs:134-137
+                    if (go && !qr_step(lam_k, delta)) {  // lm.rs:134-137
                         code = LC_SINGULAR;
                         go = false;
                     }
@@ -1344,7 +1359,12 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             }
             T sse_t = T(0);
             if (go) {
-                sse_t = eval_rows(fresh ? cur : cur ^ 1u);
+                if constexpr (QRG) {
+                    if (fresh) sse_t = eval_rows(std::true_type{});
+                    else sse_t = eval_rows(std::false_type{});
+                } else {
+                    sse_t = eval_rows(std::true_type{});
+                }
                 stamp(GH_EVAL);
                 if (!fresh) {
                     if (sse_t < sse) {
@@ -1448,22 +1468,26 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 }
             }
             if (assemble) {
-                if constexpr (LADDER) {
+                if constexpr (QRG) {
+                    if (!fresh) {  // the accepted point once more, with its Jacobian rows (every row of a ladder group for itself)
+#pragma unroll
+                        for (int q = 0; q < NC; ++q)
+                            if ((uint32_t)(hl + RS * q) < nfree) XS[my_vi[q]] = xc[q];
+                        group_sync();
+                        (void)eval_rows(std::true_type{});
+                    }
+                } else if constexpr (LADDER) {
                     if (win_row != myrow) {  // the accepted point's Jacobian rows and residuals are another row's
                         using V = typename Vec16<T>::type;
                         const unsigned char* wb = rows0 + (uint32_t)win_row * L.stride;
-                        const uint32_t tb = QRG ? (cur ^ 1u) : 0u;  // (QR build: the trial buffer, the same one in every row of a group)
-                        const V* gs = reinterpret_cast<const V*>(reinterpret_cast<const T*>(wb + L.off_g) + tb * L.mr * 8u);
-                        V* gd = reinterpret_cast<V*>(G + tb * L.mr * 8u);
+                        const V* gs = reinterpret_cast<const V*>(wb + L.off_g);
+                        V* gd = reinterpret_cast<V*>(G);
                         const uint32_t ng = m_rows * 8u / (uint32_t)Vec16<T>::n;
                         for (uint32_t i = hl; i < ng; i += RS) gd[i] = gs[i];
-                        const T* rs = reinterpret_cast<const T*>(wb + L.off_r) + tb * L.mr;
-                        for (uint32_t i = hl; i < m_rows; i += RS) R[tb * L.mr + i] = rs[i];
+                        const T* rs = reinterpret_cast<const T*>(wb + L.off_r);
+                        for (uint32_t i = hl; i < m_rows; i += RS) R[i] = rs[i];
                         group_sync();
                     }
-                }
-                if constexpr (QRG) {
-                    if (!fresh) cur ^= 1u;  // the trial point's rows are the current point's from now on
                 }
                 if constexpr (!QRG) form_normal();  // (the QR step takes J and r as they are)
                 stamp(GH_FORM);
@@ -1662,7 +1686,7 @@ static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLay
     if (p.lm.solver != FX_STEP_QR || !Q.qrg || !b.uniform || b.u_ncomp != 1u || p.lm.precision == 32 || p.prof) return false;
     if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 32u || b.max_rows > 64u || b.max_vars > 64u || !b.work_counter) return false;
     if (Q.qrg_n != b.max_free || Q.qrg_m != b.max_rows) return false;
-    const GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_words, Q.qrg_nx);
+    const GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_small, Q.qrg_nx, Q.qrg_ng);
     if ((size_t)L.tab_bytes + 4u * (size_t)L.stride > 160u * 1024u / 2u) return false;  // two wavefronts per CU at least
     if (out) *out = L;
     return true;
@@ -1672,6 +1696,10 @@ static hipError_t launch_grouped_qr(const DeviceBatch& b, const LmParams& p, hip
     GroupLayout L;
     if (!grouped_qr_applies(b, p, &L)) return hipErrorInvalidValue;
     const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
+    static const bool trace = getenv("FIKSI_AMD_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[fiksi_amd] grouped QR: %u B of LDS per wavefront (tables %u, 4 x %u per System: matrix %u doubles), program %u words\n",
+                per_wave, L.tab_bytes, L.stride, b.qr_none.qrg_nx, b.qr_none.qrg_words);
     static unsigned int raised = 0;
     hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_qr_kernel), &raised);
     if (e != hipSuccess) return e;
