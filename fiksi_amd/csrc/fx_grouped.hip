@@ -26,6 +26,7 @@
 // on the ring16 and hinged-triangle shapes (tests/test_gpu_grouped.py). DESIGN.md section 3.1a.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -51,6 +52,7 @@ struct GroupLayout {
     // the FX_STEP_QR build: the program of the batch's one structure (shared by the wavefront, at the start of its LDS) and a
     // System's matrix stored by its symbolic patterns
     uint32_t tab_bytes, off_qx;
+    uint32_t ent_in_lds;  // the steps' per-entry words are part of the LDS copy (they fit beside four wavefronts per CU)
 };
 
 static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max_rows, uint32_t es, uint32_t max_pairs_tri,
@@ -85,6 +87,7 @@ static GroupLayout make_group_layout(uint32_t n, uint32_t max_vars, uint32_t max
     L.off_pw = take(L.pw_cap * 4u);
     L.off_pe = take(L.pe_cap * 2u);
     L.tab_bytes = al(qrg_words * 4u);
+    L.ent_in_lds = 0u;
     L.stride = o;
     return L;
 }
@@ -359,8 +362,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
     unsigned char* const rows0 = smem + L.tab_bytes;  // the four Systems' blocks, behind the shared program of the QR build
     unsigned char* base = rows0 + (uint32_t)(lane / RS) * L.stride;
     if constexpr (QRG) {  // the program of the batch's one structure, once per wavefront
-        const uint32_t nw = b.qr_none.qrg_small;  // (the per-entry offsets of the steps stay in global memory: 13 KB, read by every
-                                                    // wavefront of the device and so at home in the L1 / L2 caches)
+        // (the per-entry offsets of the steps — 13 KB for the headline shape — stay in global memory when they do not fit beside
+        // four wavefronts per CU: read by every wavefront of the device, they are at home in the L1 / L2 caches)
+        const uint32_t nw = L.ent_in_lds ? b.qr_none.qrg_words : b.qr_none.qrg_small;
         const uint4* src = reinterpret_cast<const uint4*>(b.qr_none.qrg);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (uint32_t i = lane; i < nw / 4u; i += 64) dst[i] = src[i];
@@ -552,7 +556,7 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
             const uint32_t* stepT = TB + TB[8];
             const uint16_t* bptr = reinterpret_cast<const uint16_t*>(TB + TB[9]);
             const uint32_t* bent = TB + TB[10];
-            const uint32_t* ENT = b.qr_none.qrg;  // global
+            const uint32_t* ENT = L.ent_in_lds ? TB : b.qr_none.qrg;
             unsigned char* X = base + L.off_qx;
             auto xat = [&](uint32_t byte_off) -> double& { return *reinterpret_cast<double*>(X + byte_off); };
             const double sl = ::sqrt(lam);  // lm.rs:119
@@ -1686,8 +1690,20 @@ static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLay
     if (p.lm.solver != FX_STEP_QR || !Q.qrg || !b.uniform || b.u_ncomp != 1u || p.lm.precision == 32 || p.prof) return false;
     if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 32u || b.max_rows > 64u || b.max_vars > 64u || !b.work_counter) return false;
     if (Q.qrg_n != b.max_free || Q.qrg_m != b.max_rows) return false;
-    const GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_small, Q.qrg_nx, Q.qrg_ng);
+    GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_small, Q.qrg_nx, Q.qrg_ng);
     if ((size_t)L.tab_bytes + 4u * (size_t)L.stride > 160u * 1024u / 2u) return false;  // two wavefronts per CU at least
+    {  // the whole program in LDS when that costs no wavefront (FIKSI_AMD_QR_TABLES=lds|global forces either: measurements)
+        const GroupLayout Lw = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_words, Q.qrg_nx, Q.qrg_ng);
+        const size_t small_bytes = (size_t)L.tab_bytes + 4u * (size_t)L.stride, whole_bytes = (size_t)Lw.tab_bytes + 4u * (size_t)Lw.stride;
+        static const char* force = getenv("FIKSI_AMD_QR_TABLES");
+        bool whole = whole_bytes <= 160u * 1024u && (160u * 1024u) / whole_bytes >= std::min<size_t>(4, (160u * 1024u) / small_bytes);
+        if (force && force[0] == 'l' && whole_bytes <= 80u * 1024u) whole = true;
+        if (force && force[0] == 'g') whole = false;
+        if (whole) {
+            L = Lw;
+            L.ent_in_lds = 1u;
+        }
+    }
     if (out) *out = L;
     return true;
 }
