@@ -27,6 +27,8 @@ stats headline_kernel_stats python3 tools/solve_only.py 100000 10
 echo "[collect] cfg2 resident, the reference's 64-triangle sketch x 256"
 stats cfg2_kernel_stats python3 tools/cfg2_resident.py 3
 stats hinged64_kernel_stats python3 tools/hinged_batch.py 64 256 5
+stats qr_kernel_stats python3 tools/qr_once.py 100000 3
+stats shard12500_kernel_stats python3 tools/solve_only.py 12500 10
 echo "[collect] HBM counters, 100k and 500k Systems"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/k1_once.py 100000 3 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/k1_once.py 100000 3 > $OUT/pmc_write.log 2>&1
