@@ -545,7 +545,8 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     // against 0.36 ms) and cost half a microsecond per System at any size, which only the wide kernel's four-per-CU case
     // beats, and only from a thousand Systems on. By cost, measured on the reference's hinged-triangle sketches of 66 / 98 /
     // 126 variables, 1 ... 20 000 per batch (tools/hinged_batch.py):
-    //   team  = max(0.18 ms, n (0.49 us + 0.0011 (c - 66)))
+    //   team  = max(0.18 ms, n (0.49 us + 0.0011 (c - 66)))   below 768 Systems (16 wavefronts per System);
+    //           max(0.30 ms, n (0.19 us + 0.0014 (c - 66)))   from there on (2 / 4 wavefronts per System, round 4)
     //   wide  = ceil(n / (256 CUs x Systems per CU)) x (0.37 ms + 0.0123 (c - 66))
     // Both follow the reference's iteration path; they sum in different orders, so which one ran shows in the last bits (as it does
     // for a large System alone / among seven others): fx_ctx_set_wide_routing(ctx, 0 | 1) pins it.
@@ -560,7 +561,9 @@ int analyze(const fx_batch* b, HostPlan* plan) {
             const size_t lds = fx::wide_lds_bytes(probe);
             const double per_cu = lds ? std::min<double>(4., std::floor(160. * 1024. / (double)lds)) : 1.;
             const double c = (double)p.w_max_free - 66., nw = (double)p.wide_list.size();
-            const double team_ms = std::max(0.18, nw * (0.49e-3 + 1.1e-6 * c));
+            // (round 4: from 768 Systems on the team kernels run 2 / 4 wavefronts per System instead of 16 — fx_sparse.hip:
+            // team_waves_for — 0.19 us per 66-variable System, 0.27 per 126-variable one)
+            const double team_ms = nw < 768. ? std::max(0.18, nw * (0.49e-3 + 1.1e-6 * c)) : std::max(0.30, nw * (0.19e-3 + 1.4e-6 * c));
             const double wide_ms = std::ceil(nw / (256. * std::max(per_cu, 1.))) * (0.37 + 0.0123 * c);
             team = team_ms < wide_ms;
         }

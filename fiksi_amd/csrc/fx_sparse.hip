@@ -548,7 +548,7 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
 
 constexpr size_t TEAM_LDS_VALUES_MAX = size_t(140) << 10;  // of the CU's 160 KB
 
-template <bool POSE, bool LDSV, bool BLOB>
+template <bool POSE, bool LDSV, bool BLOB, int NW>
 hipError_t launch_team_t(uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l, uint32_t lds_v,
                          const uint32_t* blob, uint32_t blob_words, unsigned long long* prof) {
@@ -559,21 +559,48 @@ hipError_t launch_team_t(uint32_t n, size_t lds_bytes, hipStream_t stream, const
     (void)hipGetDevice(&dev);
     const uint32_t bit = 1u << (dev & 31);
     if (LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)TEAM_LDS_VALUES_MAX);
         if (e != hipSuccess) return e;
         raised_on.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV, BLOB>), dim3(n), dim3(TEAM_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
-                       lds_l, lds_v, blob, blob_words, prof);
+    // a narrow team's partial sums of team_sumsq: a power of two that covers the block's rows and columns, behind the rest
+    uint32_t red_n = 0, red_off = 0;
+    if (NW != TEAM_NWAVES) {
+        red_n = 64u;
+        while (red_n < std::max(B.m, B.nv) && red_n < (uint32_t)TEAM_THREADS) red_n <<= 1;
+        red_off = (uint32_t)((lds_bytes + 7u) / 8u);
+        lds_bytes = (size_t)red_off * 8u + (size_t)red_n * 8u;
+        if (lds_bytes > TEAM_LDS_VALUES_MAX + 8192u) return hipErrorInvalidValue;
+        if (!LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) raised_on.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV, BLOB, NW>), dim3(n), dim3(64 * NW), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
+                       lds_l, lds_v, blob, blob_words, prof, red_off, red_n);
     return hipGetLastError();
+}
+// Wavefronts per System: 16 run one System (or a few hundred) at the lowest latency; a batch of many Systems takes fewer —
+// more workgroups to a CU (two of 16 wavefronts fit), narrower barriers. Measured on the reference's hinged-triangle sketches
+// (tools/hinged_batch.py, ms per batch at 16 / 8 / 4 / 2 / 1 wavefronts): 66 variables x 20 000: 10.4 / 6.6 / 4.8 / 3.8 / 4.5
+// (x 256: 0.19 / - / 0.26 / 0.33 / 0.47); 126 variables x 8 192: 4.6 / 3.1 / 2.2 / 2.9 / 4.8; 258 variables x 2 048: 1.8 / 1.4 /
+// 1.8 / 2.6 / -. FIKSI_AMD_TEAM_WAVES=1|2|4|8|16 pins one (measurements). Which wavefront walks a column changes nothing in
+// its arithmetic: same bits at any width (tests/test_gpu_team.py).
+static int team_waves_for(uint32_t n_systems, uint32_t nv) {
+    static const int forced = [] { const char* e = std::getenv("FIKSI_AMD_TEAM_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) return forced;
+    if (n_systems < 768u) return 16;
+    return nv <= 100u ? 2 : nv <= 200u ? 4 : nv <= 640u ? 8 : 16;
 }
 hipError_t launch_team(bool pose, bool ldsv, bool blob_in_lds, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B,
                        const SpVals& V, SpAccum* accum, const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, uint32_t lds_l,
                        uint32_t lds_v, const uint32_t* blob, uint32_t blob_words, unsigned long long* prof) {
-#define FX_TEAM(P, L, K) launch_team_t<P, L, K>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, blob, blob_words, prof)
-    if (pose) return !ldsv ? FX_TEAM(true, false, false) : blob_in_lds ? FX_TEAM(true, true, true) : FX_TEAM(true, true, false);
-    return !ldsv ? FX_TEAM(false, false, false) : blob_in_lds ? FX_TEAM(false, true, true) : FX_TEAM(false, true, false);
+#define FX_TEAM(P, L, K, W) launch_team_t<P, L, K, W>(n, lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, lds_l, lds_v, blob, blob_words, prof)
+    const int tw = pose ? 16 : team_waves_for(n, B.nv);
+    if (tw == 4) return !ldsv ? FX_TEAM(false, false, false, 4) : blob_in_lds ? FX_TEAM(false, true, true, 4) : FX_TEAM(false, true, false, 4);
+    if (tw == 1) return !ldsv ? FX_TEAM(false, false, false, 1) : blob_in_lds ? FX_TEAM(false, true, true, 1) : FX_TEAM(false, true, false, 1);
+    if (tw == 2) return !ldsv ? FX_TEAM(false, false, false, 2) : blob_in_lds ? FX_TEAM(false, true, true, 2) : FX_TEAM(false, true, false, 2);
+    if (tw == 8) return !ldsv ? FX_TEAM(false, false, false, 8) : blob_in_lds ? FX_TEAM(false, true, true, 8) : FX_TEAM(false, true, false, 8);
+    if (pose) return !ldsv ? FX_TEAM(true, false, false, 16) : blob_in_lds ? FX_TEAM(true, true, true, 16) : FX_TEAM(true, true, false, 16);
+    return !ldsv ? FX_TEAM(false, false, false, 16) : blob_in_lds ? FX_TEAM(false, true, true, 16) : FX_TEAM(false, true, false, 16);
 #undef FX_TEAM
 }
 

@@ -398,11 +398,28 @@ __device__ __forceinline__ void team_walk_down(const SpChol& c, const ColDesc* c
 // A segment's factorization + forward sweep by the calling workgroup: levels bottom-up, a barrier after each; a
 // wavefront walks its run of columns of the level, and loads the descriptions of its next run before the barrier.
 // Returns (to every thread of a wavefront) whether its pivots were fine.
-template <bool LDSV, bool FACTOR, bool BLOB = false>
+// NW: the wavefronts of the calling workgroup. The schedules are built for TEAM_NWAVES = 16; a narrower team (the builds for
+// many small Systems side by side, sp_lm_team_kernel<..., 4>) gives each of its wavefronts every NW-th list of a level.
+// Which wavefront walks a column changes nothing in its arithmetic: same bits.
+template <bool LDSV, bool FACTOR, bool BLOB = false, int NW = TEAM_NWAVES>
 __device__ __forceinline__ bool team_factor_forward(const SpChol& c, const SpRowsOfL& lr, const SpTeamSched& sc, uint32_t seg,
                                                     double lambda, double* l, double* b, double* s_acc, unsigned long long* wprof = nullptr,
                                                     uint32_t lb = 0, uint32_t cb = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (NW != TEAM_NWAVES) {
+        bool ok = true;
+        for (uint32_t q = sc.seg_lev[seg]; q < sc.seg_lev[seg + 1]; ++q) {
+            for (uint32_t vw = (uint32_t)wave; vw < (uint32_t)TEAM_NWAVES; vw += (uint32_t)NW) {
+                const uint32_t t0 = sc.wptr[q * TEAM_NWAVES + vw], t1 = sc.wptr[q * TEAM_NWAVES + vw + 1];
+                if (t0 >= t1) continue;
+                ColDesc mine{};
+                if (t0 + lane < t1) mine = sc.cdesc[t0 + lane];
+                ok = team_walk_up<LDSV, FACTOR, BLOB>(c, lr, sc.cdesc, t0, t1, mine, lambda, l, b, s_acc + wave * 64, lane, lb, cb) && ok;
+            }
+            __syncthreads();
+        }
+        return ok;
+    }
     const bool wstamp = wprof && threadIdx.x == 0;  // diagnostics: wavefront 0's walk / barrier time, level 0 and above
     bool ok = true;
     uint32_t q = sc.seg_lev[seg];
@@ -437,7 +454,7 @@ __device__ __forceinline__ bool team_factor_forward(const SpChol& c, const SpRow
     return ok;
 }
 
-template <bool LDSV, bool USE_MID = false, bool BLOB = false>
+template <bool LDSV, bool USE_MID = false, bool BLOB = false, int NW = TEAM_NWAVES>
 __device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched& sc, uint32_t seg, const double* l, double* b, uint32_t lb = 0,
                                               uint32_t cb = 0) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -450,6 +467,18 @@ __device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched
         if ((uint32_t)lane < nb) d = sc.cdesc[a1 - nb + lane];
         return d;
     };
+    if constexpr (NW != TEAM_NWAVES) {
+        for (; q-- > qbeg;) {
+            for (uint32_t vw = (uint32_t)wave; vw < (uint32_t)TEAM_NWAVES; vw += (uint32_t)NW) {
+                const uint32_t t0 = sc.wptr[q * TEAM_NWAVES + vw], t1 = sc.wptr[q * TEAM_NWAVES + vw + 1];
+                if (t0 >= t1) continue;
+                ColDesc mine = load_last(t0, t1);
+                team_walk_down<LDSV, USE_MID, BLOB>(c, sc.cdesc, t0, t1, mine, l, b, lane, lb, cb);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     uint32_t t0 = sc.wptr[(q - 1) * TEAM_NWAVES + wave], t1 = sc.wptr[(q - 1) * TEAM_NWAVES + wave + 1];
     ColDesc mine = load_last(t0, t1);
     for (; q-- > qbeg;) {
@@ -469,10 +498,10 @@ __device__ __forceinline__ void team_backward(const SpChol& c, const SpTeamSched
 }
 
 // A segment blob (fx_sparse_plan.h: SegmentBlobs), copied into LDS by the whole workgroup, and the views the walkers take
-__device__ __forceinline__ void team_load_blob(const uint32_t* __restrict__ g, uint32_t* s, uint32_t nwords) {
+__device__ __forceinline__ void team_load_blob(const uint32_t* __restrict__ g, uint32_t* s, uint32_t nwords, uint32_t nthreads = TEAM_THREADS) {
     const uint4* g4 = reinterpret_cast<const uint4*>(g);
     uint4* s4 = reinterpret_cast<uint4*>(s);
-    for (uint32_t i = threadIdx.x; i < nwords / 4u; i += TEAM_THREADS) s4[i] = g4[i];
+    for (uint32_t i = threadIdx.x; i < nwords / 4u; i += nthreads) s4[i] = g4[i];
 }
 __device__ __forceinline__ void team_blob_views(const uint32_t* s, SpChol& c, SpRowsOfL& lr, SpTeamSched& sc) {
     c.lcolptr = nullptr;
@@ -602,10 +631,31 @@ __device__ __forceinline__ void team_form_segment(const SpBlock& B, const double
 }
 
 // sum v[i]^2 with the shape of sp_sumsq_kernel (1024 strided partial sums, then a binary tree): same bits
-__device__ __forceinline__ double team_sumsq(const double* v, uint32_t n, double* s_red) {
-    double s = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += TEAM_THREADS) s += v[i] * v[i];
-    return block_sum_1024(s, s_red);
+template <int NW = TEAM_NWAVES>
+__device__ __forceinline__ double team_sumsq(const double* v, uint32_t n, double* s_red, uint32_t red_n = TEAM_THREADS) {
+    if constexpr (NW == TEAM_NWAVES) {
+        double s = 0.0;
+        for (uint32_t i = threadIdx.x; i < n; i += TEAM_THREADS) s += v[i] * v[i];
+        return block_sum_1024(s, s_red);
+    } else {
+        // a narrower team: the same 1024 strided partial sums and the same tree, several per thread. Of a vector shorter
+        // than red_n (a power of two, at most 1024) only the first red_n partial sums are not zero, and the tree's steps
+        // above red_n would add + 0.0 to sums of squares — exact — so the tree starts at red_n: red_n doubles of LDS, not 1024
+        constexpr uint32_t NT = 64u * (uint32_t)NW;
+        for (uint32_t p = threadIdx.x; p < red_n; p += NT) {
+            double s = 0.0;
+            for (uint32_t i = p; i < n; i += TEAM_THREADS) s += v[i] * v[i];
+            s_red[p] = s;
+        }
+        __syncthreads();
+        for (uint32_t w = red_n >> 1; w > 0; w >>= 1) {
+            for (uint32_t p = threadIdx.x; p < w; p += NT) s_red[p] += s_red[p + w];
+            __syncthreads();
+        }
+        const double out = s_red[0];
+        __syncthreads();
+        return out;
+    }
 }
 
 // K1 / K2 for one row of a block (subsystem.rs:93-166), the body of sp_eval_kernel
@@ -764,11 +814,14 @@ __device__ __forceinline__ void team_refill(const SpBlock& B, const double* a, c
 // step of a column's dependent chain is then an LDS round trip instead of an L2 one. The host picks it when they fit.
 // BLOB (with LDSV): the factor's index data sits in LDS as well, copied once for the whole solve (fx_sparse_plan.h:
 // SegmentBlobs) — a column's chain then touches HBM not at all.
-template <bool POSE, bool LDSV, bool BLOB>
-__global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum,
+// NW: wavefronts per System — 16 for one System (or few) at the lowest latency, 4 for batches of small Systems: eight
+// workgroups to a CU instead of two, and barriers a quarter as wide. Same bits either way.
+template <bool POSE, bool LDSV, bool BLOB, int NW = TEAM_NWAVES>
+__global__ __launch_bounds__(64 * NW) void sp_lm_team_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum,
                                                                    fx_lm_opts o, uint32_t flags, double* __restrict__ vars_base,
                                                                    const uint64_t* __restrict__ out_off, uint32_t lds_l, uint32_t lds_v,
-                                                                   const uint32_t* __restrict__ blob, uint32_t blob_words, unsigned long long* prof) {
+                                                                   const uint32_t* __restrict__ blob, uint32_t blob_words, unsigned long long* prof,
+                                                                   uint32_t red_off, uint32_t red_n) {
     // prof (diagnostics, FIKSI_AMD_TEAM_PROF=1; else null): workgroup 0 adds up the 100 MHz ticks of its phases
     const bool stamp = prof && blockIdx.x == 0 && threadIdx.x == 0;
     unsigned long long t_prev = stamp ? wall_clock64() : 0ull;
@@ -780,8 +833,11 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
         }
     };
     extern __shared__ double s_dyn[];
-    __shared__ double s_acc[TEAM_NWAVES * 64];
-    __shared__ double s_red[TEAM_THREADS];
+    constexpr uint32_t NT = 64u * (uint32_t)NW;
+    __shared__ double s_acc[NW * 64];
+    __shared__ double s_red_all[NW == TEAM_NWAVES ? TEAM_THREADS : 1];
+    // (a narrow team keeps team_sumsq's partial sums in dynamic LDS, red_n of them at red_off doubles: see team_sumsq)
+    double* const s_red = NW == TEAM_NWAVES ? s_red_all : s_dyn + red_off;
     __shared__ uint32_t s_bad;
     const uint32_t sys = blockIdx.x, tid = threadIdx.x;
     V.shift(sys);
@@ -796,70 +852,70 @@ __global__ __launch_bounds__(TEAM_THREADS) void sp_lm_team_kernel(SpRows rows, S
     SpTeamSched sched = B.sched;
     if (BLOB) {
         uint32_t* s_blob = reinterpret_cast<uint32_t*>(s_dyn + lds_l + 2 * lds_v);
-        team_load_blob(blob, s_blob, blob_words);
+        team_load_blob(blob, s_blob, blob_words, NT);
         __syncthreads();
         team_blob_views(s_blob, chol, lrows, sched);
     }
 
-    for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, V.xs0, V.r0, V.j0);
+    for (uint32_t row = tid; row < m; row += NT) team_eval_row<POSE>(rows, sparam, B.jac, row, V.xs0, V.r0, V.j0);
     __syncthreads();
     SpLm st;
-    lm_state_init(st, team_sumsq(V.r0, m, s_red), o);
+    lm_state_init(st, team_sumsq<NW>(V.r0, m, s_red, red_n), o);
     mark(0);
     while (!st.done) {
         const double* jc = st.cur ? V.j1 : V.j0;
         const double* rc = st.cur ? V.r1 : V.r0;
-        if (st.need_form) team_form(B, jc, rc, V.a, V.rhs, dvec, fl, tid, TEAM_THREADS, wave, TEAM_NWAVES);
-        else team_refill(B, V.a, V.rhs, dvec, fl, tid, TEAM_THREADS);
+        if (st.need_form) team_form(B, jc, rc, V.a, V.rhs, dvec, fl, tid, NT, wave, NW);
+        else team_refill(B, V.a, V.rhs, dvec, fl, tid, NT);
         if (tid == 0) s_bad = 0;
         __syncthreads();
         mark(1);
-        const bool ok = team_factor_forward<LDSV, true, BLOB>(chol, lrows, sched, 0, st.lambda, fl, dvec, s_acc, stamp ? prof + 8 : nullptr);
+        const bool ok = team_factor_forward<LDSV, true, BLOB, NW>(chol, lrows, sched, 0, st.lambda, fl, dvec, s_acc, stamp ? prof + 8 : nullptr);
         if (!ok && (tid & 63) == 0) atomicOr(&s_bad, 1u);
         __syncthreads();
         st.flag = s_bad;
         __syncthreads();  // (s_bad is cleared again at the top of the next trial)
         mark(2);
         if (!st.flag) {
-            team_backward<LDSV, false, BLOB>(chol, sched, 0, fl, dvec);
+            team_backward<LDSV, false, BLOB, NW>(chol, sched, 0, fl, dvec);
             mark(3);
             if (flags & TEAM_REFINED) {  // corrected semi-normal equations, as sp_refine_*: t = -r - J delta, (A + lambda I) e = Jt t - lambda delta
-                for (uint32_t row = tid; row < m; row += TEAM_THREADS) {
+                for (uint32_t row = tid; row < m; row += NT) {
                     double acc = -rc[row];
                     for (uint32_t p = B.jac.jrow_ptr[row]; p < B.jac.jrow_ptr[row + 1]; ++p) acc -= jc[p] * dvec[B.jcol[p]];
                     V.t[row] = acc;
                 }
                 __syncthreads();
-                for (uint32_t c = tid; c < nv; c += TEAM_THREADS) {
+                for (uint32_t c = tid; c < nv; c += NT) {
                     double s = 0.0;
                     for (uint32_t p = B.cptr[c]; p < B.cptr[c + 1]; ++p) s += jc[B.cidx[p]] * V.t[B.crow[p]];
                     evec[c] = s - st.lambda * dvec[c];
                 }
                 __syncthreads();
-                team_factor_forward<LDSV, false, BLOB>(chol, lrows, sched, 0, 0.0, fl, evec, s_acc);
-                team_backward<LDSV, false, BLOB>(chol, sched, 0, fl, evec);
-                for (uint32_t c = tid; c < nv; c += TEAM_THREADS) dvec[c] += evec[c];
+                team_factor_forward<LDSV, false, BLOB, NW>(chol, lrows, sched, 0, 0.0, fl, evec, s_acc);
+                team_backward<LDSV, false, BLOB, NW>(chol, sched, 0, fl, evec);
+                for (uint32_t c = tid; c < nv; c += NT) dvec[c] += evec[c];
                 __syncthreads();
                 mark(4);
             }
-            st.dn2 = team_sumsq(dvec, nv, s_red);
+            st.dn2 = team_sumsq<NW>(dvec, nv, s_red, red_n);
             const double* xc = st.cur ? V.xs1 : V.xs0;
             double* xt = st.cur ? V.xs0 : V.xs1;
-            for (uint32_t k = tid; k < nv; k += TEAM_THREADS) {
+            for (uint32_t k = tid; k < nv; k += NT) {
                 const uint32_t v = B.fvar[B.perm[k]];
                 xt[v] = xc[v] + dvec[k];
             }
             __syncthreads();
             double* rt = st.cur ? V.r0 : V.r1;
             double* jt = st.cur ? V.j0 : V.j1;
-            for (uint32_t row = tid; row < m; row += TEAM_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, xt, rt, jt);
+            for (uint32_t row = tid; row < m; row += NT) team_eval_row<POSE>(rows, sparam, B.jac, row, xt, rt, jt);
             __syncthreads();
-            st.sse_t = team_sumsq(rt, m, s_red);
+            st.sse_t = team_sumsq<NW>(rt, m, s_red, red_n);
             mark(5);
         }
         lm_state_control(st, o);
     }
-    team_block_epilogue(B, V, st.cur, flags, vars_base + out_off[sys], tid, TEAM_THREADS);
+    team_block_epilogue(B, V, st.cur, flags, vars_base + out_off[sys], tid, 64u * (uint32_t)NW);
     mark(6);
     if (stamp) prof[7] += st.trials;
     if (tid == 0) {

@@ -132,3 +132,26 @@ def test_single_pass_with_the_qr_step_refines_large_systems(fiksi, ctx):
     nv_big = int(b["var_off"][n_big])
     assert np.array_equal(v1[:nv_big].view(np.uint64), v2[:nv_big].view(np.uint64))
     assert np.array_equal(r1[:n_big], r2[:n_big])
+
+
+@pytest.mark.parametrize("n_tri", [16, 31, 64])
+def test_narrow_teams_give_the_bits_of_the_sixteen_wavefront_team(fiksi, ctx, n_tri):
+    """From 768 Systems of a structure on, a System's workgroup is 2, 4 or 8 wavefronts instead of 16 (fx_sparse.hip:
+    team_waves_for): each wavefront walks every n-th list of a level's schedule, the sums of squares keep their 1 024 strided
+    partial sums and their tree. Which wavefront walks a column changes nothing in its arithmetic — a System solved in a batch
+    of 800 (narrow teams) carries the bits of the same System in a batch of 3 (16 wavefronts): 66, 126 and 258 variables,
+    plain and refined step."""
+    from fiksi_amd import abi, workloads
+
+    ctx.set_wide_routing(0)
+    try:
+        for solver in (0, 1):
+            o = abi.solving_opts(solver=solver)
+            vb, rb = ctx.system_solve_batch(workloads.hinged_triangles(800, n_tri), o)
+            vs, rs = ctx.system_solve_batch(workloads.hinged_triangles(3, n_tri), o)
+            nv = 2 + 4 * n_tri
+            assert np.array_equal(vb[:nv].view(np.uint64), vs[:nv].view(np.uint64)), solver
+            assert rb[0].tobytes() == rs[0].tobytes() and rb[799].tobytes() == rs[0].tobytes(), solver
+            assert rb["sse_unscaled"][0] < 1e-6
+    finally:
+        ctx.set_wide_routing(-1)
