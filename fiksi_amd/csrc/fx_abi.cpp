@@ -820,6 +820,8 @@ struct fx_dbatch {
     std::vector<double> h_vars, h_expr_param;
     std::vector<uint8_t> h_var_fixed, h_expr_tag, h_sys_large;
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
+    std::vector<uint8_t> h_qr_wide;          // FX_STEP_QR: Systems beyond one wavefront the wide kernel's QR build solves (ensure_qr_plans)
+    bool qr_wide_active = false;             // ... and they have just been solved that way: the sparse path leaves them alone
     // sparse-path plans of the batch's large Systems, one per structure and decomposer mode (hash -> candidates)
     struct ResidentPlan {
         std::vector<unsigned char> key;
@@ -1244,12 +1246,14 @@ struct QrgHostProgram {
     uint32_t n = 0, m = 0, nx = 0, ng = 0;
     bool ok = false;
 };
+// `wide`: the program of the one-wavefront QR build of the wide kernel (fx_wide.hip: components of up to 128 columns and
+// 256 rows, Householder vectors of any length) — the same tables with offsets in ELEMENTS (the matrix may pass 64 KB).
 bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, const uint32_t* rows, uint32_t m, const uint32_t* free_,
-                       uint32_t n, uint32_t nvt, QrgHostProgram& out) {
+                       uint32_t n, uint32_t nvt, QrgHostProgram& out, bool wide = false) {
     out = QrgHostProgram();
     out.n = n;
     out.m = m;
-    if (n == 0 || n > 32u || m == 0 || m > 64u) return false;
+    if (n == 0 || n > (wide ? 128u : 32u) || m == 0 || m > (wide ? 256u : 64u)) return false;
     std::vector<int32_t> colof(nvt, -1);
     for (uint32_t c = 0; c < n; ++c) colof[free_[c]] = (int32_t)c;
     std::vector<std::vector<int>> cols(n);
@@ -1290,7 +1294,8 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
     uint32_t nx = rhsbase + Mq + 1u;
     const uint32_t zero = nx - 1u;
     nx = (nx + 1u) & ~1u;
-    if (8u * nx > 0xFFF0u) return false;
+    const uint32_t osc = wide ? 1u : 8u;  // offsets in elements / in bytes
+    if (osc * nx > 0xFFF0u) return false;
     bool bad = false;
     auto at = [&](int r, uint32_t j) -> uint32_t {  // offset of entry (permuted row r, column position j; j == n: right-hand side)
         if (j == n) return rhsbase + (uint32_t)r;
@@ -1301,7 +1306,7 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
         }
         return cbase[j] + (uint32_t)(it - prow[j].begin());
     };
-    auto atb = [&](int r, uint32_t j) -> uint32_t { return 8u * at(r, j); };  // ... in bytes, as the kernel takes them
+    auto atb = [&](int r, uint32_t j) -> uint32_t { return osc * at(r, j); };  // ... as the kernel takes them
     std::vector<uint16_t> scat((size_t)m * 8, 0xFFFFu), rhs_off(m), damp(n), cpos16(n), bptr(n + 1, 0);
     for (uint32_t r = 0; r < m; ++r) {
         for (int q = 0; q < 8; ++q)
@@ -1328,7 +1333,7 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
         steps[3 * k + 1] = (uint32_t)ent.size();
         steps[3 * k + 2] = na;
         const size_t e0 = ent.size();
-        ent.resize(e0 + (size_t)(len + 1u) * na, (8u * zero) | ((8u * zero) << 16));
+        ent.resize(e0 + (size_t)(len + 1u) * na, (osc * zero) | ((osc * zero) << 16));
         for (uint32_t i = 0; i < na; ++i) {
             ent[e0 + i] = atb((int)k, active[i]);
             for (uint32_t u = 0; u < below; ++u) {
@@ -1339,10 +1344,10 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
     }
     for (uint32_t i = 0; i < n; ++i) {
         bptr[i] = (uint16_t)bent.size();
-        for (int p = sy.rptr[i]; p < sy.rptr[i + 1] - 1; ++p) bent.push_back(((8u * (uint32_t)sy.rrows[p]) << 16) | atb(sy.rrows[p], i));
+        for (int p = sy.rptr[i]; p < sy.rptr[i + 1] - 1; ++p) bent.push_back(((osc * (uint32_t)sy.rrows[p]) << 16) | atb(sy.rrows[p], i));
     }
     bptr[n] = (uint16_t)bent.size();
-    if (bad || max_len > 32u) return false;
+    if (bad || (!wide && max_len > 32u) || max_len > 0xFFFFu) return false;
     std::vector<uint32_t>& w = out.words;
     w.assign(16, 0);
     auto put16 = [&](const std::vector<uint16_t>& v) -> uint32_t {
@@ -1379,7 +1384,7 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
     for (uint32_t k = 0; k < n; ++k) w[w[8] + 3 * k + 1] += o_ent;  // entries' first word, from the start of the program
     w.resize((w.size() + 3u) & ~size_t(3), 0);
     w[11] = (uint32_t)w.size();
-    w[12] = 8u * rhsbase;
+    w[12] = osc * rhsbase;
     w[13] = max_len;
     out.nx = nx;
     out.ok = true;
@@ -1572,8 +1577,102 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
             if (expr_comp[i] == 0) rows.push_back(i);
         (void)build_qrg_program(expr_tag.data(), expr_idx.data(), rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), nvt, prog);
     }
+    // Systems beyond one wavefront whose components all fit the wide kernel (at most 128 columns, 256 rows, 512 variables):
+    // a program per component for its FX_STEP_QR build (fx_wide.hip). Systems of one structure share theirs. All or nothing
+    // for the Systems the analysis marked for the wide kernel (they have no other reference-numerics home), and within a
+    // budget of program words — beyond it, as for everything larger, FX_STEP_QR stays FX_STEP_CHOLESKY_REFINED.
+    std::vector<uint32_t> w_list, w_comp_off(1, 0), w_prog_off, w_words;
+    uint32_t w_nx = 0, w_free = 0, w_vars = 0, w_rows = 0;
+    db->h_qr_wide.assign(n, 0);
+    if (!units) {
+        bool all_marked = true;
+        std::vector<std::pair<uint32_t, uint32_t>> first_of;  // owner System -> first entry of w_prog_off
+        constexpr size_t WORD_BUDGET = size_t(48) << 20;       // 192 MB of tables per batch
+        for (uint32_t s = 0; s < n && w_words.size() <= WORD_BUDGET; ++s) {
+            if (!sys_large[s]) continue;
+            const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0, e0 = expr_off[s], net = expr_off[s + 1] - e0;
+            bool fits = nvt <= 512u && sys_ncomp[s] >= 1u;
+            const uint32_t own = owner(s);
+            uint32_t first = 0xFFFFFFFFu;
+            if (fits && own != s)
+                for (auto& kv : first_of)
+                    if (kv.first == own) first = kv.second;
+            std::vector<uint32_t> offs;
+            if (fits && first == 0xFFFFFFFFu) {
+                std::vector<uint32_t> rows, free_;
+                for (uint32_t c = 0; c < sys_ncomp[s] && fits; ++c) {
+                    rows.clear();
+                    free_.clear();
+                    bool any_var = false;
+                    for (uint32_t i = 0; i < nvt; ++i) {
+                        const uint16_t info = var_info[v0 + i];
+                        any_var = any_var || (info & fx::VAR_COMP_MASK) == c;
+                        if ((info & fx::VAR_COMP_MASK) == c && !(info & fx::VAR_FIXED_BIT)) free_.push_back(i);
+                    }
+                    for (uint32_t i = 0; i < net; ++i)
+                        if (expr_comp[e0 + i] == c) rows.push_back(i);
+                    if (!any_var) {  // skipped by the kernel, as by the reference
+                        offs.push_back(0xFFFFFFFFu);
+                        continue;
+                    }
+                    QrgHostProgram wp;
+                    if (free_.empty() || rows.empty() ||
+                        !build_qrg_program(expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0, rows.data(), (uint32_t)rows.size(), free_.data(),
+                                           (uint32_t)free_.size(), nvt, wp, /*wide=*/true)) {
+                        fits = false;
+                        break;
+                    }
+                    offs.push_back((uint32_t)w_words.size());
+                    w_words.insert(w_words.end(), wp.words.begin(), wp.words.end());
+                    w_nx = std::max(w_nx, wp.nx);
+                    w_free = std::max(w_free, wp.n);
+                    w_rows = std::max(w_rows, wp.m);
+                }
+                if (fits) {
+                    first = (uint32_t)w_prog_off.size();
+                    w_prog_off.insert(w_prog_off.end(), offs.begin(), offs.end());
+                    first_of.push_back({s, first});
+                }
+            }
+            if (fits && first != 0xFFFFFFFFu) {
+                if (own != s) {  // a System of a structure already planned: its own row of offsets (the same values)
+                    const uint32_t nc = sys_ncomp[s];
+                    const uint32_t at = (uint32_t)w_prog_off.size();
+                    for (uint32_t c = 0; c < nc; ++c) {
+                        const uint32_t po = w_prog_off[first + c];
+                        w_prog_off.push_back(po);
+                    }
+                    first = at;
+                }
+                w_list.push_back(s);
+                w_comp_off.push_back(first);
+                w_vars = std::max(w_vars, nvt);
+                db->h_qr_wide[s] = 1;
+            } else if (sys_large[s] == 2) {
+                all_marked = false;
+            }
+        }
+        if (!all_marked || w_words.size() > WORD_BUDGET ||
+            (!w_list.empty() && fx::wide_qr_lds_bytes(w_free, w_vars, w_rows, w_nx) > 160u * 1024u)) {
+            w_list.clear();
+            db->h_qr_wide.assign(n, 0);
+        }
+    }
     unsigned long long* d64 = nullptr;
     int rc = dev_alloc_copy(ctx, db, &q.u16, u16.data(), u16.size());
+    if (!rc && !w_list.empty()) {
+        // (w_comp_off holds, per listed System, the first entry of ITS components in w_prog_off)
+        w_comp_off.erase(w_comp_off.begin());
+        rc = dev_alloc_copy(ctx, db, &q.qrw_list, w_list.data(), w_list.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &q.qrw_comp_first, w_comp_off.data(), w_comp_off.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &q.qrw_prog_off, w_prog_off.data(), w_prog_off.size());
+        if (!rc) rc = dev_alloc_copy(ctx, db, &q.qrw_words, w_words.data(), w_words.size());
+        q.n_qrw = (uint32_t)w_list.size();
+        q.qrw_nx = w_nx;
+        q.qrw_free = w_free;
+        q.qrw_vars = w_vars;
+        q.qrw_rows = w_rows;
+    }
     if (!rc && prog.ok) {
         rc = dev_alloc_copy(ctx, db, &q.qrg, prog.words.data(), prog.words.size());
         q.qrg_words = (uint32_t)prog.words.size();
@@ -1723,7 +1822,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (!db->n_large) return FX_OK;
     // cluster problems with pose rows: only the one-wavefront pose build and the sparse path evaluate those
     const bool pose = db->d.has_pose != 0;
-    if (!pose && wide_kernel_applies(p) && db->d.n_wide) {
+    if (!pose && wide_kernel_applies(p) && db->d.n_wide && !db->qr_wide_active) {  // (FX_STEP_QR: the QR build has solved them)
         hipError_t e = fx::launch_solve_wide(db->d, p, ctx->stream);
         if (e != hipSuccess) return fail(FX_ERR_HIP, "wide kernel launch failed: %s", hipGetErrorString(e));
     }
@@ -1744,7 +1843,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     const fx_batch& hb = db->h_batch;
     const bool wide_done = !pose && wide_kernel_applies(p);
     const uint32_t groups_of = (p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS)) | (wide_done ? 0x100u : 0u) | (device_units ? 0x200u : 0u) |
-                               (comp_walk ? 0x400u : 0u) | (pose ? 0x800u : 0u);
+                               (comp_walk ? 0x400u : 0u) | (pose ? 0x800u : 0u) | (db->qr_wide_active ? 0x1000u : 0u);
     std::vector<fx_dbatch::StructureGroup> local_groups;
     const bool cached = db->resident && db->large_groups.count(groups_of) != 0;
     std::vector<fx_dbatch::StructureGroup>& groups = db->resident ? db->large_groups[groups_of] : local_groups;
@@ -1753,6 +1852,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         for (uint32_t s = 0; s < db->d.n_systems; ++s) {
             if (!db->h_sys_large[s]) continue;
             if (db->h_sys_large[s] == 2 && wide_done) continue;                                            // done by the wide kernel
+            if (db->qr_wide_active && s < db->h_qr_wide.size() && db->h_qr_wide[s]) continue;             // done by its QR build
             if (device_units && s < db->h_units_on_device.size() && db->h_units_on_device[s]) continue;  // done by the kernel
             if (comp_walk && s < db->h_comp_walk.size() && db->h_comp_walk[s]) continue;                  // done by the walker
             todo.push_back(s);
@@ -2419,6 +2519,24 @@ int fx_batch_get_results(fx_ctx* ctx, fx_dbatch* db, fx_result* results) {
 
 uint64_t fx_batch_nnz(const fx_dbatch* db) { return db ? db->d.nnz : 0; }
 
+// Systems beyond one wavefront. FX_STEP_QR: those whose components have at most 128 columns run the wide kernel's QR build
+// (the reference's numerics; ensure_qr_plans listed them), everything larger takes the refined step on the sparse path.
+static int solve_beyond_one_wavefront(fx_ctx* ctx, fx_dbatch* db, fx::LmParams p) {
+    if (p.lm.solver == FX_STEP_QR) {
+        const bool qr_wide = !(p.mode & (fx::MODE_UNITS | fx::MODE_LBFGS)) && db->d.qr_none.n_qrw != 0 && !db->d.has_pose;
+        if (qr_wide) {
+            hipError_t e = fx::launch_solve_wide_qr(db->d, p, ctx->stream);
+            if (e != hipSuccess) return fail(FX_ERR_HIP, "wide QR kernel launch failed: %s", hipGetErrorString(e));
+        }
+        p.lm.solver = FX_STEP_CHOLESKY_REFINED;
+        db->qr_wide_active = qr_wide;
+        const int rc = solve_large_systems(ctx, db, p);
+        db->qr_wide_active = false;
+        return rc;
+    }
+    return solve_large_systems(ctx, db, p);
+}
+
 int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts) {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -2450,8 +2568,7 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     }
     rc = launch_solve_scheduled(ctx, db, p);
     if (rc) return rc;
-    if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
-    return solve_large_systems(ctx, db, p);
+    return solve_beyond_one_wavefront(ctx, db, p);
 }
 
 int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
@@ -2470,8 +2587,7 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
     }
     rc = launch_solve_scheduled(ctx, db, p);
     if (rc) return rc;
-    if (p.lm.solver == FX_STEP_QR) p.lm.solver = FX_STEP_CHOLESKY_REFINED;  // Systems beyond one wavefront
-    return solve_large_systems(ctx, db, p);
+    return solve_beyond_one_wavefront(ctx, db, p);
 }
 
 int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* route) {

@@ -52,6 +52,13 @@ struct QrPlans {
     uint32_t* index = nullptr;  // Decomposer::None: [n_systems] first desc of the System (+ component); SinglePass: [units] desc of the block
     uint32_t max_m = 0;         // rows of the largest augmented matrix (expressions + free variables)
     uint32_t max_h = 0;         // entries of the largest Householder structure
+    // the wide kernel's QR build (fx_wide.hip): Systems beyond one wavefront whose components have at most 128 columns —
+    // qrw_list[i] is solved with the programs words + prog_off[comp_first[i] + c] of its components c (0xFFFFFFFF: none)
+    uint32_t* qrw_list = nullptr;
+    uint32_t* qrw_comp_first = nullptr;
+    uint32_t* qrw_prog_off = nullptr;
+    uint32_t* qrw_words = nullptr;
+    uint32_t n_qrw = 0, qrw_nx = 0, qrw_free = 0, qrw_vars = 0, qrw_rows = 0;
     // the grouped build's program (fx_abi.cpp: build_qrg_program), for a batch of one structure; null otherwise
     uint32_t* qrg = nullptr;
     uint32_t qrg_words = 0, qrg_small = 0, qrg_nx = 0, qrg_n = 0, qrg_m = 0, qrg_ng = 0;
@@ -167,6 +174,9 @@ hipError_t launch_dense_jacobian(const DeviceBatch& b, const double* x, const ui
                                  const uint16_t* sys_nfree, const uint64_t* dense_off, double* resid, double* jac,
                                  hipStream_t stream);
 hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+// FX_STEP_QR on the Systems of b.qr_none.qrw_list (components of at most 128 columns)
+hipError_t launch_solve_wide_qr(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+size_t wide_qr_lds_bytes(uint32_t max_free, uint32_t max_vars, uint32_t max_rows, uint32_t nx);
 // several Systems per wavefront (fx_grouped.hip): batches of components with at most 32 free variables
 bool grouped_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream);

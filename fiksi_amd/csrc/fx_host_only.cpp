@@ -11,6 +11,8 @@ hipError_t launch_identity_residuals(const DeviceBatch&, const double*, double*,
 hipError_t launch_dense_jacobian(const DeviceBatch&, const double*, const uint16_t*, const uint32_t*, const uint16_t*, const uint64_t*,
                                  double*, double*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_solve_wide(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_solve_wide_qr(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
+size_t wide_qr_lds_bytes(uint32_t, uint32_t, uint32_t, uint32_t) { return 0; }
 bool grouped_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t grouped_lds_bytes(const DeviceBatch&, uint32_t, bool) { return 0; }

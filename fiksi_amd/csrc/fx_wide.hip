@@ -31,7 +31,7 @@ struct WideLayout {
     uint32_t total;
 };
 
-static WideLayout make_wide_layout(uint32_t max_free, uint32_t max_vars, uint32_t max_rows) {
+static WideLayout make_wide_layout(uint32_t max_free, uint32_t max_vars, uint32_t max_rows, uint32_t qr_nx = 0) {
     WideLayout L;
     L.vt = (max_vars + 7u) & ~7u;
     L.mr = (max_rows + 7u) & ~7u;
@@ -43,7 +43,8 @@ static WideLayout make_wide_layout(uint32_t max_free, uint32_t max_vars, uint32_
     auto take = [&](uint32_t bytes) { uint32_t at = o; o += (bytes + 15u) & ~15u; return at; };
     L.off_xs = take(2u * L.vt * 8u);
     L.off_vout = take(L.vt * 8u);
-    L.off_l = take(L.n * (L.n + 1u) / 2u * 8u);
+    // (QR build: the augmented matrix by its symbolic patterns, qr_nx doubles, in place of the triangle)
+    L.off_l = take(qr_nx ? qr_nx * 8u : L.n * (L.n + 1u) / 2u * 8u);
     L.off_rhs = take(L.n * 8u);
     L.off_delta = take(L.n * 8u);
     L.off_aux = take(L.n * 8u);
@@ -63,10 +64,15 @@ size_t wide_lds_bytes(const DeviceBatch& b) { return make_wide_layout(b.w_max_fr
 
 __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return i * (i + 1u) / 2u + j; }  // i >= j
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_wide_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
-    extern __shared__ __align__(16) unsigned char smem[];
+// QR = true is FX_STEP_QR for these components: the reference's Householder QR of [J; sqrt(lambda) I]
+// (solvi/src/decomposition/sparse/qr.rs:226-356) with the operations and the order of the one-wavefront QR kernel
+// (fx_kernels.hip: qr_step), driven by the host's table program (fx_abi.cpp: build_qrg_program, wide form) — the matrix by
+// its symbolic patterns in LDS, a lane per ACTIVE column of the Householder step at hand, the tables in global memory; the
+// reference's sequential sums, the correctly rounded atan2. Every bit is the oracle's (tests/test_gpu_wide.py).
+template <bool QR>
+__device__ __forceinline__ void wide_body(const DeviceBatch& b, const LmParams& prm, const WideLayout& L, unsigned char* smem) {
     const int lane = threadIdx.x;
-    const uint32_t s = b.w_list[blockIdx.x];
+    const uint32_t s = QR ? b.qr_none.qrw_list[blockIdx.x] : b.w_list[blockIdx.x];
     // diagnostic phase stamps (prm.prof != nullptr only from fx_debug_phase_cycles):
     // 0 setup, 1 eval, 2 form, 3 factor, 4 solve, 5 tail
     unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
@@ -193,13 +199,159 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 double v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = xs[gvar[row * 8 + e]];
-                double r = eval_expression<double, true>(rtag[row], v, P[row], g);
+                double r = eval_expression<double, true, QR>(rtag[row], v, P[row], g);
                 R[buf * mr + row] = r;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) G[(buf * mr + row) * 8 + e] = g[e];
                 part += r * r;
             }
+            if constexpr (QR) {  // the reference's sum of squares, in index order (lm.rs:195-197): every lane adds the same numbers
+                __syncthreads();
+                double acc = 0.0;
+                const double* rb = R + buf * mr;
+                for (uint32_t row0 = 0; row0 < m_rows; row0 += 16) {
+                    double rr[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) rr[u] = (row0 + u < m_rows) ? rb[row0 + u] : 0.0;  // + 0.0: exact
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += rr[u] * rr[u];
+                }
+                return bcast(acc, 0);
+            }
             return wave_sum(part);
+        };
+        // One LM trial's step by the reference's QR, table-driven. Returns false when R has an exactly zero diagonal entry
+        // (sparse_col_mat.rs:800-810); the step lands in DEL, |delta|^2 (summed in index order) in dn2_out.
+        auto qr_step = [&](double lam, int buf, double& dn2_out) -> bool {
+            bool ok = true;
+            if constexpr (QR) {
+                const QrPlans& Q = b.qr_none;
+                const uint32_t* TB = Q.qrw_words + Q.qrw_prog_off[Q.qrw_comp_first[blockIdx.x] + c];
+                const uint32_t qn = TB[0], qm = TB[1], nx = TB[2], rhsbase = TB[12];  // (offsets into the matrix in elements)
+                const uint16_t* scat = reinterpret_cast<const uint16_t*>(TB + TB[4]);
+                const uint16_t* rhs_off = reinterpret_cast<const uint16_t*>(TB + TB[5]);
+                const uint16_t* damp = reinterpret_cast<const uint16_t*>(TB + TB[6]);
+                const uint16_t* cposT = reinterpret_cast<const uint16_t*>(TB + TB[7]);
+                const uint32_t* stepT = TB + TB[8];
+                const uint16_t* bptr = reinterpret_cast<const uint16_t*>(TB + TB[9]);
+                const uint32_t* bent = TB + TB[10];
+                double* X = Lm;
+                const double sl = ::sqrt(lam);  // lm.rs:119
+                __syncthreads();
+                for (uint32_t i = lane; i < nx; i += 64) X[i] = 0.0;
+                __syncthreads();
+                // J (duplicates of a row summed in gradient order) and b = -r; the damping entry of every column
+                for (uint32_t row = lane; row < qm; row += 64) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t off = scat[row * 8 + e];
+                        if (off != 0xFFFFu) lds_add(&X[off], G[(buf * mr + row) * 8 + e]);
+                    }
+                    X[rhs_off[row]] = -R[buf * mr + row];
+                }
+                for (uint32_t cc = lane; cc < qn; cc += 64) X[damp[cc]] = sl;
+                __syncthreads();
+                for (uint32_t k = 0; k < qn; ++k) {
+                    const uint32_t w0 = stepT[3 * k], ent = stepT[3 * k + 1], nact = stepT[3 * k + 2];
+                    const uint32_t vdiag = w0 & 0xFFFFu, len = w0 >> 16;
+                    const double v0 = X[vdiag];
+                    double norm = 0.0, beta = 0.0, v0n = 1.0;
+                    auto householder = [&](double sigma) {  // calculate_householder (qr.rs:244-275); every lane computes it
+                        norm = ::fabs(v0);
+                        beta = (v0 >= 0.0) ? 0.0 : 2.0;
+                        v0n = 1.0;
+                        if (sigma != 0.0) {
+                            norm = ::sqrt(sigma + v0 * v0);
+                            v0n = (v0 <= 0.0) ? v0 - norm : -sigma / (v0 + norm);
+                            beta = -(1.0 / (norm * v0n));
+                        }
+                    };
+                    for (uint32_t i0 = 0; i0 < nact; i0 += 64) {
+                        const bool act = i0 + (uint32_t)lane < nact;
+                        const uint32_t* e = TB + ent + (act ? i0 + (uint32_t)lane : 0u);  // (idle lanes follow column 0 and store nothing)
+                        const uint32_t wk0 = e[0];
+                        const double xk0 = X[wk0];
+                        // the vector's entries in blocks of four (the host pads with the zero slot), three passes: the
+                        // vector's own square sum, the column's inner product (qr.rs:226-240), the update
+                        double sigma = 0.0;
+                        for (uint32_t u = 0; u < len; u += 4) {
+                            double vk[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) vk[t] = X[e[(1u + u + (uint32_t)t) * nact] >> 16];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) sigma = sigma + vk[t] * vk[t];
+                        }
+                        householder(sigma);
+                        double tau = 0.0;
+                        tau = tau + v0n * xk0;
+                        for (uint32_t u = 0; u < len; u += 4) {
+                            double vk[4], xj[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const uint32_t w = e[(1u + u + (uint32_t)t) * nact];
+                                vk[t] = X[w >> 16];
+                                xj[t] = X[w & 0xFFFFu];
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) tau = tau + vk[t] * xj[t];
+                        }
+                        tau = tau * beta;
+                        if (act) {
+                            X[wk0] = xk0 - v0n * tau;
+                            for (uint32_t u = 0; u < len; u += 4) {
+                                uint32_t w[4];
+                                double vk[4], xj[4];
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    w[t] = e[(1u + u + (uint32_t)t) * nact];
+                                    vk[t] = X[w[t] >> 16];
+                                    xj[t] = X[w[t] & 0xFFFFu];
+                                }
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) X[w[t] & 0xFFFFu] = xj[t] - vk[t] * tau;  // (padding: 0 - 0 tau into the zero slot)
+                            }
+                        }
+                        __syncthreads();
+                    }
+                    if (lane == 0) X[vdiag] = norm;  // R's diagonal (qr.rs:319)
+                    __syncthreads();
+                }
+                // back substitution with R (sparse_col_mat.rs:788-826), in place on the right-hand side
+                {
+                    bool zero_diag = false;
+                    for (uint32_t cc = lane; cc < qn; cc += 64) zero_diag = zero_diag || X[stepT[3 * cc] & 0xFFFFu] == 0.0;
+                    ok = __ballot(zero_diag) == 0ull;
+                }
+                if (ok) {
+                    for (uint32_t ii = qn; ii > 0; --ii) {
+                        const uint32_t i = ii - 1u;
+                        const uint32_t dgo = stepT[3 * i] & 0xFFFFu, eb = bptr[i], ee = bptr[i + 1];
+                        const double coeff = X[rhsbase + i] / X[dgo];
+                        for (uint32_t t = eb + (uint32_t)lane; t < ee; t += 64) {
+                            const uint32_t wv = bent[t];
+                            const uint32_t yo = rhsbase + (wv >> 16);
+                            X[yo] = X[yo] - coeff * X[wv & 0xFFFFu];
+                        }
+                        __syncthreads();
+                        if (lane == 0) X[rhsbase + i] = coeff;
+                        __syncthreads();
+                    }
+                }
+                // undo the column permutation (qr.rs:354): delta[colperm[j]] = x_j; |delta|^2 in index order
+                for (uint32_t cc = lane; cc < qn; cc += 64) DEL[cc] = ok ? X[rhsbase + cposT[cc]] : 0.0;
+                __syncthreads();
+                double acc = 0.0;
+                for (uint32_t c0 = 0; c0 < qn; c0 += 16) {
+                    double dd[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) dd[u] = (c0 + u < qn) ? DEL[c0 + u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) acc += dd[u] * dd[u];
+                }
+                dn2_out = bcast(acc, 0);
+                __syncthreads();
+            }
+            return ok;
         };
         // rhs = -Jt r at `buf`, one row per wave instruction (row order)
         auto form_rhs = [&](int buf) {
@@ -360,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         double sse = eval_rows(0);
         const double sse_start = sse;
         stamp(1);
-        form_rhs(0);
+        if constexpr (!QR) form_rhs(0);
         stamp(2);
         double lambda = o.lambda0;
         uint32_t accepted = 0, trials = 0, exit_code = FX_EXIT_MAX_OUTER;
@@ -382,6 +534,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 trials += 1;
                 stamp(5);
+                double dn2 = 0.0;
+                if constexpr (QR) {
+                    if (!uniform(qr_step(lambda, cur, dn2))) {  // lm.rs:134-137
+                        lambda *= o.singular_factor;
+                        continue;
+                    }
+                } else {
                 form_matrix(cur, lambda);
                 stamp(2);
                 const bool factored = factor();
@@ -397,9 +556,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 for (uint32_t i = lane; i < nfree; i += 64) DEL[i] = RHS[i];
                 __syncthreads();
-                double dn2 = solve();
+                dn2 = solve();
                 stamp(4);
-                if (o.solver == FX_STEP_CHOLESKY_REFINED) {
+                }
+                if (!QR && o.solver == FX_STEP_CHOLESKY_REFINED) {
                     // corrected semi-normal equations, as in lm_solve_kernel: t = -r - J delta from the rows,
                     // (JtJ + lambda I) e = Jt t - lambda delta with the factor at hand, delta += e
                     double* tr = R + (cur ^ 1) * mr;
@@ -467,7 +627,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         break;
                     }
                     __syncthreads();
-                    form_rhs(cur);
+                    if constexpr (!QR) form_rhs(cur);
                     break;
                 } else {  // reject, lm.rs:187-190
                     lambda *= o.reject_factor;
@@ -530,7 +690,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         double v[8], g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = VOUT[vars8[e]];
-        double r = eval_expression<double, false>(tag, v, b.expr_param[e0 + i], g);
+        double r = eval_expression<double, false, QR>(tag, v, b.expr_param[e0 + i], g);
         part += r * r;
     }
     double sse_u = wave_sum(part);
@@ -552,6 +712,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < 6; ++i) atomicAdd(&prm.prof[i], ph[i]);
     }
 }
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_wide_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    wide_body<false>(b, prm, L, smem);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_wide_qr_kernel(DeviceBatch b, LmParams prm, WideLayout L) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    wide_body<true>(b, prm, L, smem);
+}
+
+hipError_t launch_solve_wide_qr(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    const QrPlans& Q = b.qr_none;
+    if (Q.n_qrw == 0) return hipSuccess;
+    if (p.lm.precision == 32 || (p.mode & (MODE_UNITS | MODE_LBFGS)) || p.prof) return hipErrorInvalidValue;
+    WideLayout L = make_wide_layout(Q.qrw_free, Q.qrw_vars, Q.qrw_rows, Q.qrw_nx);
+    if (L.total > 160u * 1024u) return hipErrorInvalidValue;
+    static unsigned int raised = 0;
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_wide_qr_kernel), &raised);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lm_solve_wide_qr_kernel, dim3(Q.n_qrw), dim3(64), L.total, stream, b, p, L);
+    return hipGetLastError();
+}
+// LDS bytes of that launch (the host checks them before it plans)
+size_t wide_qr_lds_bytes(uint32_t max_free, uint32_t max_vars, uint32_t max_rows, uint32_t nx) { return make_wide_layout(max_free, max_vars, max_rows, nx).total; }
 
 hipError_t launch_solve_wide(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_wide == 0) return hipSuccess;

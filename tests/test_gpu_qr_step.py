@@ -223,3 +223,35 @@ def test_four_systems_per_wavefront_is_the_same_bits(fiksi, oracle, ctx, shape):
     with oracle.atan2_mode("correctly_rounded"):
         v_o, res_o = oracle.solve_batch(sub, mode=3, nthreads=8)
     _assert_identical(sub, out[("1", True)][0][: len(v_o)], out[("1", True)][1][:n], v_o, res_o)
+
+
+@pytest.mark.parametrize("wide_routing", [-1, 1])
+def test_components_of_65_to_128_columns_keep_the_reference_numerics(fiksi, oracle, ctx, wide_routing):
+    """FX_STEP_QR beyond one wavefront (round 4): Systems whose components have at most 128 columns and 256 rows run the
+    wide kernel's QR build (fx_wide.hip: the matrix by its symbolic patterns in LDS, a lane per active column, the host's
+    table program) instead of being downgraded to the refined step — whatever the wide / team routing of the plain step is.
+    Every variable, counter and SSE is the oracle's bits: hinged chains of 66 ... 126 variables, a sketch with angles (the
+    correctly rounded atan2 on both sides), mixed with one-wavefront Systems and a System too large for it (which still
+    takes the refined step)."""
+    from fiksi_amd import abi, workloads
+
+    ctx.set_wide_routing(wide_routing)
+    try:
+        b = workloads.concat([workloads.hinged_triangles(3, 16), workloads.ring16(4), workloads.hinged_triangles(2, 24),
+                              workloads.large_sketch(40, seed=5), workloads.hinged_triangles(2, 31), workloads.large_sketch(60, seed=9),
+                              workloads.hinged_triangles(2, 5)])
+        n_big = 3 + 4 + 2 + 1 + 2 + 1 + 2
+        assert len(b["var_off"]) - 1 == n_big
+        v, res = ctx.system_solve_batch(b, abi.solving_opts(solver=2))
+        with oracle.atan2_mode("correctly_rounded"):
+            v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+        sizes = np.diff(b["var_off"])
+        assert sizes.max() <= 128 and (sizes > 64).sum() >= 8
+        _assert_identical(b, v, res, v_o, res_o)
+        # with a System beyond 128 columns in the batch: that one takes the refined step, the others keep their bits
+        b2 = workloads.concat([b, workloads.hinged_triangles(1, 40)])
+        v2, res2 = ctx.system_solve_batch(b2, abi.solving_opts(solver=2))
+        assert np.array_equal(_bits(v2[: len(v)]), _bits(v)) and res2[:n_big].tobytes() == res.tobytes()
+        assert res2["sse_unscaled"][-1] < 1e-6
+    finally:
+        ctx.set_wide_routing(-1)
