@@ -137,9 +137,12 @@ typedef enum fx_step_solver {
                       kinds, relative to a correctly rounded atan2: the QR kernels evaluate the two angle
                       residuals with fx_atan2.h's correctly rounded routine (a platform libm's atan2 — the
                       reference's — may be an ulp off on ~7e-4 of arguments; see fx_atan2_cr_batch). f64,
-                      Levenberg-Marquardt, Systems the one-wavefront kernel takes
-                      (components of up to FX_MAX_FREE_VARS free variables); larger Systems run
-                      FX_STEP_CHOLESKY_REFINED instead. Several times the cost of FX_STEP_CHOLESKY.        */
+                      Levenberg-Marquardt. Components of up to FX_MAX_FREE_VARS free variables on the one-wavefront
+                      kernels (batches of one structure with at most 32 columns: four Systems per wavefront);
+                      Decomposer::None Systems of at most 512 variables whose components have up to 128 free variables
+                      and 256 expressions on the wide kernel's QR build; larger Systems, and SinglePass blocks
+                      beyond one wavefront, run FX_STEP_CHOLESKY_REFINED instead.
+                      Two to six times the cost of FX_STEP_CHOLESKY.                                        */
 } fx_step_solver;
 
 /* Levenberg-Marquardt constants; fx_lm_opts_default() == the literals of lm.rs:108-189. */
