@@ -335,7 +335,7 @@ enum GPhase { GH_SETUP = 0, GH_EVAL = 1, GH_FORM = 2, GH_FACTOR = 3, GH_SOLVE = 
 // their order of the one-wavefront QR kernel (fx_kernels.hip: qr_step), driven by the host's program (build_qrg_program) —
 // the lanes of a row are the ACTIVE columns of the Householder step at hand (about seven of 33 for the headline shape), and
 // the wavefront serves four Systems. Sums are the reference's sequential ones, the angle residuals use the correctly rounded
-// atan2: every bit is that kernel's, and the oracle's.
+// atan2: every bit is that kernel's, and so the reference algorithm's.
 template <int NC, typename T, bool PROF, bool UNITS, bool QRG = false>
 __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParams& prm, const GroupLayout& L,
                                              uint32_t* __restrict__ next_system, unsigned char* smem) {

@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return i * (i 
 // (solvi/src/decomposition/sparse/qr.rs:226-356) with the operations and the order of the one-wavefront QR kernel
 // (fx_kernels.hip: qr_step), driven by the host's table program (fx_abi.cpp: build_qrg_program, wide form) — the matrix by
 // its symbolic patterns in LDS, a lane per ACTIVE column of the Householder step at hand, the tables in global memory; the
-// reference's sequential sums, the correctly rounded atan2. Every bit is the oracle's (tests/test_gpu_wide.py).
+// reference's sequential sums, the correctly rounded atan2. Every bit is the reference algorithm's (tests/test_gpu_qr_step.py).
 template <bool QR>
 __device__ __forceinline__ void wide_body(const DeviceBatch& b, const LmParams& prm, const WideLayout& L, unsigned char* smem) {
     const int lane = threadIdx.x;
