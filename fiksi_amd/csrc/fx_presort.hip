@@ -68,25 +68,26 @@ __global__ __launch_bounds__(256) void presort_scout_kernel(DeviceBatch b, float
 }
 
 // workgroup c ranks chunk c (Systems c, c + nc, ...; at most 512) by descending key — every thread counts the entries
-// in front of its own, four per LDS read — and writes the entry of rank i to position i * nc + c of the order
+// in front of its own — and writes the entry of rank i to position i * nc + c of the order. Keys are non-negative floats, so
+// their bit patterns order like the numbers: an entry is the 64-bit word (key bits << 32 | 511 - index), unique per entry, and
+// "in front of" is one unsigned compare (two entries per 16-byte LDS read, which every lane reads from the same address).
 __global__ __launch_bounds__(PS_CHUNK) void presort_chunk_kernel(uint32_t n, uint32_t nc, const float* __restrict__ keys,
                                                                  uint32_t* __restrict__ order) {
-    __shared__ float4 k4[PS_CHUNK / 4];
-    float* k = reinterpret_cast<float*>(k4);
+    __shared__ ulonglong2 k2[PS_CHUNK / 2];
+    unsigned long long* k = reinterpret_cast<unsigned long long*>(k2);
     const uint32_t t = threadIdx.x, c = blockIdx.x;
     const uint32_t s = c + t * nc;
-    const float mine = s < n ? keys[s] : -1.0f;  // keys are >= 0: the padding ranks last
+    // (the padding: zero — nothing is behind it, and no real entry counts it: a real entry's low word is >= 0 and ties cannot
+    // be in front)
+    const unsigned long long mine = s < n ? ((unsigned long long)__float_as_uint(keys[s]) << 32) | (unsigned long long)(PS_CHUNK - 1u - t) : 0ull;
     k[t] = mine;
     __syncthreads();
     uint32_t rank = 0;
 #pragma unroll 8
-    for (uint32_t j = 0; j < PS_CHUNK / 4u; ++j) {
-        const float4 v = k4[j];
-        const uint32_t j0 = 4u * j;
-        rank += (v.x > mine || (v.x == mine && j0 < t)) ? 1u : 0u;
-        rank += (v.y > mine || (v.y == mine && j0 + 1u < t)) ? 1u : 0u;
-        rank += (v.z > mine || (v.z == mine && j0 + 2u < t)) ? 1u : 0u;
-        rank += (v.w > mine || (v.w == mine && j0 + 3u < t)) ? 1u : 0u;
+    for (uint32_t j = 0; j < PS_CHUNK / 2u; ++j) {
+        const ulonglong2 v = k2[j];
+        rank += v.x > mine ? 1u : 0u;
+        rank += v.y > mine ? 1u : 0u;
     }
     if (s < n) order[rank * nc + c] = s;
 }
