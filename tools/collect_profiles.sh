@@ -27,6 +27,7 @@ stats headline_kernel_stats python3 tools/solve_only.py 100000 10
 echo "[collect] cfg2 resident, the reference's 64-triangle sketch x 256"
 stats cfg2_kernel_stats python3 tools/cfg2_resident.py 3
 stats hinged64_kernel_stats python3 tools/hinged_batch.py 64 256 5
+stats hinged16_kernel_stats python3 tools/hinged_batch.py 16 20000 3
 stats qr_kernel_stats python3 tools/qr_once.py 100000 3
 stats shard12500_kernel_stats python3 tools/solve_only.py 12500 10
 echo "[collect] HBM counters, 100k and 500k Systems"
@@ -42,6 +43,8 @@ python3 tools/pmc_summary.py $OUT/pmc_fetch5m $OUT/pmc_write5m $OUT/${TAG}_pmc_t
 echo "[collect] SQ counters of the solve kernels"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/pmc_sq -- python3 tools/solve_only.py 100000 2 > $OUT/pmc_sq.log 2>&1
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/${TAG}_pmc_sq.json 100000 "tools/solve_only.py 100000 2" > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/qr_sq -- python3 tools/qr_once.py 100000 2 > $OUT/qr_sq.log 2>&1
+python3 tools/pmc_sq_summary.py $OUT/qr_sq $OUT/${TAG}_qr_pmc_sq.json 100000 "tools/qr_once.py 100000 2" > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/cfg2_sq -- python3 tools/cfg2_resident.py 1 > $OUT/cfg2_sq.log 2>&1
 python3 tools/pmc_sq_summary.py $OUT/cfg2_sq $OUT/${TAG}_cfg2_pmc_sq.json 1 "tools/cfg2_resident.py 1" > /dev/null
 echo "[collect] K1 store policy A / B"
