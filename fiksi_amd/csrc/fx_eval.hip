@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t compute_slots(int tag, const uint16_t f[4], 
 // stay in L1, instead of 11 bytes per row streamed from HBM in two more dependent round trips. What is left in front of a
 // block's arithmetic is ONE trip to HBM (parameters and variables, both addressed from the cached structure).
 template <bool WANT_J, bool NT = true>
-__global__ __launch_bounds__(256) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x, uint32_t uni_period) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void eval_rows_kernel(DeviceBatch b, const double* __restrict__ x, uint32_t uni_period) {
     // Block = 256 consecutive rows. Threads take the block's rows in tag-sorted order (host-built
     // permutation) so that a wavefront sees as few expression kinds as possible (divergence: the
     // angle rows cost ~8x a distance row). Residuals and the block's CSR values (contiguous in the
