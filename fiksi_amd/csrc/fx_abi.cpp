@@ -672,7 +672,7 @@ struct fx_ctx {
     size_t free_bytes = 0;
     // routing of batches of small Systems (fx_ctx_set_routing)
     int route_grouped = -1;
-    uint32_t grouped_min_systems = 64u;
+    uint32_t grouped_min_systems = 8u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
     uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, ladder_spread = 1u;  // fx_ctx_set_ladder

@@ -141,7 +141,7 @@ struct LmParams {
     // routing of batches of small Systems (fx_ctx_set_routing): -1 = by batch size, 0 = never the grouped kernel,
     // 1 = whenever the batch qualifies; the size from which a batch takes it
     int route_grouped = -1;
-    uint32_t grouped_min_systems = 64u;
+    uint32_t grouped_min_systems = 8u;
     uint32_t hold_passes = 2u;  // grouped kernel: passes a finished row waits for a second one before its set-up blocks (fx_ctx_set_hold_passes)
     // grouped kernel, the lambda ladder (fx_ctx_set_ladder): rows without a System of their own try the next lambdas of a
     // running System of their wavefront side by side. ladder_tail / ladder_k: with at most ladder_tail Systems left in the

@@ -213,12 +213,14 @@ int fx_device_count(int* count);           /* HIP devices visible to this proces
 int fx_ctx_create(fx_ctx** ctx, int device);
 void fx_ctx_destroy(fx_ctx* ctx);
 /* Which kernel batches of small Systems (components of at most 48 free variables) take: grouped = -1 (default): the
- * grouped kernel — four Systems per wavefront — from grouped_min_systems Systems on (default 64; 0 keeps the current value),
+ * grouped kernel — four Systems per wavefront — from grouped_min_systems Systems on (default 8; 0 keeps the current value),
  * one wavefront per System below; 0: never the grouped kernel; 1: whenever the batch qualifies. (Round 4: since the rows of a
  * wavefront that have run out of Systems help the ones still running — fx_ctx_set_ladder — a small batch of sketches of
- * uneven difficulty is as slow as its slowest System's LADDER, not its trial count: 256 ring16 sketches 0.75 -> 0.33 ms,
- * 1000: 0.80 -> 0.40 ms; a small batch of identical Systems, which has no slowest one, loses up to a third — 500 four-triangle
- * sketches 0.041 -> 0.058 ms — and may pin 0. Up to round 3 the threshold was 1024.) Results do not
+ * uneven difficulty is as slow as its slowest System's LADDER, not its trial count: 8 ring16 sketches 0.19 -> 0.15 ms,
+ * 256: 0.75 -> 0.33 ms, 1000: 0.80 -> 0.40 ms, and ONE sketch that takes 97 trials 0.92 -> 0.39 ms — but one that takes 3
+ * trials 0.051 -> 0.067 ms, which is why a handful of Systems stay on the lighter kernel; a small batch of identical Systems,
+ * which has no slowest one, loses up to a third — 500 four-triangle sketches 0.041 -> 0.058 ms — and may pin 0. Up to round 3
+ * the threshold was 1024.) Results do not
  * depend on it beyond the last bits of sums of LDS float atomics on sketches where several rows add into one entry.
  * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment. */
 int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);

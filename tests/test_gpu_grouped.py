@@ -1,7 +1,7 @@
 """The grouped kernel (fx_grouped.hip: four Systems per wavefront, components of at most 32 free variables)
 against the oracle and against the one-System-per-wavefront kernel it replaces for large batches.
 The context's routing option (fx_ctx_set_routing): 1 sends every qualifying batch to the grouped kernel, 0 none;
-by default (-1) batches of 64 Systems and more take it."""
+by default (-1) batches of 8 Systems and more take it."""
 import os
 
 import numpy as np
@@ -153,7 +153,7 @@ def test_against_the_oracle_on_the_headline_shape(fiksi, oracle, ctx, routing):
 def test_mixed_kinds_fixed_variables_and_several_components(fiksi, oracle, ctx, routing, f32):
     """All eleven constraint kinds, fixed variables, Systems of different sizes and component counts in one batch
     (no shared structure: every row builds its lists per System), against the oracle with the tolerances of
-    tests/test_gpu_parity.py; the default routing gives the bits of "1" for this batch and of "0" for its first 40 Systems."""
+    tests/test_gpu_parity.py; the default routing gives the bits of "1" for this batch and of "0" for its first 7 Systems."""
     import helpers
     from fiksi_amd import workloads
 
@@ -167,10 +167,10 @@ def test_mixed_kinds_fixed_variables_and_several_components(fiksi, oracle, ctx, 
     v0, res0 = _solve(ctx, b, f32=f32)
     routing(None)
     vd, resd = _solve(ctx, b, f32=f32)
-    assert np.array_equal(_bits(vd), _bits(v))  # 323 Systems: from 64 Systems on the default is the grouped kernel (round 4)
-    small = workloads.concat(flats[:40])
+    assert np.array_equal(_bits(vd), _bits(v))  # 323 Systems: from 8 Systems on the default is the grouped kernel (round 4)
+    small = workloads.concat(flats[:7])
     vs, _ = _solve(ctx, small, f32=f32)
-    assert np.array_equal(_bits(vs), _bits(v0[: len(vs)]))  # 40 Systems: below the threshold, one System per wavefront
+    assert np.array_equal(_bits(vs), _bits(v0[: len(vs)]))  # 7 Systems: below the threshold, one System per wavefront
     # the two kernels add the products of an entry of JtJ in a different lane order: same path, last-bit sums
     assert np.array_equal(res["scale"], res0["scale"])
     assert np.array_equal(res["ncomp"], res0["ncomp"])
