@@ -226,7 +226,7 @@ def main() -> int:
                 "algorithmic_flops_per_launch": FLOPS_PER_TRIAL * trials_per_step,
                 "achieved_TFLOPs": FLOPS_PER_TRIAL * trials_per_step / (solve_ms * 1e-3) / 1e12,
                 "frac_of_f64_vector_peak": FLOPS_PER_TRIAL * trials_per_step / (solve_ms * 1e-3) / 1e12 / F64_VECTOR_PEAK_TFLOPS,
-                "includes": "the scout pass + radix sort of fx_ctx_set_presort (most-work-first hand-out, ~0.1 ms; part of every step)",
+                "includes": "the scout pass + chunk ranking of fx_ctx_set_presort (most-work-first hand-out, two launches, ~0.035 ms; part of every step)",
                 "note": "latency/f64-VALU bound by construction (~14 kflop per LM trial on a serial "
                         "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d). "
                         "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead",

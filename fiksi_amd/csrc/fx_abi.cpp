@@ -1942,7 +1942,10 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
             fx_dbatch::ResidentPlan* found = nullptr;
             for (auto it = range.first; it != range.second; ++it)
                 if (it->second.key == groups[g].key) found = &it->second;
-            if (!found) found = &db->sparse_plans.emplace(h, fx_dbatch::ResidentPlan{groups[g].key, fx::sparse_cache_new()})->second;
+            if (!found) {
+                found = &db->sparse_plans.emplace(h, fx_dbatch::ResidentPlan{groups[g].key, fx::sparse_cache_new()})->second;
+                fx::sparse_cache_keep_slab(found->plan, SIZE_MAX);  // the batch is there to be solved again: its slab goes with it
+            }
             group_plan[g] = found->plan;
         } else if (!pose) {
             group_plan[g] = ctx->plan_for(std::vector<unsigned char>(groups[g].key), call_clock);

@@ -16,6 +16,8 @@ struct SparsePlanCache;
 SparsePlanCache* sparse_cache_new();
 void sparse_cache_free(SparsePlanCache* c);
 bool sparse_cache_ready(const SparsePlanCache* c);  // filled by a completed solve: later solves only read it
+// how much of the value slab a solve leaves with the plan for the next one (default 256 MB; a resident batch's plans: all of it)
+void sparse_cache_keep_slab(SparsePlanCache* c, size_t bytes);
 // Levenberg-Marquardt or L-BFGS (prm.mode) for Systems systems[0 .. n) of the host batch `b`, which all have the structure of the first one
 // (fixed flags, tags, fields, components): one plan, every launch covers the whole group, results and solved variables
 // go straight to the resident batch `d` (d.vars, d.results). Synchronises `stream` before it returns.

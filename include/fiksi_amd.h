@@ -225,8 +225,8 @@ void fx_ctx_destroy(fx_ctx* ctx);
  * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment. */
 int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);
 /* Batches the grouped kernel takes, of min_systems Systems or more (default 8192; 0 keeps the current value): a scout
- * pass (residuals at the start values) and a radix sort hand the Systems out most-work-first, because a batch is as slow
- * as its slowest System plus the time before that System was started (~0.1 ms per 100 000 Systems; enable = 0 turns it
+ * pass (residuals at the start values) and a ranking of strided chunks hand the Systems out most-work-first, because a batch is as slow
+ * as its slowest System plus the time before that System was started (~0.035 ms per 100 000 Systems; enable = 0 turns it
  * off). Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
 /* Grouped kernel: a row of a wavefront that has finished its System (SinglePass: its block) waits up to `passes` trial passes (default 2) for a
