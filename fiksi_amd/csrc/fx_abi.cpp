@@ -1230,6 +1230,131 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
     return true;
 }
 
+// The program of the grouped kernel's one-structure build (fx_grouped_c.hip): everything about a System's STRUCTURE that kernel
+// needs, written once for a batch whose Systems all share it — one component, at most 32 variables and 32 expressions (every
+// expression a row of the component), 17 ... 32 free variables. Jt J is kept by its pattern: a slot per structural non-zero of
+// the lower triangle (all 32 diagonal entries included: the columns past the free variables are identity padding), one slot of
+// zero behind them. Bytes from the start of the table; words:
+// [0] version [1] variables [2] expressions [3] free variables [4] products (padded to 64) [5] right-hand-side entries (padded
+// to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [9] vcol (i8 [32]:
+// variable -> free column, -1 = fixed) [10] fidx (u8 [32]: free column -> variable) [11] rtag (u8 [32]) [12] gbase (u16 [32]:
+// first compact entry of a row) [13] gvar (u8 [32][8]: the variables a row reads, gradient order) [14] products (u32: entry a |
+// entry b << 8 | slot << 16, 0xFFFFFFFF = padding; rows ascending, a ascending, b from a upward, a pair of entries on one column
+// twice — the order fx_grouped.hip builds its lists in, and so the order of the additions) [15] right-hand side (u32: entry | row
+// << 8 | column << 16) [16] load table (u8 [16][64]: lane l's element i of column l + 16 q at [l][32 q + i] — the slot of
+// (max, min), or the zero slot) [17] words in all.
+struct GcHostProgram {
+    std::vector<uint32_t> words;
+    uint32_t nslots = 0, ng = 0;
+};
+static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
+                             uint32_t nvt, uint32_t net, GcHostProgram& out) {
+    out = GcHostProgram();
+    if (nvt == 0 || nvt > 32u || net == 0 || net > 32u) return false;
+    int8_t vcol[32];
+    uint8_t fidx[32] = {0}, rtag[32] = {0}, gvar[32][8] = {{0}};
+    uint16_t gbase[32] = {0};
+    uint32_t nfree = 0;
+    for (uint32_t i = 0; i < 32u; ++i) vcol[i] = -1;
+    for (uint32_t i = 0; i < nvt; ++i) {
+        if ((var_info[i] & fx::VAR_COMP_MASK) != 0) return false;  // (a variable of no component carries another number)
+        if (!(var_info[i] & fx::VAR_FIXED_BIT)) {
+            vcol[i] = (int8_t)nfree;
+            fidx[nfree++] = (uint8_t)i;
+        }
+    }
+    if (nfree <= 16u || nfree > 32u) return false;
+    int gcol[32][8];
+    uint32_t ng = 0;
+    for (uint32_t r = 0; r < net; ++r) {
+        if (expr_comp[r] != 0) return false;
+        const int tag = (int)(expr_tag[r] & 0x7F);
+        if (tag >= FX_TAG_POSE_X) return false;
+        uint32_t vars8[8];
+        const int k = fx::expand_vars(tag, expr_idx16 + 4 * (size_t)r, vars8);
+        rtag[r] = (uint8_t)tag;
+        gbase[r] = (uint16_t)ng;
+        for (int e = 0; e < 8; ++e) {
+            if (vars8[e] >= nvt) return false;
+            gvar[r][e] = (uint8_t)vars8[e];
+            gcol[r][e] = e < k ? (int)vcol[vars8[e]] : -1;
+        }
+        ng += (uint32_t)k;
+    }
+    if (ng > 256u) return false;
+    // the pattern of the lower triangle, slots in packed-triangle order
+    std::vector<int32_t> slot_of(32 * 33 / 2, -1);
+    auto tri = [](uint32_t hi, uint32_t lo) { return hi * (hi + 1u) / 2u + lo; };
+    for (uint32_t j = 0; j < 32u; ++j) slot_of[tri(j, j)] = 0;
+    for (uint32_t r = 0; r < net; ++r)
+        for (int a = 0; a < 8; ++a)
+            for (int bb = a; bb < 8; ++bb)
+                if (gcol[r][a] >= 0 && gcol[r][bb] >= 0) {
+                    const uint32_t ca = (uint32_t)gcol[r][a], cb = (uint32_t)gcol[r][bb];
+                    slot_of[tri(std::max(ca, cb), std::min(ca, cb))] = 0;
+                }
+    uint32_t nslots = 0;
+    for (int32_t& sl : slot_of)
+        if (sl == 0) sl = (int32_t)nslots++;
+    const uint32_t zero = nslots++;
+    nslots = (nslots + 1u) & ~1u;
+    if (nslots > 256u) return false;
+    std::vector<uint32_t> pw, pe;
+    for (uint32_t r = 0; r < net; ++r)
+        for (int a = 0; a < 8; ++a) {
+            if (gcol[r][a] < 0) continue;
+            const uint32_t ca = (uint32_t)gcol[r][a];
+            pe.push_back((gbase[r] + (uint32_t)a) | (r << 8) | (ca << 16));
+            for (int bb = a; bb < 8; ++bb) {
+                if (gcol[r][bb] < 0) continue;
+                const uint32_t cb = (uint32_t)gcol[r][bb];
+                const uint32_t w = (gbase[r] + (uint32_t)a) | ((gbase[r] + (uint32_t)bb) << 8) |
+                                   ((uint32_t)slot_of[tri(std::max(ca, cb), std::min(ca, cb))] << 16);
+                pw.push_back(w);
+                if (a != bb && ca == cb) pw.push_back(w);
+            }
+        }
+    while (pw.size() % 64u) pw.push_back(0xFFFFFFFFu);
+    while (pe.size() % 64u) pe.push_back(0xFFFFFFFFu);
+    uint8_t lt[16][64];
+    for (uint32_t l = 0; l < 16u; ++l)
+        for (uint32_t q = 0; q < 2u; ++q)
+            for (uint32_t i = 0; i < 32u; ++i) {
+                const uint32_t j = l + 16u * q;
+                const int32_t sl = slot_of[tri(std::max(i, j), std::min(i, j))];
+                lt[l][32u * q + i] = (uint8_t)(sl >= 0 ? (uint32_t)sl : zero);
+            }
+    std::vector<uint32_t>& w = out.words;
+    w.assign(20, 0);
+    auto put = [&](const void* src, size_t bytes) -> uint32_t {
+        const uint32_t at = (uint32_t)w.size() * 4u;
+        w.resize(w.size() + (bytes + 15u) / 16u * 4u, 0u);
+        memcpy(reinterpret_cast<unsigned char*>(w.data()) + at, src, bytes);
+        return at;
+    };
+    w[9] = put(vcol, sizeof(vcol));
+    w[10] = put(fidx, sizeof(fidx));
+    w[11] = put(rtag, sizeof(rtag));
+    w[12] = put(gbase, sizeof(gbase));
+    w[13] = put(gvar, sizeof(gvar));
+    w[14] = put(pw.data(), pw.size() * 4u);
+    w[15] = put(pe.data(), pe.size() * 4u);
+    w[16] = put(lt, sizeof(lt));
+    w[0] = 1u;
+    w[1] = nvt;
+    w[2] = net;
+    w[3] = nfree;
+    w[4] = (uint32_t)pw.size();
+    w[5] = (uint32_t)pe.size();
+    w[6] = nslots;
+    w[7] = (ng + 1u) & ~1u;
+    w[8] = zero;
+    w[17] = (uint32_t)w.size();
+    out.nslots = nslots;
+    out.ng = (ng + 1u) & ~1u;
+    return true;
+}
+
 // The same analysis compiled into a table-driven program for the grouped FX_STEP_QR build (fx_grouped.hip: four Systems per
 // wavefront, one per row of 16 lanes; batches of ONE structure, so one program serves every System). The permuted augmented
 // matrix [J | -r; sqrt(lambda) I | 0] is stored by its symbolic patterns — per column position j the rows of R(:, j) above the
@@ -2260,6 +2385,17 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     FX_UP(expr_param, batch->expr_param + e0, n_exprs)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
     if (sys_class) FX_UP(sys_class, sys_class, n_sys)
+    // a batch of one structure: the program of the grouped kernel's two-wavefronts-per-SIMD build (fx_grouped_c.hip), when
+    // the structure qualifies
+    GcHostProgram gc;
+    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free > 16u && p.max_free <= 32u &&
+        build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
+                         d.u_nexprs, gc)) {
+        FX_UP(gc_tab, gc.words.data(), gc.words.size())
+        d.gc_words = (uint32_t)gc.words.size();
+        d.gc_nslots = gc.nslots;
+        d.gc_ng = gc.ng;
+    }
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy
     FX_UP(vars, (const double*)batch->vars + v0, n_vars)

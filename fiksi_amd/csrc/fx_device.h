@@ -129,6 +129,10 @@ struct DeviceBatch {
     int16_t* g_colof;         // [total] variable -> free column of the block in flight
     // FX_STEP_QR plans, built on first use (null until then)
     QrPlans qr_none, qr_units;
+    // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_abi.cpp: build_gc_program): null unless the
+    // batch is uniform with one component of 17 ... 32 free variables among at most 32, and at most 32 expressions
+    uint32_t* gc_tab;
+    uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
     // only the pose instantiations of the solve kernel may run it
     uint32_t has_pose;
@@ -181,6 +185,10 @@ size_t wide_qr_lds_bytes(uint32_t max_free, uint32_t max_vars, uint32_t max_rows
 bool grouped_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool single_pass_blocks);
+// ... its build for batches of one structure, two wavefronts per SIMD (fx_grouped_c.hip)
+bool grouped_c_applies(const DeviceBatch& b, const LmParams& p);
+hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+size_t grouped_c_lds_bytes(const DeviceBatch& b);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // dst[0 .. bytes) = src[0 .. bytes), 16 bytes per thread (both 16-byte aligned, bytes a multiple of 16): pulls a one-shot
