@@ -214,7 +214,10 @@ def main() -> int:
             },
             "roofline": None,  # filled below: the HBM figure needs the 500k-System batch (weak scaling, N = 1) or falls back
             "solve_kernel": {
-                "kernel": ("lm_solve_grouped_kernel<2 columns per lane, f64> (fused scale+perturb+assembly+LM+write-back, four "
+                "kernel": ("lm_solve_grouped_c_kernel (fused scale+perturb+assembly+LM+write-back, four Systems per wavefront: one per "
+                           "DPP row; the build for batches of one structure — lists shared by the wavefront, Jt J by its pattern, "
+                           "two wavefronts per SIMD: fx_grouped_c.hip)") if db.grouped_build() == 1 else
+                          ("lm_solve_grouped_kernel<2 columns per lane, f64> (fused scale+perturb+assembly+LM+write-back, four "
                            "Systems per wavefront: one per DPP row, fx_grouped.hip)") if db.solve_route() == 1 else
                           "lm_solve_kernel<32> (fused scale+perturb+assembly+LM+write-back, one wavefront per system)",
                 "avg_launch_ms": solve_ms,
@@ -229,7 +232,8 @@ def main() -> int:
                 "includes": "the scout pass + chunk ranking of fx_ctx_set_presort (most-work-first hand-out, two launches, ~0.035 ms; part of every step)",
                 "note": "latency/f64-VALU bound by construction (~14 kflop per LM trial on a serial "
                         "Cholesky dependency chain); HBM is not its roof (SURVEY.md §7, §8d). "
-                        "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead",
+                        "FIKSI_AMD_GROUPED=0 times the one-System-per-wavefront kernel instead, FIKSI_AMD_GROUPED_C=0 the "
+                        "grouped kernel's general build (one wavefront per SIMD)",
             },
         }
         in_cache = {
@@ -254,7 +258,7 @@ def main() -> int:
                          "note": "in-cache figure (the 500k-System HBM measurement runs at N = 1, weak scaling)"})
         roof["in_cache"] = in_cache
         out["roofline"] = roof
-        out["solve_kernel"].update(sq_counters("lm_solve_grouped_kernel", FLOPS_PER_TRIAL * trials_per_step))
+        out["solve_kernel"].update(sq_counters("lm_solve_grouped", FLOPS_PER_TRIAL * trials_per_step))
         if world == 1 and not args.quick:
             out["host_path"] = host_path(ctx, batch, np)
             out["step_solvers"] = step_solvers(ctx, db, abi, np, n_sys, solve_ms)

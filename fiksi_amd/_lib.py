@@ -132,6 +132,7 @@ SIGNATURES = [
     ("fx_batch_get_jacobian_values", C.c_int, [_vp, _vp, _vp]),
     ("fx_debug_phase_cycles", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts), u64p]),
     ("fx_debug_solve_route", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts), C.POINTER(C.c_int)]),
+    ("fx_debug_grouped_build", C.c_int, [_vp, _vp, C.POINTER(FxSolvingOpts), C.POINTER(C.c_int)]),
     ("fx_timer_begin", C.c_int, [_vp]),
     ("fx_timer_end", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("fx_system_solve_batch", C.c_int, [_vp, C.POINTER(FxBatch), C.POINTER(FxSolvingOpts), _vp]),

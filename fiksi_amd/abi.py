@@ -360,6 +360,13 @@ class DeviceBatch:
         check(lib.fx_debug_solve_route(self.ctx.handle, self._h, C.byref(o), C.byref(r)), "fx_debug_solve_route")
         return int(r.value)
 
+    def grouped_build(self, opts=None) -> int:
+        """-1: not the grouped kernel, 0: its general build, 1: its build for batches of one structure (diagnostic)."""
+        o = opts if opts is not None else solving_opts()
+        r = C.c_int(0)
+        check(lib.fx_debug_grouped_build(self.ctx.handle, self._h, C.byref(o), C.byref(r)), "fx_debug_grouped_build")
+        return int(r.value)
+
     def schedule_by_last_solve(self, enable: bool = True):
         """Later solves start the Systems that took the most LM trials in the last solve first (results unchanged)."""
         check(lib.fx_batch_schedule_by_last_solve(self.ctx.handle, self._h, 1 if enable else 0), "fx_batch_schedule_by_last_solve")

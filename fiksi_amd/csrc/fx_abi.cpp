@@ -672,6 +672,7 @@ struct fx_ctx {
     size_t free_bytes = 0;
     // routing of batches of small Systems (fx_ctx_set_routing)
     int route_grouped = -1;
+    int grouped_one_structure = 1;  // the grouped kernel's build for batches of one structure (FIKSI_AMD_GROUPED_C=0: never)
     uint32_t grouped_min_systems = 8u;
     int presort = 1;                       // fx_ctx_set_presort
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
@@ -756,6 +757,7 @@ struct fx_ctx {
     uint32_t presort_min_systems = 8192u;
     void route(fx::LmParams& p) const {
         p.route_grouped = route_grouped;
+        p.grouped_one_structure = grouped_one_structure;
         p.grouped_min_systems = grouped_min_systems;
         p.hold_passes = hold_passes;
         p.ladder = ladder;
@@ -1234,15 +1236,15 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 // needs, written once for a batch whose Systems all share it — one component, at most 32 variables and 32 expressions (every
 // expression a row of the component), 17 ... 32 free variables. Jt J is kept by its pattern: a slot per structural non-zero of
 // the lower triangle (all 32 diagonal entries included: the columns past the free variables are identity padding), one slot of
-// zero behind them. Bytes from the start of the table; words:
+// zero behind them. Words:
 // [0] version [1] variables [2] expressions [3] free variables [4] products (padded to 64) [5] right-hand-side entries (padded
-// to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [9] vcol (i8 [32]:
-// variable -> free column, -1 = fixed) [10] fidx (u8 [32]: free column -> variable) [11] rtag (u8 [32]) [12] gbase (u16 [32]:
-// first compact entry of a row) [13] gvar (u8 [32][8]: the variables a row reads, gradient order) [14] products (u32: entry a |
-// entry b << 8 | slot << 16, 0xFFFFFFFF = padding; rows ascending, a ascending, b from a upward, a pair of entries on one column
-// twice — the order fx_grouped.hip builds its lists in, and so the order of the additions) [15] right-hand side (u32: entry | row
-// << 8 | column << 16) [16] load table (u8 [16][64]: lane l's element i of column l + 16 q at [l][32 q + i] — the slot of
-// (max, min), or the zero slot) [17] words in all.
+// to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [17] words in all;
+// then, at the byte offsets GC_T_* of fx_device.h: vcol (i8 [32]: variable -> free column, -1 = fixed), fidx (u8 [32]: free
+// column -> variable), rtag (u8 [32]), gbase (u16 [32]: first compact entry of a row), gvar (u8 [32][8]: the variables a row
+// reads, gradient order), the load table (u8 [16][64]: lane l's element i of column l + 16 q at [l][32 q + i] — the slot of
+// (max, min), or the zero slot), the right-hand side (u32: entry | row << 8 | column << 16) and behind it the products (u32:
+// entry a | entry b << 8 | slot << 16, 0xFFFFFFFF = padding; rows ascending, a ascending, b from a upward, a pair of entries on
+// one column twice — the order fx_grouped.hip builds its lists in, and so the order of the additions).
 struct GcHostProgram {
     std::vector<uint32_t> words;
     uint32_t nslots = 0, ng = 0;
@@ -1332,14 +1334,15 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
         memcpy(reinterpret_cast<unsigned char*>(w.data()) + at, src, bytes);
         return at;
     };
-    w[9] = put(vcol, sizeof(vcol));
-    w[10] = put(fidx, sizeof(fidx));
-    w[11] = put(rtag, sizeof(rtag));
-    w[12] = put(gbase, sizeof(gbase));
-    w[13] = put(gvar, sizeof(gvar));
-    w[14] = put(pw.data(), pw.size() * 4u);
-    w[15] = put(pe.data(), pe.size() * 4u);
-    w[16] = put(lt, sizeof(lt));
+    bool placed = put(vcol, sizeof(vcol)) == fx::GC_T_VCOL;
+    placed = put(fidx, sizeof(fidx)) == fx::GC_T_FIDX && placed;
+    placed = put(rtag, sizeof(rtag)) == fx::GC_T_RTAG && placed;
+    placed = put(gbase, sizeof(gbase)) == fx::GC_T_GBASE && placed;
+    placed = put(gvar, sizeof(gvar)) == fx::GC_T_GVAR && placed;
+    placed = put(lt, sizeof(lt)) == fx::GC_T_LT && placed;
+    placed = put(pe.data(), pe.size() * 4u) == fx::GC_T_PE && placed;
+    (void)put(pw.data(), pw.size() * 4u);
+    if (!placed) return false;
     w[0] = 1u;
     w[1] = nvt;
     w[2] = net;
@@ -2156,6 +2159,8 @@ int fx_ctx_create(fx_ctx** out, int device) {
     fx_ctx* ctx = new (std::nothrow) fx_ctx();
     if (!ctx) return fail(FX_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    if (const char* sw = getenv("FIKSI_AMD_GROUPED_C"))  // A / B and tests: 0 keeps every batch on the grouped kernel's general build
+        if (sw[0] == '0') ctx->grouped_one_structure = 0;
     if (const char* sw = getenv("FIKSI_AMD_GROUPED")) {  // the default of fx_ctx_set_routing's first option
         if (sw[0] == '0') ctx->route_grouped = 0;
         if (sw[0] == '1') ctx->route_grouped = 1;
@@ -2740,6 +2745,20 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
     *route = fx::grouped_applies(db->d, p) ? 1 : 0;
+    return FX_OK;
+}
+
+int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!db || !build) return fail(FX_ERR_INVALID, "bad argument");
+    fx_solving_opts o;
+    if (opts) o = *opts; else fx_solving_opts_default(&o);
+    fx::LmParams p;
+    ctx->route(p);
+    p.lm = o.lm;
+    p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
+    *build = !fx::grouped_applies(db->d, p) ? -1 : (p.lm.solver == FX_STEP_CHOLESKY && fx::grouped_c_applies(db->d, p)) ? 1 : 0;
     return FX_OK;
 }
 

@@ -66,6 +66,10 @@ struct QrPlans {
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
+// The program of the grouped kernel's one-structure build (fx_grouped_c.hip; written by fx_abi.cpp: build_gc_program): byte
+// offsets of its tables of fixed size; the right-hand-side list and, behind it, the product list follow at GC_T_PE
+constexpr uint32_t GC_T_VCOL = 80, GC_T_FIDX = 112, GC_T_RTAG = 144, GC_T_GBASE = 176, GC_T_GVAR = 240, GC_T_LT = 496, GC_T_PE = 1520;
+
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
     uint32_t n_systems, n_vars, n_exprs;
@@ -145,6 +149,7 @@ struct LmParams {
     // routing of batches of small Systems (fx_ctx_set_routing): -1 = by batch size, 0 = never the grouped kernel,
     // 1 = whenever the batch qualifies; the size from which a batch takes it
     int route_grouped = -1;
+    int grouped_one_structure = 1;  // 0: batches of one structure stay on the general build (fx_grouped_c.hip is never taken)
     uint32_t grouped_min_systems = 8u;
     uint32_t hold_passes = 2u;  // grouped kernel: passes a finished row waits for a second one before its set-up blocks (fx_ctx_set_hold_passes)
     // grouped kernel, the lambda ladder (fx_ctx_set_ladder): rows without a System of their own try the next lambdas of a

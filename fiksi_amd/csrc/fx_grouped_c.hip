@@ -29,24 +29,18 @@
 
 namespace fx {
 
-// bytes, per System block (XS at 0)
+// A System's block, bytes: everything of fixed size first, at offsets the instructions carry as immediates (one base register per
+// row), then Jt J's slots and behind them the compact Jacobian rows
+constexpr uint32_t GC_XS = 0, GC_RHS = 256, GC_R = 512, GC_P = 768, GC_VOUT = 1024, GC_STASH = 1280, GC_A = 1296;
 struct GcLayout {
-    uint32_t tab_bytes, off_a, off_rhs, off_g, off_r, off_p, off_vout, stride;
+    uint32_t tab_bytes, off_g, stride;
 };
 
 static GcLayout make_gc_layout(const DeviceBatch& b) {
     GcLayout L;
-    auto al = [](uint32_t bytes) { return (bytes + 15u) & ~15u; };
-    uint32_t o = 32u * 8u;  // XS
-    auto take = [&](uint32_t bytes) { uint32_t at = o; o += al(bytes); return at; };
-    L.tab_bytes = al(b.gc_words * 4u);
-    L.off_a = take(b.gc_nslots * 8u);
-    L.off_rhs = take(32u * 8u);
-    L.off_g = take(b.gc_ng * 8u);
-    L.off_r = take(32u * 8u);
-    L.off_p = take(32u * 8u);
-    L.off_vout = take(32u * 8u);
-    L.stride = o;
+    L.tab_bytes = (b.gc_words * 4u + 15u) & ~15u;
+    L.off_g = GC_A + b.gc_nslots * 8u;  // (slots are an even number: 16-byte aligned)
+    L.stride = L.off_g + b.gc_ng * 8u;
     return L;
 }
 
@@ -69,24 +63,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t nvt = rfl(TB[1]), net = rfl(TB[2]), nfree = rfl(TB[3]), n_pw = rfl(TB[4]), n_pe = rfl(TB[5]), nslots = rfl(TB[6]);
-    const int8_t* vcol = reinterpret_cast<const int8_t*>(smem + rfl(TB[9]));      // [32] variable -> free column or -1
-    const uint8_t* fidx = smem + rfl(TB[10]);                                     // [32] free column -> variable
-    const uint8_t* rtag = smem + rfl(TB[11]);                                     // [32] kind of expression i
-    const uint16_t* gbaseT = reinterpret_cast<const uint16_t*>(smem + rfl(TB[12]));  // [32] first compact Jacobian entry of row i
-    const uint2* gvar = reinterpret_cast<const uint2*>(smem + rfl(TB[13]));       // [32] eight variable numbers, a byte each
-    const uint32_t* PW = reinterpret_cast<const uint32_t*>(smem + rfl(TB[14]));   // products: entry a | entry b << 8 | slot << 16
-    const uint32_t* PE = reinterpret_cast<const uint32_t*>(smem + rfl(TB[15]));   // right-hand side: entry | row << 8 | column << 16
-    const uint4* LT = reinterpret_cast<const uint4*>(smem + rfl(TB[16]) + (uint32_t)hl * 64u);  // this lane's 64 slot numbers
+    // (the tables of fixed size sit at fixed places: fx_device.h, GC_T_*)
+    const int8_t* vcol = reinterpret_cast<const int8_t*>(smem + GC_T_VCOL);         // [32] variable -> free column or -1
+    const uint8_t* fidx = smem + GC_T_FIDX;                                         // [32] free column -> variable
+    const uint8_t* rtag = smem + GC_T_RTAG;                                         // [32] kind of expression i
+    const uint16_t* gbaseT = reinterpret_cast<const uint16_t*>(smem + GC_T_GBASE);  // [32] first compact Jacobian entry of row i
+    const uint2* gvar = reinterpret_cast<const uint2*>(smem + GC_T_GVAR);           // [32] eight variable numbers, a byte each
+    const uint4* LT = reinterpret_cast<const uint4*>(smem + GC_T_LT + (uint32_t)hl * 64u);  // this lane's 64 slot numbers
+    const uint32_t* PE = reinterpret_cast<const uint32_t*>(smem + GC_T_PE);         // right-hand side: entry | row << 8 | column << 16
+    const uint32_t* PW = reinterpret_cast<const uint32_t*>(smem + GC_T_PE) + n_pe;  // products: entry a | entry b << 8 | slot << 16
 
     unsigned char* const rows0 = smem + L.tab_bytes;
     unsigned char* base = rows0 + (uint32_t)myrow * L.stride;
-    T* XS = reinterpret_cast<T*>(base);                  // [32] working variables: trial point on the free ones
-    T* At = reinterpret_cast<T*>(base + L.off_a);        // Jt J by slots (+ lambda on the diagonal per trial)
-    T* rhsv = reinterpret_cast<T*>(base + L.off_rhs);    // [32] -Jt r
+    T* XS = reinterpret_cast<T*>(base + GC_XS);          // [32] working variables: trial point on the free ones
+    T* At = reinterpret_cast<T*>(base + GC_A);           // Jt J by slots (+ lambda on the diagonal per trial)
+    T* rhsv = reinterpret_cast<T*>(base + GC_RHS);       // [32] -Jt r
     T* G = reinterpret_cast<T*>(base + L.off_g);         // compact Jacobian rows of the last evaluated point
-    T* R = reinterpret_cast<T*>(base + L.off_r);         // [32]
-    T* P = reinterpret_cast<T*>(base + L.off_p);         // [32] scaled parameters
-    double* VOUT = reinterpret_cast<double*>(base + L.off_vout);  // [32] unscaled values as written back
+    T* R = reinterpret_cast<T*>(base + GC_R);            // [32]
+    T* P = reinterpret_cast<T*>(base + GC_P);            // [32] scaled parameters
+    double* VOUT = reinterpret_cast<double*>(base + GC_VOUT);    // [32] unscaled values as written back
+    double* STASH = reinterpret_cast<double*>(base + GC_STASH);  // [2] the System's scale, the SSE of its start point
 
     const fx_lm_opts o = prm.lm;
     auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & 0xFFFFu; };
@@ -103,16 +99,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // per-row state (identical in every lane of the row unless noted)
     int phase = GP_NEXT;
     uint32_t s = 0;
-    double scale = 1.0;
     T xc[NC], diag[NC], rhs_l[NC];
-    double c_param[NC];  // the unscaled parameters of expressions hl, hl + 16 (closing check)
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         xc[q] = rhs_l[q] = T(0);
         diag[q] = T(1);
-        c_param[q] = 0.0;
     }
-    T sse = T(0), sse_start = T(0);
+    T sse = T(0);
     double lambda = 0.0;
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
     bool fresh = false;
@@ -237,7 +230,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             } else {
                 s = nxt;
                 const uint32_t v0 = s * nvt, e0 = s * net;
-                double c_var[NC];
+                double c_var[NC], c_param[NC];
                 int tagk[NC], colk[NC];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
@@ -249,8 +242,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 // K0a: system scale, summed strictly in reference order (utils.rs:11-33)
-                scale = 1.0;
-                double scale_recip = 1.0;
+                double scale = 1.0, scale_recip = 1.0;
                 if (prm.mode & 1u) {
                     double sum = 0.0;
                     uint32_t count = nvt;
@@ -291,6 +283,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                         P[i] = prm_e;
                     }
                 }
+                if (hl == 0) STASH[0] = scale;
                 group_sync();
 #pragma unroll
                 for (int q = 0; q < NC; ++q) xc[q] = ((uint32_t)(hl + RS * q) < nfree) ? XS[my_vi[q]] : T(0);
@@ -484,7 +477,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             bool assemble = false, fin = false;
             if (fresh) {  // the start point
                 sse = sse_t;
-                sse_start = sse_t;
+                if (hl == 0) STASH[1] = sse_t;
                 assemble = true;
             } else {
                 if (kw > 0) {  // the plain rejects in front (lm.rs:189)
@@ -534,9 +527,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const unsigned char* wb = rows0 + (uint32_t)win_row * L.stride;
                     const double2* gs = reinterpret_cast<const double2*>(wb + L.off_g);
                     double2* gd = reinterpret_cast<double2*>(G);
-                    const uint32_t ng2 = (L.off_r - L.off_g) / 16u;
+                    const uint32_t ng2 = (L.stride - L.off_g) / 16u;
                     for (uint32_t i = hl; i < ng2; i += RS) gd[i] = gs[i];
-                    const T* rs = reinterpret_cast<const T*>(wb + L.off_r);
+                    const T* rs = reinterpret_cast<const T*>(wb + GC_R);
 #pragma unroll
                     for (int q = 0; q < NC; ++q) R[hl + RS * q] = rs[hl + RS * q];
                     group_sync();
@@ -581,7 +574,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // ================= FINISH: write back scale * x (assemble/mod.rs:161-166), the closing check
         // (constraints/mod.rs:96-109), the result record =================
         if (finish_now) {
-            const uint32_t v0 = s * nvt;
+            const uint32_t v0 = s * nvt, e0 = s * net;
+            double c_param[NC];  // the unscaled parameters of expressions hl, hl + 16
+#pragma unroll
+            for (int k = 0; k < NC; ++k) c_param[k] = (uint32_t)(RS * k + hl) < net ? b.expr_param[e0 + (uint32_t)(RS * k + hl)] : 0.0;
+            const double scale = STASH[0];
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 if ((uint32_t)(hl + RS * q) < nfree) {
@@ -610,7 +607,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 res.exit = exit_code;
                 res.ncomp = 1;
                 res.scale = scale;
-                res.sse0 = (double)sse_start;
+                res.sse0 = STASH[1];
                 res.sse = (double)sse;
                 res.sse_unscaled = sse_u;
                 b.results[s] = res;
@@ -634,8 +631,7 @@ size_t grouped_c_lds_bytes(const DeviceBatch& b) {
 }
 
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
-    static const char* env = getenv("FIKSI_AMD_GROUPED_C");  // 0: the general build for every batch (A/B measurements, tests)
-    if (env && env[0] == '0') return false;
+    if (!p.grouped_one_structure) return false;  // (a context created under FIKSI_AMD_GROUPED_C=0: A / B measurements, tests)
     if (!b.gc_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
     if (p.prof || p.lm.precision == 32 || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
     // six wavefronts per CU or more (a SIMD with two is what the build is for)

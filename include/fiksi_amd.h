@@ -321,6 +321,11 @@ int fx_debug_phase_cycles(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opt
  * variables of this batch with these options: 0 = lm_solve_kernel (one System per wavefront),
  * 1 = the grouped kernel (four Systems per wavefront, fx_grouped.hip). Launches nothing. */
 int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* route);
+/* Diagnostic only: which BUILD of the grouped kernel such a launch would be: -1 = not the grouped kernel, 0 = the general build
+ * (one wavefront per SIMD for components of 17 ... 32 free variables), 1 = the build for batches of one structure
+ * (fx_grouped_c.hip: the structure's lists shared by a wavefront's four Systems, Jt J by its pattern, two wavefronts per
+ * SIMD; same bits). A context created under FIKSI_AMD_GROUPED_C=0 never takes build 1. Launches nothing. */
+int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */
 /* == assemble::solve: batch->vars in: unscaled values, out: solved values. results may be NULL.

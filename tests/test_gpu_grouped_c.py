@@ -1,0 +1,120 @@
+"""The grouped kernel's build for batches of ONE structure (fx_grouped_c.hip: the structure's lists shared by the four Systems
+of a wavefront, Jt J stored by its pattern, two wavefronts per SIMD) against the general build (fx_grouped.hip) it replaces
+for such batches: the same operations on the same operands in the same order, so every bit of every result must agree.
+(The oracle comparisons of test_gpu_grouped.py / test_gpu_parity.py run through this build too: their ring16 batches are of
+one structure.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx_general(fiksi):
+    """A context that never takes the one-structure build (FIKSI_AMD_GROUPED_C is read when a context is created)."""
+    import os
+
+    old = os.environ.get("FIKSI_AMD_GROUPED_C")
+    os.environ["FIKSI_AMD_GROUPED_C"] = "0"
+    try:
+        c = fiksi.Context(0)
+    finally:
+        if old is None:
+            del os.environ["FIKSI_AMD_GROUPED_C"]
+        else:
+            os.environ["FIKSI_AMD_GROUPED_C"] = old
+    yield c
+    c.close()
+
+
+def _mixed_uniform(n, fix_some):
+    """n sketches of ONE topology that uses every constraint kind (an expression reading a variable twice included)."""
+    from fiksi_amd import workloads
+
+    from helpers import mixed_sketch
+
+    return workloads.concat([mixed_sketch(2 * s + int(fix_some), fix_some=fix_some).flatten() for s in range(n)])
+
+
+def _cases():
+    from fiksi_amd import workloads
+
+    return [("ring16", workloads.ring16(4099), {}), ("ring16_fixed_gauge", workloads.ring16(3001, fix_gauge=True), {}),
+            ("ring16_inconsistent", workloads.ring16(3000, inconsistent=True), {}),
+            ("ring16_trial_cap", workloads.ring16(2000), {"max_trials": 21}),
+            ("ring16_no_perturbation", workloads.ring16(2000), {"perturb": False}),
+            ("hinged_4", workloads.hinged_triangles(2000, 4), {}), ("hinged_5", workloads.hinged_triangles(1500, 5), {}),
+            ("hinged_7", workloads.hinged_triangles(1203, 7), {}),
+            ("every_kind", _mixed_uniform(1500, False), {}), ("every_kind_some_fixed", _mixed_uniform(1500, True), {})]
+
+
+def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
+    from fiksi_amd import abi, workloads
+
+    taken = {}
+    for name, b, kw in _cases():
+        db = ctx.upload(b)
+        taken[name] = db.grouped_build(abi.solving_opts(**kw))
+        # the other builds of the same batch are never this one
+        assert db.grouped_build(abi.solving_opts(f32=True)) != 1 and db.grouped_build(abi.solving_opts(decomposer=1)) != 1
+        assert db.grouped_build(abi.solving_opts(solver=1)) != 1 and db.grouped_build(abi.solving_opts(solver=2)) != 1
+        db.free()
+        dg = ctx_general.upload(b)
+        assert dg.grouped_build(abi.solving_opts(**kw)) == 0
+        dg.free()
+    for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "hinged_4",
+                 "hinged_5", "hinged_7"):
+        assert taken[name] == 1, taken
+    # not of one structure / 16 free variables or fewer / more than 32 variables: the general build
+    for b in (workloads.ring16_two_structures(2000), workloads.hinged_triangles(2000, 3), workloads.hinged_triangles(500, 8)):
+        db = ctx.upload(b)
+        assert db.grouped_build() == 0
+        db.free()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_same_bits_as_the_general_build(fiksi, ctx, ctx_general):
+    """Every solved variable and every field of every result record, for the queue in index order and longest-first, with
+    the lambda ladder off, at the end of the queue, and with every wavefront one ladder from the start."""
+    from fiksi_amd import abi
+
+    try:
+        for name, b, kw in _cases():
+            o = abi.solving_opts(**kw)
+            ctx_general.set_ladder(True)
+            v0, r0 = ctx_general.system_solve_batch(b, o)
+            for ladder in ((False, 0, 16, False), (True, 0, 16, True), (True, 1 << 30, 0, True)):
+                ctx.set_ladder(*ladder)
+                for presort in (True, False):
+                    ctx.set_presort(presort, 1)
+                    v1, r1 = ctx.system_solve_batch(b, o)
+                    assert np.array_equal(_bits(v1), _bits(v0)), (name, ladder, presort)
+                    assert r1.tobytes() == r0.tobytes(), (name, ladder, presort)
+            if "max_trials" in kw:
+                assert int(r0["trials"].max()) == 21
+    finally:
+        ctx.set_ladder()
+        ctx.set_presort(True, 8192)
+        ctx_general.set_ladder()
+
+
+def test_resident_batch_solved_again_and_in_chunks(fiksi, ctx, ctx_general):
+    """A resident batch keeps its program between solves; the host-buffer call cuts a big batch into chunks, each with its own
+    copy of the program."""
+    from fiksi_amd import workloads
+
+    b = workloads.ring16(30000)
+    db = ctx.upload(b)
+    assert db.grouped_build() == 1
+    db.system_solve()
+    v1, r1 = db.get_vars().copy(), db.get_results().copy()
+    db.system_solve()
+    assert np.array_equal(_bits(db.get_vars()), _bits(v1)) and db.get_results().tobytes() == r1.tobytes()
+    db.free()
+    v0, r0 = ctx_general.system_solve_batch(b)
+    v2, r2 = ctx.system_solve_batch(b)  # (a big host batch goes up and is solved in two chunks)
+    assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
+    assert np.array_equal(_bits(v2), _bits(v0)) and r2.tobytes() == r0.tobytes()
