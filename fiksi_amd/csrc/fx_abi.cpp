@@ -1233,31 +1233,35 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 }
 
 // The program of the grouped kernel's one-structure build (fx_grouped_c.hip): everything about a System's STRUCTURE that kernel
-// needs, written once for a batch whose Systems all share it — one component, at most 32 variables and 32 expressions (every
-// expression a row of the component), 17 ... 32 free variables. Jt J is kept by its pattern: a slot per structural non-zero of
-// the lower triangle (all 32 diagonal entries included: the columns past the free variables are identity padding), one slot of
+// needs, written once for a batch whose Systems all share it — one component, at most NV = 32 (48) variables and expressions
+// (every expression a row of the component), 17 ... 32 (33 ... 48) free variables: two (three) matrix columns per lane. Jt J is kept by its pattern: a slot per structural non-zero of
+// the lower triangle (all NV diagonal entries included: the columns past the free variables are identity padding), one slot of
 // zero behind them. Words:
 // [0] version [1] variables [2] expressions [3] free variables [4] products (padded to 64) [5] right-hand-side entries (padded
 // to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [17] words in all;
-// then, at the byte offsets GC_T_* of fx_device.h: vcol (i8 [32]: variable -> free column, -1 = fixed), fidx (u8 [32]: free
-// column -> variable), rtag (u8 [32]), gbase (u16 [32]: first compact entry of a row), gvar (u8 [32][8]: the variables a row
-// reads, gradient order), the load table (u8 [16][64]: lane l's element i of column l + 16 q at [l][32 q + i] — the slot of
+// then, at the byte offsets of fx_device.h's GcTable: vcol (i8 [NV]: variable -> free column, -1 = fixed), fidx (u8 [NV]: free
+// column -> variable), rtag (u8 [NV]), gbase (u16 [NV]: first compact entry of a row), gvar (u8 [NV][8]: the variables a row
+// reads, gradient order), the load table (u8 [16][NC NV]: lane l's element i of column l + 16 q at [l][NV q + i] — the slot of
 // (max, min), or the zero slot), the right-hand side (u32: entry | row << 8 | column << 16) and behind it the products (u32:
 // entry a | entry b << 8 | slot << 16, 0xFFFFFFFF = padding; rows ascending, a ascending, b from a upward, a pair of entries on
 // one column twice — the order fx_grouped.hip builds its lists in, and so the order of the additions).
 struct GcHostProgram {
     std::vector<uint32_t> words;
-    uint32_t nslots = 0, ng = 0;
+    uint32_t nslots = 0, ng = 0, nc = 0;
 };
-static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
-                             uint32_t nvt, uint32_t net, GcHostProgram& out) {
+template <int NC>
+static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
+                               uint32_t nvt, uint32_t net, GcHostProgram& out) {
+    using TK = fx::GcTable<NC>;
+    constexpr uint32_t NV = TK::NV;
     out = GcHostProgram();
-    if (nvt == 0 || nvt > 32u || net == 0 || net > 32u) return false;
-    int8_t vcol[32];
-    uint8_t fidx[32] = {0}, rtag[32] = {0}, gvar[32][8] = {{0}};
-    uint16_t gbase[32] = {0};
+    out.nc = NC;
+    if (nvt == 0 || nvt > NV || net == 0 || net > NV) return false;
+    int8_t vcol[NV];
+    uint8_t fidx[NV] = {0}, rtag[NV] = {0}, gvar[NV][8] = {{0}};
+    uint16_t gbase[NV] = {0};
     uint32_t nfree = 0;
-    for (uint32_t i = 0; i < 32u; ++i) vcol[i] = -1;
+    for (uint32_t i = 0; i < NV; ++i) vcol[i] = -1;
     for (uint32_t i = 0; i < nvt; ++i) {
         if ((var_info[i] & fx::VAR_COMP_MASK) != 0) return false;  // (a variable of no component carries another number)
         if (!(var_info[i] & fx::VAR_FIXED_BIT)) {
@@ -1265,8 +1269,8 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
             fidx[nfree++] = (uint8_t)i;
         }
     }
-    if (nfree <= 16u || nfree > 32u) return false;
-    int gcol[32][8];
+    if (nfree <= NV - 16u || nfree > NV) return false;
+    int gcol[NV][8];
     uint32_t ng = 0;
     for (uint32_t r = 0; r < net; ++r) {
         if (expr_comp[r] != 0) return false;
@@ -1285,9 +1289,9 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
     }
     if (ng > 256u) return false;
     // the pattern of the lower triangle, slots in packed-triangle order
-    std::vector<int32_t> slot_of(32 * 33 / 2, -1);
+    std::vector<int32_t> slot_of(NV * (NV + 1u) / 2u, -1);
     auto tri = [](uint32_t hi, uint32_t lo) { return hi * (hi + 1u) / 2u + lo; };
-    for (uint32_t j = 0; j < 32u; ++j) slot_of[tri(j, j)] = 0;
+    for (uint32_t j = 0; j < NV; ++j) slot_of[tri(j, j)] = 0;
     for (uint32_t r = 0; r < net; ++r)
         for (int a = 0; a < 8; ++a)
             for (int bb = a; bb < 8; ++bb)
@@ -1318,13 +1322,13 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
         }
     while (pw.size() % 64u) pw.push_back(0xFFFFFFFFu);
     while (pe.size() % 64u) pe.push_back(0xFFFFFFFFu);
-    uint8_t lt[16][64];
+    std::vector<uint8_t> lt((size_t)16 * NC * NV);
     for (uint32_t l = 0; l < 16u; ++l)
-        for (uint32_t q = 0; q < 2u; ++q)
-            for (uint32_t i = 0; i < 32u; ++i) {
+        for (uint32_t q = 0; q < (uint32_t)NC; ++q)
+            for (uint32_t i = 0; i < NV; ++i) {
                 const uint32_t j = l + 16u * q;
                 const int32_t sl = slot_of[tri(std::max(i, j), std::min(i, j))];
-                lt[l][32u * q + i] = (uint8_t)(sl >= 0 ? (uint32_t)sl : zero);
+                lt[(size_t)l * NC * NV + NV * q + i] = (uint8_t)(sl >= 0 ? (uint32_t)sl : zero);
             }
     std::vector<uint32_t>& w = out.words;
     w.assign(20, 0);
@@ -1334,13 +1338,14 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
         memcpy(reinterpret_cast<unsigned char*>(w.data()) + at, src, bytes);
         return at;
     };
-    bool placed = put(vcol, sizeof(vcol)) == fx::GC_T_VCOL;
-    placed = put(fidx, sizeof(fidx)) == fx::GC_T_FIDX && placed;
-    placed = put(rtag, sizeof(rtag)) == fx::GC_T_RTAG && placed;
-    placed = put(gbase, sizeof(gbase)) == fx::GC_T_GBASE && placed;
-    placed = put(gvar, sizeof(gvar)) == fx::GC_T_GVAR && placed;
-    placed = put(lt, sizeof(lt)) == fx::GC_T_LT && placed;
-    placed = put(pe.data(), pe.size() * 4u) == fx::GC_T_PE && placed;
+    // (the tables are a multiple of 16 bytes each, so `put` places them back to back where GcTable says)
+    bool placed = put(vcol, sizeof(vcol)) == TK::VCOL;
+    placed = put(fidx, sizeof(fidx)) == TK::FIDX && placed;
+    placed = put(rtag, sizeof(rtag)) == TK::RTAG && placed;
+    placed = put(gbase, sizeof(gbase)) == TK::GBASE && placed;
+    placed = put(gvar, sizeof(gvar)) == TK::GVAR && placed;
+    placed = put(lt.data(), lt.size()) == TK::LT && placed;
+    placed = put(pe.data(), pe.size() * 4u) == TK::PE && placed;
     (void)put(pw.data(), pw.size() * 4u);
     if (!placed) return false;
     w[0] = 1u;
@@ -1356,6 +1361,11 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
     out.nslots = nslots;
     out.ng = (ng + 1u) & ~1u;
     return true;
+}
+static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
+                             uint32_t nvt, uint32_t net, uint32_t max_free, GcHostProgram& out) {
+    if (max_free > 32u) return build_gc_program_t<3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
+    return build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
 }
 
 // The same analysis compiled into a table-driven program for the grouped FX_STEP_QR build (fx_grouped.hip: four Systems per
@@ -2393,13 +2403,14 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     // a batch of one structure: the program of the grouped kernel's two-wavefronts-per-SIMD build (fx_grouped_c.hip), when
     // the structure qualifies
     GcHostProgram gc;
-    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free > 16u && p.max_free <= 32u &&
+    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free > 16u && p.max_free <= 48u &&
         build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
-                         d.u_nexprs, gc)) {
+                         d.u_nexprs, p.max_free, gc)) {
         FX_UP(gc_tab, gc.words.data(), gc.words.size())
         d.gc_words = (uint32_t)gc.words.size();
         d.gc_nslots = gc.nslots;
         d.gc_ng = gc.ng;
+        d.gc_nc = gc.nc;
     }
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy

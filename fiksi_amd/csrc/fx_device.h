@@ -67,8 +67,12 @@ constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
 // The program of the grouped kernel's one-structure build (fx_grouped_c.hip; written by fx_abi.cpp: build_gc_program): byte
-// offsets of its tables of fixed size; the right-hand-side list and, behind it, the product list follow at GC_T_PE
-constexpr uint32_t GC_T_VCOL = 80, GC_T_FIDX = 112, GC_T_RTAG = 144, GC_T_GBASE = 176, GC_T_GVAR = 240, GC_T_LT = 496, GC_T_PE = 1520;
+// offsets of its tables of fixed size; the right-hand-side list and, behind it, the product list follow at PE
+template <int NC> struct GcTable {  // NC columns per lane: Systems of at most NV = 16 NC variables and expressions
+    static constexpr uint32_t NV = 16u * NC;
+    static constexpr uint32_t VCOL = 80, FIDX = VCOL + NV, RTAG = FIDX + NV, GBASE = RTAG + NV, GVAR = GBASE + 2 * NV, LT = GVAR + 8 * NV,
+                              PE = LT + 16 * NC * NV;
+};
 
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
@@ -134,9 +138,10 @@ struct DeviceBatch {
     // FX_STEP_QR plans, built on first use (null until then)
     QrPlans qr_none, qr_units;
     // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_abi.cpp: build_gc_program): null unless the
-    // batch is uniform with one component of 17 ... 32 free variables among at most 32, and at most 32 expressions
+    // batch is uniform with one component of 17 ... 48 free variables
     uint32_t* gc_tab;
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
+    uint32_t gc_nc;                       // columns per lane of the build the program is for: 2 (17 ... 32 free variables) or 3 (33 ... 48)
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
     // only the pose instantiations of the solve kernel may run it
     uint32_t has_pose;

@@ -31,7 +31,10 @@ namespace fx {
 
 // A System's block, bytes: everything of fixed size first, at offsets the instructions carry as immediates (one base register per
 // row), then Jt J's slots and behind them the compact Jacobian rows
-constexpr uint32_t GC_XS = 0, GC_RHS = 256, GC_R = 512, GC_P = 768, GC_VOUT = 1024, GC_STASH = 1280, GC_A = 1296;
+// (NV = 16 NC: the most variables / expressions of a System in the build with NC columns per lane)
+template <int NV> struct GcBlock {
+    static constexpr uint32_t XS = 0, RHS = 8 * NV, R = 16 * NV, P = 24 * NV, VOUT = 32 * NV, STASH = 40 * NV, A = 40 * NV + 16;
+};
 struct GcLayout {
     uint32_t tab_bytes, off_g, stride;
 };
@@ -39,18 +42,20 @@ struct GcLayout {
 static GcLayout make_gc_layout(const DeviceBatch& b) {
     GcLayout L;
     L.tab_bytes = (b.gc_words * 4u + 15u) & ~15u;
-    L.off_g = GC_A + b.gc_nslots * 8u;  // (slots are an even number: 16-byte aligned)
+    L.off_g = 40u * 16u * b.gc_nc + 16u + b.gc_nslots * 8u;  // (slots are an even number: 16-byte aligned)
     L.stride = L.off_g + b.gc_ng * 8u;
     return L;
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_kernel(
-    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+template <int NC>
+__device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmParams& prm, const GcLayout& L, uint32_t* __restrict__ next_system,
+                                               unsigned char* smem) {
     using T = double;
-    constexpr int NC = 2, N = 32;
-    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int N = RS * NC;
+    using BK = GcBlock<N>;
+    using TK = GcTable<NC>;
     const int lane = threadIdx.x;
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
@@ -63,26 +68,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t nvt = rfl(TB[1]), net = rfl(TB[2]), nfree = rfl(TB[3]), n_pw = rfl(TB[4]), n_pe = rfl(TB[5]), nslots = rfl(TB[6]);
-    // (the tables of fixed size sit at fixed places: fx_device.h, GC_T_*)
-    const int8_t* vcol = reinterpret_cast<const int8_t*>(smem + GC_T_VCOL);         // [32] variable -> free column or -1
-    const uint8_t* fidx = smem + GC_T_FIDX;                                         // [32] free column -> variable
-    const uint8_t* rtag = smem + GC_T_RTAG;                                         // [32] kind of expression i
-    const uint16_t* gbaseT = reinterpret_cast<const uint16_t*>(smem + GC_T_GBASE);  // [32] first compact Jacobian entry of row i
-    const uint2* gvar = reinterpret_cast<const uint2*>(smem + GC_T_GVAR);           // [32] eight variable numbers, a byte each
-    const uint4* LT = reinterpret_cast<const uint4*>(smem + GC_T_LT + (uint32_t)hl * 64u);  // this lane's 64 slot numbers
-    const uint32_t* PE = reinterpret_cast<const uint32_t*>(smem + GC_T_PE);         // right-hand side: entry | row << 8 | column << 16
-    const uint32_t* PW = reinterpret_cast<const uint32_t*>(smem + GC_T_PE) + n_pe;  // products: entry a | entry b << 8 | slot << 16
+    // (the tables of fixed size sit at fixed places: fx_device.h, GcTable)
+    const int8_t* vcol = reinterpret_cast<const int8_t*>(smem + TK::VCOL);         // [N] variable -> free column or -1
+    const uint8_t* fidx = smem + TK::FIDX;                                         // [N] free column -> variable
+    const uint8_t* rtag = smem + TK::RTAG;                                         // [N] kind of expression i
+    const uint16_t* gbaseT = reinterpret_cast<const uint16_t*>(smem + TK::GBASE);  // [N] first compact Jacobian entry of row i
+    const uint2* gvar = reinterpret_cast<const uint2*>(smem + TK::GVAR);           // [N] eight variable numbers, a byte each
+    const uint4* LT = reinterpret_cast<const uint4*>(smem + TK::LT + (uint32_t)hl * (uint32_t)(NC * N));  // this lane's NC x N slot numbers
+    const uint32_t* PE = reinterpret_cast<const uint32_t*>(smem + TK::PE);         // right-hand side: entry | row << 8 | column << 16
+    const uint32_t* PW = reinterpret_cast<const uint32_t*>(smem + TK::PE) + n_pe;  // products: entry a | entry b << 8 | slot << 16
 
     unsigned char* const rows0 = smem + L.tab_bytes;
     unsigned char* base = rows0 + (uint32_t)myrow * L.stride;
-    T* XS = reinterpret_cast<T*>(base + GC_XS);          // [32] working variables: trial point on the free ones
-    T* At = reinterpret_cast<T*>(base + GC_A);           // Jt J by slots (+ lambda on the diagonal per trial)
-    T* rhsv = reinterpret_cast<T*>(base + GC_RHS);       // [32] -Jt r
-    T* G = reinterpret_cast<T*>(base + L.off_g);         // compact Jacobian rows of the last evaluated point
-    T* R = reinterpret_cast<T*>(base + GC_R);            // [32]
-    T* P = reinterpret_cast<T*>(base + GC_P);            // [32] scaled parameters
-    double* VOUT = reinterpret_cast<double*>(base + GC_VOUT);    // [32] unscaled values as written back
-    double* STASH = reinterpret_cast<double*>(base + GC_STASH);  // [2] the System's scale, the SSE of its start point
+    T* XS = reinterpret_cast<T*>(base + BK::XS);          // [N] working variables: trial point on the free ones
+    T* At = reinterpret_cast<T*>(base + BK::A);           // Jt J by slots (+ lambda on the diagonal per trial)
+    T* rhsv = reinterpret_cast<T*>(base + BK::RHS);       // [N] -Jt r
+    T* G = reinterpret_cast<T*>(base + L.off_g);          // compact Jacobian rows of the last evaluated point
+    T* R = reinterpret_cast<T*>(base + BK::R);            // [N]
+    T* P = reinterpret_cast<T*>(base + BK::P);            // [N] scaled parameters
+    double* VOUT = reinterpret_cast<double*>(base + BK::VOUT);    // [N] unscaled values as written back
+    double* STASH = reinterpret_cast<double*>(base + BK::STASH);  // [2] the System's scale, the SSE of its start point
 
     const fx_lm_opts o = prm.lm;
     auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & 0xFFFFu; };
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     for (int q = 0; q < NC; ++q) {
         const uint32_t j = (uint32_t)(hl + RS * q);
         my_vi[q] = j < nfree ? (uint32_t)fidx[j] : 0u;
-        dslot[q] = (uint32_t)reinterpret_cast<const uint8_t*>(LT)[(uint32_t)(32 * q) + j];
+        dslot[q] = (uint32_t)reinterpret_cast<const uint8_t*>(LT)[(uint32_t)(N * q) + j];
     }
 
     // per-row state (identical in every lane of the row unless noted)
@@ -124,11 +129,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 + e] = from[(gv.y >> (8 * e)) & 0xFFu];
     };
-    // residuals and Jacobian rows of the point in XS; the sum of squares as wave_sum adds it (rows 0..15, then 16..31)
+    // sum over a vector laid out 16 entries per accumulator, as wave_sum adds its blocks: (b0 + b1) + (b2 + b3) with the blocks
+    // past the end left out (+ 0.0 of a sum of squares: exact)
+    auto chunk_sum = [&](const T (&part)[NC]) -> T {
+        T s01 = row_sum(part[0]) + row_sum(part[1]);
+        if constexpr (NC >= 3) s01 = s01 + row_sum(part[2]);
+        return s01;
+    };
+    // residuals and Jacobian rows of the point in XS
     auto eval_rows = [&]() -> T {
-        T part[2] = {T(0), T(0)};
+        T part[NC];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NC; ++k) part[k] = T(0);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
             const uint32_t row = (uint32_t)(hl + RS * k);
             if (row < net) {
                 T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         group_sync();
-        return row_sum(part[0]) + row_sum(part[1]);
+        return chunk_sum(part);
     };
     // K3: Jt J into its slots and -Jt r from the program's lists (ds_add_f64; entry t is lane t % 16's, 16 consecutive entries
     // per instruction, in list order — fx_grouped.hip's order)
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     group_sync();
                     T a[NC][N];
 #pragma unroll
-                    for (int cch = 0; cch < 4; ++cch) {
+                    for (int cch = 0; cch < NC * N / 16; ++cch) {
                         const uint4 w4 = LT[cch];
                         const uint32_t ws[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
@@ -416,7 +430,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     }
                 }
                 if (go) {
-                    const T dn2 = row_sum(delta[0] * delta[0]) + row_sum(delta[1] * delta[1]);
+                    T dsq[NC];
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) dsq[q] = delta[q] * delta[q];
+                    const T dn2 = chunk_sum(dsq);
                     if (!(dn2 == dn2)) {
                         code = LC_NAN;
                         go = false;
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     double2* gd = reinterpret_cast<double2*>(G);
                     const uint32_t ng2 = (L.stride - L.off_g) / 16u;
                     for (uint32_t i = hl; i < ng2; i += RS) gd[i] = gs[i];
-                    const T* rs = reinterpret_cast<const T*>(wb + GC_R);
+                    const T* rs = reinterpret_cast<const T*>(wb + BK::R);
 #pragma unroll
                     for (int q = 0; q < NC; ++q) R[hl + RS * q] = rs[hl + RS * q];
                     group_sync();
@@ -588,10 +605,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
             group_sync();
-            double part[2] = {0.0, 0.0};
+            double part[NC];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < NC; ++k) {
                 const uint32_t i = (uint32_t)(hl + RS * k);
+                part[k] = 0.0;
                 if (i < net) {
                     double v[8], g[8];
                     row_vars(i, VOUT, v);
@@ -599,7 +617,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     part[k] = r * r;
                 }
             }
-            const double sse_u = row_sum(part[0]) + row_sum(part[1]);
+            const double sse_u = chunk_sum(part);
             if (hl == 0) {
                 fx_result res;
                 res.accepted = accepted;
@@ -620,6 +638,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// 17 ... 32 free variables: two columns per lane, 256 registers, two wavefronts per SIMD
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<2>(b, prm, L, next_system, smem);
+}
+// 33 ... 48 free variables (the reference's own bench sketch, fiksi_bench.rs:15-40: 46): three columns per lane are 288
+// registers of matrix alone — one wavefront per SIMD, but on every SIMD (the general build's 16 KB of LDS per System leave two
+// wavefronts per CU)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_c3_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<3>(b, prm, L, next_system, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------
@@ -634,9 +667,9 @@ bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
     if (!p.grouped_one_structure) return false;  // (a context created under FIKSI_AMD_GROUPED_C=0: A / B measurements, tests)
     if (!b.gc_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
     if (p.prof || p.lm.precision == 32 || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
-    // six wavefronts per CU or more (a SIMD with two is what the build is for)
+    // two columns per lane: six wavefronts per CU or more (a SIMD with two is what the build is for); three: one per SIMD
     const size_t lds = grouped_c_lds_bytes(b);
-    return lds != 0 && lds <= (160u * 1024u) / 6u;
+    return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 2u ? 6u : 4u);
 }
 
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
@@ -646,8 +679,9 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
     if (trace)
         fprintf(stderr, "[fiksi_amd] grouped kernel, one-structure build: %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of Jt J, %u Jacobian entries)\n",
                 per_wave, L.tab_bytes, L.stride, b.gc_nslots, b.gc_ng);
-    static unsigned int raised = 0;
-    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised);
+    static unsigned int raised = 0, raised3 = 0;
+    hipError_t e = b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
+                                 : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -659,12 +693,14 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t by_lds = (160u * 1024u) / per_wave;
-        uint32_t resident = (uint32_t)cus * (by_lds < 8u ? by_lds : 8u);
+        const uint32_t by_simd = b.gc_nc == 2u ? 8u : 4u;
+        uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
         if (resident > waves) resident = waves;
         if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
         if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
     }
-    hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    if (b.gc_nc == 2u) hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    else hipLaunchKernelGGL(lm_solve_grouped_c3_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 """The grouped kernel's build for batches of ONE structure (fx_grouped_c.hip: the structure's lists shared by the four Systems
-of a wavefront, Jt J stored by its pattern, two wavefronts per SIMD) against the general build (fx_grouped.hip) it replaces
+of a wavefront, Jt J stored by its pattern; two wavefronts per SIMD for 17 ... 32 free variables, one on every SIMD for 33 ... 48) against the general build (fx_grouped.hip) it replaces
 for such batches: the same operations on the same operands in the same order, so every bit of every result must agree.
 (The oracle comparisons of test_gpu_grouped.py / test_gpu_parity.py run through this build too: their ring16 batches are of
 one structure.)"""
@@ -44,7 +44,8 @@ def _cases():
             ("ring16_trial_cap", workloads.ring16(2000), {"max_trials": 21}),
             ("ring16_no_perturbation", workloads.ring16(2000), {"perturb": False}),
             ("hinged_4", workloads.hinged_triangles(2000, 4), {}), ("hinged_5", workloads.hinged_triangles(1500, 5), {}),
-            ("hinged_7", workloads.hinged_triangles(1203, 7), {}),
+            ("hinged_7", workloads.hinged_triangles(1203, 7), {}), ("hinged_8", workloads.hinged_triangles(1000, 8), {}),
+            ("hinged_11", workloads.hinged_triangles(1501, 11), {}),
             ("every_kind", _mixed_uniform(1500, False), {}), ("every_kind_some_fixed", _mixed_uniform(1500, True), {})]
 
 
@@ -63,10 +64,10 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
         assert dg.grouped_build(abi.solving_opts(**kw)) == 0
         dg.free()
     for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "hinged_4",
-                 "hinged_5", "hinged_7"):
+                 "hinged_5", "hinged_7", "hinged_8", "hinged_11"):
         assert taken[name] == 1, taken
-    # not of one structure / 16 free variables or fewer / more than 32 variables: the general build
-    for b in (workloads.ring16_two_structures(2000), workloads.hinged_triangles(2000, 3), workloads.hinged_triangles(500, 8)):
+    # not of one structure / 16 free variables or fewer: the general build
+    for b in (workloads.ring16_two_structures(2000), workloads.hinged_triangles(2000, 3)):
         db = ctx.upload(b)
         assert db.grouped_build() == 0
         db.free()

@@ -17,7 +17,8 @@ def one(n, reps):
     ctx = fiksi_amd.Context(0)
     out = {}
     for name, b in (("ring16", workloads.ring16(n)), ("ring16_fixed_gauge", workloads.ring16(n // 4, fix_gauge=True)),
-                    ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True))):
+                    ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("hinged_11", workloads.hinged_triangles(n, 11)),
+                    ("hinged_5", workloads.hinged_triangles(n, 5))):
         db = ctx.upload(b)
         db.system_solve()
         ctx.synchronize()
