@@ -1303,7 +1303,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
     for (int32_t& sl : slot_of)
         if (sl == 0) sl = (int32_t)nslots++;
     const uint32_t zero = nslots++;
-    nslots = (nslots + 1u) & ~1u;
+    nslots = (nslots + 3u) & ~3u;  // (whole 16-byte vectors in f32 too)
     if (nslots > 256u) return false;
     std::vector<uint32_t> pw, pe;
     for (uint32_t r = 0; r < net; ++r)
@@ -1355,11 +1355,11 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
     w[4] = (uint32_t)pw.size();
     w[5] = (uint32_t)pe.size();
     w[6] = nslots;
-    w[7] = (ng + 1u) & ~1u;
+    w[7] = (ng + 3u) & ~3u;
     w[8] = zero;
     w[17] = (uint32_t)w.size();
     out.nslots = nslots;
-    out.ng = (ng + 1u) & ~1u;
+    out.ng = (ng + 3u) & ~3u;
     return true;
 }
 static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
@@ -1514,7 +1514,7 @@ bool build_qrg_program(const uint8_t* expr_tag, const uint16_t* expr_idx16, cons
             ng += (uint32_t)fx::tag_nvars<true>((int)(expr_tag[rows[r]] & 0x7F));
         }
         w[15] = put16(gbase);
-        out.ng = (ng + 1u) & ~1u;
+        out.ng = (ng + 3u) & ~3u;
     }
     w.resize((w.size() + 3u) & ~size_t(3), 0);
     w[14] = (uint32_t)w.size();  // the small tables end here (the kernel keeps them in LDS); the per-entry words stay in global memory

@@ -198,7 +198,7 @@ size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool singl
 // ... its build for batches of one structure, two wavefronts per SIMD (fx_grouped_c.hip)
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
-size_t grouped_c_lds_bytes(const DeviceBatch& b);
+size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t element_size);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // dst[0 .. bytes) = src[0 .. bytes), 16 bytes per thread (both 16-byte aligned, bytes a multiple of 16): pulls a one-shot

@@ -31,30 +31,30 @@ namespace fx {
 
 // A System's block, bytes: everything of fixed size first, at offsets the instructions carry as immediates (one base register per
 // row), then Jt J's slots and behind them the compact Jacobian rows
-// (NV = 16 NC: the most variables / expressions of a System in the build with NC columns per lane)
-template <int NV> struct GcBlock {
-    static constexpr uint32_t XS = 0, RHS = 8 * NV, R = 16 * NV, P = 24 * NV, VOUT = 32 * NV, STASH = 40 * NV, A = 40 * NV + 16;
+// (NV = 16 NC: the most variables / expressions of a System in the build with NC columns per lane; ES: bytes of the compute type)
+template <int NV, int ES> struct GcBlock {
+    static constexpr uint32_t XS = 0, RHS = ES * NV, R = 2 * ES * NV, P = 3 * ES * NV, VOUT = 4 * ES * NV, STASH = VOUT + 8 * NV, A = STASH + 16;
 };
 struct GcLayout {
     uint32_t tab_bytes, off_g, stride;
 };
 
-static GcLayout make_gc_layout(const DeviceBatch& b) {
+static GcLayout make_gc_layout(const DeviceBatch& b, uint32_t es) {
     GcLayout L;
     L.tab_bytes = (b.gc_words * 4u + 15u) & ~15u;
-    L.off_g = 40u * 16u * b.gc_nc + 16u + b.gc_nslots * 8u;  // (slots are an even number: 16-byte aligned)
-    L.stride = L.off_g + b.gc_ng * 8u;
+    L.off_g = (4u * es + 8u) * 16u * b.gc_nc + 16u + b.gc_nslots * es;  // (slots are a multiple of four: 16-byte aligned)
+    L.stride = L.off_g + b.gc_ng * es;
     return L;
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <int NC>
+template <int NC, typename T>
 __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmParams& prm, const GcLayout& L, uint32_t* __restrict__ next_system,
                                                unsigned char* smem) {
-    using T = double;
     constexpr int N = RS * NC;
-    using BK = GcBlock<N>;
+    using BK = GcBlock<N, (int)sizeof(T)>;
+    using V16 = typename Vec16<T>::type;
     using TK = GcTable<NC>;
     const int lane = threadIdx.x;
     const int hl = lane & (RS - 1);
@@ -165,9 +165,9 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     // per instruction, in list order — fx_grouped.hip's order)
     auto form_normal = [&]() {
         {
-            double2 z;
-            z.x = z.y = 0.0;
-            for (uint32_t i = hl; i < nslots / 2u; i += RS) reinterpret_cast<double2*>(At)[i] = z;
+            V16 z;
+            for (int q = 0; q < Vec16<T>::n; ++q) reinterpret_cast<T*>(&z)[q] = T(0);
+            for (uint32_t i = hl; i < nslots / (uint32_t)Vec16<T>::n; i += RS) reinterpret_cast<V16*>(At)[i] = z;
         }
 #pragma unroll
         for (int q = 0; q < NC; ++q) rhsv[hl + RS * q] = T(0);
@@ -287,14 +287,14 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                             const double f2 = (1.0 / 4294967295.0) * (double)st;
                             x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
                         }
-                        XS[i] = x;
+                        XS[i] = (T)x;  // (perturbed from the f64 input: the f64 start point is bit-identical to the reference)
                         VOUT[i] = c_var[k];
                         b.vars[v0 + i] = c_var[k];  // fixed variables stay bit-identical
                     }
                     if (i < net) {
                         double prm_e = c_param[k];
                         if ((prm.mode & 1u) && (tagk[k] == FX_TAG_PPD || tagk[k] == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
-                        P[i] = prm_e;
+                        P[i] = (T)prm_e;
                     }
                 }
                 if (hl == 0) STASH[0] = scale;
@@ -364,8 +364,8 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     if (joining) {
                         lad_lead = (int)nl;
                         lad_rank = (int)((newrank >> (4 * myrow)) & 15u);
-                        const double2* lb = reinterpret_cast<const double2*>(rows0 + (uint32_t)nl * L.stride);
-                        double2* mine = reinterpret_cast<double2*>(base);
+                        const uint4* lb = reinterpret_cast<const uint4*>(rows0 + (uint32_t)nl * L.stride);
+                        uint4* mine = reinterpret_cast<uint4*>(base);
                         for (uint32_t i = hl; i < L.stride / 16u; i += RS) mine[i] = lb[i];
                         fresh = false;
                         phase = GP_RUN;
@@ -395,7 +395,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     // K4: factor (Jt J + lambda I) and solve for delta; columns hl and hl + 16 of the symmetric matrix through
                     // the lane's table of slots
 #pragma unroll
-                    for (int q = 0; q < NC; ++q) At[dslot[q]] = diag[q] + lam_k;
+                    for (int q = 0; q < NC; ++q) At[dslot[q]] = diag[q] + (T)lam_k;
                     group_sync();
                     T a[NC][N];
 #pragma unroll
@@ -460,6 +460,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                         if (lad_rank > 0)
                             for (int k = 0; k < lad_rank; ++k) lam_k *= o.reject_factor;
                         if (!(sse_t == sse_t) && !(lam_k < 1.0e300)) code = LC_REJ_NAN;  // the reference would double lambda forever
+                        else if (sizeof(T) == 4 && sse_t - sse <= (T)o.ftol * sse) code = LC_REJ_FTOL;  // f32: stagnated at round-off (fx_grouped.hip)
                     }
                 }
             }
@@ -494,7 +495,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
             bool assemble = false, fin = false;
             if (fresh) {  // the start point
                 sse = sse_t;
-                if (hl == 0) STASH[1] = sse_t;
+                if (hl == 0) STASH[1] = (double)sse_t;
                 assemble = true;
             } else {
                 if (kw > 0) {  // the plain rejects in front (lm.rs:189)
@@ -534,7 +535,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                         }
                     } else {  // a reject that ends the solve
                         lambda *= o.reject_factor;
-                        exit_code = FX_EXIT_NAN;
+                        exit_code = (code_w == LC_REJ_NAN) ? FX_EXIT_NAN : FX_EXIT_FTOL;
                         fin = true;
                     }
                 }
@@ -542,8 +543,8 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
             if (assemble) {
                 if (win_row != myrow) {  // the accepted point's Jacobian rows and residuals are another row's
                     const unsigned char* wb = rows0 + (uint32_t)win_row * L.stride;
-                    const double2* gs = reinterpret_cast<const double2*>(wb + L.off_g);
-                    double2* gd = reinterpret_cast<double2*>(G);
+                    const uint4* gs = reinterpret_cast<const uint4*>(wb + L.off_g);
+                    uint4* gd = reinterpret_cast<uint4*>(G);
                     const uint32_t ng2 = (L.stride - L.off_g) / 16u;
                     for (uint32_t i = hl; i < ng2; i += RS) gd[i] = gs[i];
                     const T* rs = reinterpret_cast<const T*>(wb + BK::R);
@@ -599,7 +600,8 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 if ((uint32_t)(hl + RS * q) < nfree) {
-                    const double xo = (prm.mode & 1u) ? scale * xc[q] : xc[q];
+                    const double x = (double)xc[q];
+                    const double xo = (prm.mode & 1u) ? scale * x : x;
                     b.vars[v0 + my_vi[q]] = xo;
                     VOUT[my_vi[q]] = xo;
                 }
@@ -612,12 +614,17 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                 part[k] = 0.0;
                 if (i < net) {
                     double v[8], g[8];
-                    row_vars(i, VOUT, v);
+                    const uint2 gv = gvar[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = VOUT[(gv.x >> (8 * e)) & 0xFFu];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 + e] = VOUT[(gv.y >> (8 * e)) & 0xFFu];
                     const double r = eval_expression<double, false, false>((int)rtag[i], v, c_param[k], g);
                     part[k] = r * r;
                 }
             }
-            const double sse_u = chunk_sum(part);
+            double sse_u = row_sum(part[0]) + row_sum(part[1]);
+            if constexpr (NC >= 3) sse_u = sse_u + row_sum(part[2]);
             if (hl == 0) {
                 fx_result res;
                 res.accepted = accepted;
@@ -642,7 +649,14 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<2>(b, prm, L, next_system, smem);
+    grouped_c_body<2, double>(b, prm, L, next_system, smem);
+}
+// ... in f32 (fx_lm_opts_default_f32): 178 registers (three wavefronts per SIMD — 168 registers, 24 bytes of scratch — measured
+// the same: 2.79 against 2.77 ms on 125 000 inconsistent ring16 sketches)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_f32_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<2, float>(b, prm, L, next_system, smem);
 }
 // 33 ... 48 free variables (the reference's own bench sketch, fiksi_bench.rs:15-40: 46): three columns per lane are 288
 // registers of matrix alone — one wavefront per SIMD, but on every SIMD (the general build's 16 KB of LDS per System leave two
@@ -650,38 +664,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_c3_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<3>(b, prm, L, next_system, smem);
+    grouped_c_body<3, double>(b, prm, L, next_system, smem);
 }
 
 // ------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------
 // LDS bytes per wavefront, 0 when the batch has no program
-size_t grouped_c_lds_bytes(const DeviceBatch& b) {
+size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t es) {
     if (!b.gc_tab || !b.gc_words) return 0;
-    const GcLayout L = make_gc_layout(b);
+    const GcLayout L = make_gc_layout(b, es);
     return (size_t)L.tab_bytes + 4u * (size_t)L.stride;
 }
 
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
     if (!p.grouped_one_structure) return false;  // (a context created under FIKSI_AMD_GROUPED_C=0: A / B measurements, tests)
     if (!b.gc_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
-    if (p.prof || p.lm.precision == 32 || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
+    if (p.prof || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
+    const bool f32 = p.lm.precision == 32;
+    if (f32 && b.gc_nc != 2u) return false;
     // two columns per lane: six wavefronts per CU or more (a SIMD with two is what the build is for); three: one per SIMD
-    const size_t lds = grouped_c_lds_bytes(b);
+    const size_t lds = grouped_c_lds_bytes(b, f32 ? 4u : 8u);
     return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 2u ? 6u : 4u);
 }
 
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
-    const GcLayout L = make_gc_layout(b);
+    const bool f32 = p.lm.precision == 32;
+    const GcLayout L = make_gc_layout(b, f32 ? 4u : 8u);
     const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
     static const bool trace = getenv("FIKSI_AMD_TRACE") != nullptr;
     if (trace)
         fprintf(stderr, "[fiksi_amd] grouped kernel, one-structure build: %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of Jt J, %u Jacobian entries)\n",
                 per_wave, L.tab_bytes, L.stride, b.gc_nslots, b.gc_ng);
-    static unsigned int raised = 0, raised3 = 0;
-    hipError_t e = b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
-                                 : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
+    static unsigned int raised = 0, raised3 = 0, raised_f = 0;
+    hipError_t e = f32           ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_f32_kernel), &raised_f)
+                   : b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
+                                   : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -699,7 +717,8 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
         if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
         if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
     }
-    if (b.gc_nc == 2u) hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    if (f32) hipLaunchKernelGGL(lm_solve_grouped_c_f32_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    else if (b.gc_nc == 2u) hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     else hipLaunchKernelGGL(lm_solve_grouped_c3_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     return hipGetLastError();
 }

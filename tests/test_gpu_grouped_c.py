@@ -43,6 +43,8 @@ def _cases():
             ("ring16_inconsistent", workloads.ring16(3000, inconsistent=True), {}),
             ("ring16_trial_cap", workloads.ring16(2000), {"max_trials": 21}),
             ("ring16_no_perturbation", workloads.ring16(2000), {"perturb": False}),
+            ("ring16_f32", workloads.ring16(4099), {"f32": True}), ("ring16_inconsistent_f32", workloads.ring16(5000, inconsistent=True), {"f32": True}),
+            ("hinged_5_f32", workloads.hinged_triangles(1500, 5), {"f32": True}),
             ("hinged_4", workloads.hinged_triangles(2000, 4), {}), ("hinged_5", workloads.hinged_triangles(1500, 5), {}),
             ("hinged_7", workloads.hinged_triangles(1203, 7), {}), ("hinged_8", workloads.hinged_triangles(1000, 8), {}),
             ("hinged_11", workloads.hinged_triangles(1501, 11), {}),
@@ -57,14 +59,14 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
         db = ctx.upload(b)
         taken[name] = db.grouped_build(abi.solving_opts(**kw))
         # the other builds of the same batch are never this one
-        assert db.grouped_build(abi.solving_opts(f32=True)) != 1 and db.grouped_build(abi.solving_opts(decomposer=1)) != 1
+        assert db.grouped_build(abi.solving_opts(decomposer=1)) != 1 and db.grouped_build(abi.solving_opts(optimizer=1)) != 1
         assert db.grouped_build(abi.solving_opts(solver=1)) != 1 and db.grouped_build(abi.solving_opts(solver=2)) != 1
         db.free()
         dg = ctx_general.upload(b)
         assert dg.grouped_build(abi.solving_opts(**kw)) == 0
         dg.free()
-    for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "hinged_4",
-                 "hinged_5", "hinged_7", "hinged_8", "hinged_11"):
+    for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "ring16_f32",
+                 "ring16_inconsistent_f32", "hinged_5_f32", "hinged_4", "hinged_5", "hinged_7", "hinged_8", "hinged_11"):
         assert taken[name] == 1, taken
     # not of one structure / 16 free variables or fewer: the general build
     for b in (workloads.ring16_two_structures(2000), workloads.hinged_triangles(2000, 3)):

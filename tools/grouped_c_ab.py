@@ -13,18 +13,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def one(n, reps):
     import numpy as np
     import fiksi_amd
-    from fiksi_amd import workloads
+    from fiksi_amd import abi, workloads
     ctx = fiksi_amd.Context(0)
     out = {}
     for name, b in (("ring16", workloads.ring16(n)), ("ring16_fixed_gauge", workloads.ring16(n // 4, fix_gauge=True)),
                     ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("hinged_11", workloads.hinged_triangles(n, 11)),
-                    ("hinged_5", workloads.hinged_triangles(n, 5))):
+                    ("hinged_5", workloads.hinged_triangles(n, 5)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True))):
         db = ctx.upload(b)
-        db.system_solve()
+        o = abi.solving_opts(f32=name.endswith("_f32"))
+        db.system_solve(o)
         ctx.synchronize()
         ctx.timer_begin()
         for _ in range(reps):
-            db.system_solve()
+            db.system_solve(o)
         ms = ctx.timer_end() / reps
         res = db.get_results()
         h = hashlib.sha256()
