@@ -222,7 +222,10 @@ void fx_ctx_destroy(fx_ctx* ctx);
  * which has no slowest one, loses up to a third — 500 four-triangle sketches 0.041 -> 0.058 ms — and may pin 0. Up to round 3
  * the threshold was 1024.) Results do not
  * depend on it beyond the last bits of sums of LDS float atomics on sketches where several rows add into one entry.
- * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment. */
+ * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment.
+ * A batch whose Systems all have ONE structure (one component of 17 ... 48 free variables) runs the grouped kernel's build for
+ * such batches (fx_grouped_c.hip: two wavefronts per SIMD; 100 000 ring16 sketches 2.81 -> 1.76 ms, same bits) — nothing to set;
+ * fx_debug_grouped_build tells, FIKSI_AMD_GROUPED_C=0 in the environment of fx_ctx_create keeps the general build. */
 int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);
 /* Batches the grouped kernel takes, of min_systems Systems or more (default 8192; 0 keeps the current value): a scout
  * pass (residuals at the start values) and a ranking of strided chunks hand the Systems out most-work-first, because a batch is as slow

@@ -30,6 +30,7 @@ stats hinged64_kernel_stats python3 tools/hinged_batch.py 64 256 5
 stats hinged16_kernel_stats python3 tools/hinged_batch.py 16 20000 3
 stats qr_kernel_stats python3 tools/qr_once.py 100000 3
 stats shard12500_kernel_stats python3 tools/solve_only.py 12500 10
+stats hinged11_kernel_stats python3 tools/hinged_batch.py 11 100000 3
 echo "[collect] HBM counters, 100k and 500k Systems"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/k1_once.py 100000 3 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/k1_once.py 100000 3 > $OUT/pmc_write.log 2>&1
@@ -59,6 +60,7 @@ python3 tools/ra_batch.py 10000 7 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_recu
 python3 tools/straggler_probe.py 12500 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_straggler_probe.json
 python3 tools/shard_times.py 100000 off:0 default 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_cfg4_shard_times.json
 python3 tools/ladder_probe.py 100000 full 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_ladder_probe.json
+python3 tools/grouped_c_ab.py 100000 10 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_grouped_builds_ab.json
 tools/probes/rw_mix_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_hbm_rw_mix.json
 tools/probes/valu_cost_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_valu_cost.json
 echo "[collect] plain bench line (it quotes the counter files: this run's go to profiles/ first)"
