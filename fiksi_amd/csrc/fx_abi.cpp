@@ -1269,7 +1269,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
             fidx[nfree++] = (uint8_t)i;
         }
     }
-    if (nfree <= NV - 16u || nfree > NV) return false;
+    if (nfree == 0 || nfree <= NV - 16u || nfree > NV) return false;
     int gcol[NV][8];
     uint32_t ng = 0;
     for (uint32_t r = 0; r < net; ++r) {
@@ -1365,6 +1365,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
 static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
                              uint32_t nvt, uint32_t net, uint32_t max_free, GcHostProgram& out) {
     if (max_free > 32u) return build_gc_program_t<3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
+    if (max_free <= 16u) return build_gc_program_t<1>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
     return build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
 }
 
@@ -2403,7 +2404,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     // a batch of one structure: the program of the grouped kernel's two-wavefronts-per-SIMD build (fx_grouped_c.hip), when
     // the structure qualifies
     GcHostProgram gc;
-    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free > 16u && p.max_free <= 48u &&
+    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u &&
         build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
                          d.u_nexprs, p.max_free, gc)) {
         FX_UP(gc_tab, gc.words.data(), gc.words.size())

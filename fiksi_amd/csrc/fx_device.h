@@ -138,10 +138,10 @@ struct DeviceBatch {
     // FX_STEP_QR plans, built on first use (null until then)
     QrPlans qr_none, qr_units;
     // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_abi.cpp: build_gc_program): null unless the
-    // batch is uniform with one component of 17 ... 48 free variables
+    // batch is uniform with one component of at most 48 free variables
     uint32_t* gc_tab;
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
-    uint32_t gc_nc;                       // columns per lane of the build the program is for: 2 (17 ... 32 free variables) or 3 (33 ... 48)
+    uint32_t gc_nc;                       // columns per lane of the build the program is for: 1 (up to 16 free variables), 2 (17 ... 32) or 3 (33 ... 48)
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
     // only the pose instantiations of the solve kernel may run it
     uint32_t has_pose;

@@ -13,8 +13,8 @@
 //     program — the product lists name slots, and a lane's 64 matrix elements are loaded through a table of slot numbers
 //     (64 bytes per lane; what is not in the pattern reads the zero slot). The factor's fill exists in registers only;
 //   * Jacobian rows compact (an expression's own entries instead of eight).
-// ring16: 3.5 KB per System, 18.2 KB per wavefront, eight wavefronts per CU; f32 (cfg5) and the 48-column shape are instantiations
-// of the same body.
+// ring16: 3.5 KB per System, 18.2 KB per wavefront, eight wavefronts per CU; f32 (cfg5), the 48-column shape (one wavefront on
+// every SIMD) and the 16-column shape (four per SIMD) are instantiations of the same body.
 // The per-row state machine, the device-side queue, the lambda ladder, the hold passes are fx_grouped.hip's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -132,8 +132,9 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     };
     // sum over a vector laid out 16 entries per accumulator, as wave_sum adds its blocks: (b0 + b1) + (b2 + b3) with the blocks
     // past the end left out (+ 0.0 of a sum of squares: exact)
-    auto chunk_sum = [&](const T (&part)[NC]) -> T {
-        T s01 = row_sum(part[0]) + row_sum(part[1]);
+    auto chunk_sum = [&](const auto (&part)[NC]) {
+        auto s01 = row_sum(part[0]);
+        if constexpr (NC >= 2) s01 = s01 + row_sum(part[1]);
         if constexpr (NC >= 3) s01 = s01 + row_sum(part[2]);
         return s01;
     };
@@ -624,8 +625,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     part[k] = r * r;
                 }
             }
-            double sse_u = row_sum(part[0]) + row_sum(part[1]);
-            if constexpr (NC >= 3) sse_u = sse_u + row_sum(part[2]);
+            const double sse_u = chunk_sum(part);
             if (hl == 0) {
                 fx_result res;
                 res.accepted = accepted;
@@ -646,6 +646,13 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     }
 }
 
+// 16 free variables and fewer (the reference's bench sketches of one to three triangles): one column per lane, four wavefronts
+// per SIMD
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lm_solve_grouped_c1_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<1, double>(b, prm, L, next_system, smem);
+}
 // 17 ... 32 free variables: two columns per lane, 256 registers, two wavefronts per SIMD
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
@@ -683,10 +690,10 @@ bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
     if (!b.gc_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
     if (p.prof || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
     const bool f32 = p.lm.precision == 32;
-    if (f32 && b.gc_nc != 2u) return false;
+    if (f32 && b.gc_nc != 2u) return false;  // (f32: the 32-column instantiation only)
     // two columns per lane: six wavefronts per CU or more (a SIMD with two is what the build is for); three: one per SIMD
     const size_t lds = grouped_c_lds_bytes(b, f32 ? 4u : 8u);
-    return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 2u ? 6u : 4u);
+    return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 1u ? 16u : b.gc_nc == 2u ? 6u : 4u);
 }
 
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
@@ -697,8 +704,9 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
     if (trace)
         fprintf(stderr, "[fiksi_amd] grouped kernel, one-structure build: %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of Jt J, %u Jacobian entries)\n",
                 per_wave, L.tab_bytes, L.stride, b.gc_nslots, b.gc_ng);
-    static unsigned int raised = 0, raised3 = 0, raised_f = 0;
+    static unsigned int raised = 0, raised3 = 0, raised_f = 0, raised1 = 0;
     hipError_t e = f32           ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_f32_kernel), &raised_f)
+                   : b.gc_nc == 1u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c1_kernel), &raised1)
                    : b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
                                    : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
     if (e != hipSuccess) return e;
@@ -712,13 +720,14 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t by_lds = (160u * 1024u) / per_wave;
-        const uint32_t by_simd = b.gc_nc == 2u ? 8u : 4u;
+        const uint32_t by_simd = b.gc_nc == 1u ? 16u : b.gc_nc == 2u ? 8u : 4u;
         uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
         if (resident > waves) resident = waves;
         if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
         if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
     }
     if (f32) hipLaunchKernelGGL(lm_solve_grouped_c_f32_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    else if (b.gc_nc == 1u) hipLaunchKernelGGL(lm_solve_grouped_c1_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     else if (b.gc_nc == 2u) hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     else hipLaunchKernelGGL(lm_solve_grouped_c3_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     return hipGetLastError();

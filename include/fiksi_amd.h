@@ -223,8 +223,8 @@ void fx_ctx_destroy(fx_ctx* ctx);
  * the threshold was 1024.) Results do not
  * depend on it beyond the last bits of sums of LDS float atomics on sketches where several rows add into one entry.
  * A new context starts from FIKSI_AMD_GROUPED=0|1 if that is set in the environment.
- * A batch whose Systems all have ONE structure (one component of 17 ... 48 free variables) runs the grouped kernel's build for
- * such batches (fx_grouped_c.hip: two wavefronts per SIMD; 100 000 ring16 sketches 2.81 -> 1.76 ms, same bits) — nothing to set;
+ * A batch whose Systems all have ONE structure (one component of at most 48 free variables) runs the grouped kernel's build for
+ * such batches (fx_grouped_c.hip: four / two wavefronts per SIMD up to 16 / 32 free variables; 100 000 ring16 sketches 2.81 -> 1.76 ms, same bits) — nothing to set;
  * fx_debug_grouped_build tells, FIKSI_AMD_GROUPED_C=0 in the environment of fx_ctx_create keeps the general build. */
 int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems);
 /* Batches the grouped kernel takes, of min_systems Systems or more (default 8192; 0 keeps the current value): a scout
@@ -327,7 +327,7 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
 /* Diagnostic only: which BUILD of the grouped kernel such a launch would be: -1 = not the grouped kernel, 0 = the general build
  * (one wavefront per SIMD for components of 17 ... 32 free variables), 1 = the build for batches of one structure
  * (fx_grouped_c.hip: the structure's lists shared by a wavefront's four Systems, Jt J by its pattern, two wavefronts per
- * SIMD; same bits). A context created under FIKSI_AMD_GROUPED_C=0 never takes build 1. Launches nothing. */
+ * SIMD for that shape; same bits). A context created under FIKSI_AMD_GROUPED_C=0 never takes build 1. Launches nothing. */
 int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */

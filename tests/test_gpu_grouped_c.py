@@ -1,5 +1,5 @@
 """The grouped kernel's build for batches of ONE structure (fx_grouped_c.hip: the structure's lists shared by the four Systems
-of a wavefront, Jt J stored by its pattern; two wavefronts per SIMD for 17 ... 32 free variables, one on every SIMD for 33 ... 48) against the general build (fx_grouped.hip) it replaces
+of a wavefront, Jt J stored by its pattern; four wavefronts per SIMD up to 16 free variables, two for 17 ... 32, one on every SIMD for 33 ... 48) against the general build (fx_grouped.hip) it replaces
 for such batches: the same operations on the same operands in the same order, so every bit of every result must agree.
 (The oracle comparisons of test_gpu_grouped.py / test_gpu_parity.py run through this build too: their ring16 batches are of
 one structure.)"""
@@ -45,6 +45,7 @@ def _cases():
             ("ring16_no_perturbation", workloads.ring16(2000), {"perturb": False}),
             ("ring16_f32", workloads.ring16(4099), {"f32": True}), ("ring16_inconsistent_f32", workloads.ring16(5000, inconsistent=True), {"f32": True}),
             ("hinged_5_f32", workloads.hinged_triangles(1500, 5), {"f32": True}),
+            ("hinged_1", workloads.hinged_triangles(3001, 1), {}), ("hinged_3", workloads.hinged_triangles(2000, 3), {}),
             ("hinged_4", workloads.hinged_triangles(2000, 4), {}), ("hinged_5", workloads.hinged_triangles(1500, 5), {}),
             ("hinged_7", workloads.hinged_triangles(1203, 7), {}), ("hinged_8", workloads.hinged_triangles(1000, 8), {}),
             ("hinged_11", workloads.hinged_triangles(1501, 11), {}),
@@ -66,13 +67,15 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
         assert dg.grouped_build(abi.solving_opts(**kw)) == 0
         dg.free()
     for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "ring16_f32",
-                 "ring16_inconsistent_f32", "hinged_5_f32", "hinged_4", "hinged_5", "hinged_7", "hinged_8", "hinged_11"):
+                 "ring16_inconsistent_f32", "hinged_5_f32", "hinged_1", "hinged_3", "hinged_4", "hinged_5", "hinged_7", "hinged_8", "hinged_11"):
         assert taken[name] == 1, taken
-    # not of one structure / 16 free variables or fewer: the general build
-    for b in (workloads.ring16_two_structures(2000), workloads.hinged_triangles(2000, 3)):
-        db = ctx.upload(b)
-        assert db.grouped_build() == 0
-        db.free()
+    # not of one structure: the general build; f32 has the 32-column instantiation only
+    db = ctx.upload(workloads.ring16_two_structures(2000))
+    assert db.grouped_build() == 0
+    db.free()
+    db = ctx.upload(workloads.hinged_triangles(2000, 3))
+    assert db.grouped_build(abi.solving_opts(f32=True)) == 0
+    db.free()
 
 
 def _bits(a):

@@ -18,7 +18,8 @@ def one(n, reps):
     out = {}
     for name, b in (("ring16", workloads.ring16(n)), ("ring16_fixed_gauge", workloads.ring16(n // 4, fix_gauge=True)),
                     ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("hinged_11", workloads.hinged_triangles(n, 11)),
-                    ("hinged_5", workloads.hinged_triangles(n, 5)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True))):
+                    ("hinged_5", workloads.hinged_triangles(n, 5)), ("hinged_1", workloads.hinged_triangles(n, 1)),
+                    ("hinged_3", workloads.hinged_triangles(n, 3)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True))):
         db = ctx.upload(b)
         o = abi.solving_opts(f32=name.endswith("_f32"))
         db.system_solve(o)
