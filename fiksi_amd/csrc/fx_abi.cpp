@@ -1369,6 +1369,211 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
     return build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
 }
 
+// The program of the grouped kernel's SPARSE build (fx_grouped_s.hip): batches of one structure whose single component is too
+// wide for a register-resident factor (49 free variables and more) but whose Cholesky factor is small — the reference's bench
+// sketch of 16 hinged triangles has 66 variables and a factor of 291 entries. Everything the kernel does is a walk over tables:
+// the row lists and product lists of fx_grouped_c.hip, and the factorisation as a level schedule — a minimum-degree order of the
+// columns, the factor's pattern by columns (column k: its diagonal slot, then its rows ascending), the levels of its
+// elimination tree (the columns of a level are independent), per level the update triples L(i, j) -= L(i, k) L(j, k) and the
+// (slot, column, row) entries of the triangular solves. Words: [0] version [1] variables [2] expressions [3] free variables
+// [4] products (padded to 64) [5] right-hand-side entries (padded to 64) [6] factor slots (even) [7] compact Jacobian entries
+// (even) [8] levels [9] update triples [10] below-diagonal entries [11 ...] byte offsets of the tables, in the order of the
+// `put` calls below [31] words in all.
+struct GsHostProgram {
+    std::vector<uint32_t> words;
+    uint32_t nl = 0, ng = 0, nvt = 0, net = 0, nfree = 0;
+};
+static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
+                             uint32_t nvt, uint32_t net, GsHostProgram& out) {
+    out = GsHostProgram();
+    if (nvt == 0 || nvt > 128u || net == 0 || net > 128u) return false;
+    std::vector<int16_t> vcol(nvt, -1);
+    std::vector<uint16_t> fidx;
+    for (uint32_t i = 0; i < nvt; ++i) {
+        if ((var_info[i] & fx::VAR_COMP_MASK) != 0) return false;
+        if (!(var_info[i] & fx::VAR_FIXED_BIT)) {
+            vcol[i] = (int16_t)fidx.size();
+            fidx.push_back((uint16_t)i);
+        }
+    }
+    const uint32_t n = (uint32_t)fidx.size();
+    if (n <= 48u || n > 128u) return false;
+    std::vector<uint8_t> rtag(net), gvar((size_t)net * 8, 0);
+    std::vector<uint16_t> gbase(net);
+    std::vector<int> gcol((size_t)net * 8, -1);
+    uint32_t ng = 0;
+    std::vector<uint8_t> adj((size_t)n * n, 0);  // pattern of Jt J
+    for (uint32_t r = 0; r < net; ++r) {
+        if (expr_comp[r] != 0) return false;
+        const int tag = (int)(expr_tag[r] & 0x7F);
+        if (tag >= FX_TAG_POSE_X) return false;
+        uint32_t vars8[8];
+        const int k = fx::expand_vars(tag, expr_idx16 + 4 * (size_t)r, vars8);
+        rtag[r] = (uint8_t)tag;
+        gbase[r] = (uint16_t)ng;
+        for (int e = 0; e < 8; ++e) {
+            if (vars8[e] >= nvt) return false;
+            gvar[(size_t)r * 8 + e] = (uint8_t)vars8[e];
+            gcol[(size_t)r * 8 + e] = e < k ? (int)vcol[vars8[e]] : -1;
+        }
+        ng += (uint32_t)k;
+        for (int a = 0; a < k; ++a)
+            for (int bb = 0; bb < k; ++bb)
+                if (gcol[(size_t)r * 8 + a] >= 0 && gcol[(size_t)r * 8 + bb] >= 0)
+                    adj[(size_t)gcol[(size_t)r * 8 + a] * n + (size_t)gcol[(size_t)r * 8 + bb]] = 1;
+    }
+    if (ng > 1023u) return false;
+    // ---- minimum-degree order on the graph of Jt J (ties: the lower column), eliminating on a copy
+    std::vector<uint32_t> order, pos(n, 0);
+    {
+        std::vector<uint8_t> g = adj;
+        std::vector<uint8_t> gone(n, 0);
+        for (uint32_t step = 0; step < n; ++step) {
+            uint32_t best = n, bdeg = 0xFFFFFFFFu;
+            for (uint32_t c = 0; c < n; ++c) {
+                if (gone[c]) continue;
+                uint32_t deg = 0;
+                for (uint32_t e = 0; e < n; ++e) deg += (!gone[e] && e != c && g[(size_t)c * n + e]) ? 1u : 0u;
+                if (deg < bdeg) {
+                    bdeg = deg;
+                    best = c;
+                }
+            }
+            gone[best] = 1;
+            pos[best] = step;
+            order.push_back(best);
+            for (uint32_t a = 0; a < n; ++a)
+                if (!gone[a] && g[(size_t)best * n + a])
+                    for (uint32_t bb = 0; bb < n; ++bb)
+                        if (!gone[bb] && g[(size_t)best * n + bb]) g[(size_t)a * n + bb] = 1;
+        }
+    }
+    // ---- the factor's pattern in elimination order: lp[i][k] (positions), with fill
+    std::vector<uint8_t> lp((size_t)n * n, 0);
+    for (uint32_t a = 0; a < n; ++a)
+        for (uint32_t bb = 0; bb < n; ++bb)
+            if (a == bb || adj[(size_t)a * n + bb]) {
+                const uint32_t pi = std::max(pos[a], pos[bb]), pk = std::min(pos[a], pos[bb]);
+                lp[(size_t)pi * n + pk] = 1;
+            }
+    for (uint32_t k = 0; k < n; ++k)
+        for (uint32_t i = k + 1; i < n; ++i)
+            if (lp[(size_t)i * n + k])
+                for (uint32_t j = k + 1; j <= i; ++j)
+                    if (lp[(size_t)j * n + k]) lp[(size_t)i * n + j] = 1;
+    // slots: column position k holds its diagonal, then its rows (positions ascending)
+    std::vector<uint16_t> cbase(n + 1, 0);
+    std::vector<int32_t> slot((size_t)n * n, -1);
+    std::vector<uint8_t> rowof;  // free COLUMN id of a slot's row
+    uint32_t nl = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        cbase[k] = (uint16_t)nl;
+        for (uint32_t i = k; i < n; ++i)
+            if (lp[(size_t)i * n + k]) {
+                slot[(size_t)i * n + k] = (int32_t)nl++;
+                rowof.push_back((uint8_t)order[i]);
+            }
+        if (nl > 1023u) return false;
+    }
+    cbase[n] = (uint16_t)nl;
+    // levels of the elimination tree: a column waits for every column that updates it
+    std::vector<uint32_t> level(n, 0);
+    uint32_t nlev = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        for (uint32_t j = 0; j < k; ++j)
+            if (lp[(size_t)k * n + j]) level[k] = std::max(level[k], level[j] + 1u);
+        nlev = std::max(nlev, level[k] + 1u);
+    }
+    std::vector<uint8_t> lcol;      // column POSITIONS in level order
+    std::vector<uint16_t> lptr(1, 0);
+    std::vector<uint32_t> uptr(1, 0), eptr(1, 0), upd, ent;
+    for (uint32_t lv = 0; lv < nlev; ++lv) {
+        for (uint32_t k = 0; k < n; ++k) {
+            if (level[k] != lv) continue;
+            lcol.push_back((uint8_t)k);
+            for (uint32_t i = k + 1; i < n; ++i) {
+                if (!lp[(size_t)i * n + k]) continue;
+                // (slot | column id of k << 10 | column id of the row << 18): the triangular solves' entries
+                ent.push_back((uint32_t)slot[(size_t)i * n + k] | (order[k] << 10) | (order[i] << 18));
+                for (uint32_t j = k + 1; j <= i; ++j)
+                    if (lp[(size_t)j * n + k])
+                        upd.push_back((uint32_t)slot[(size_t)i * n + j] | ((uint32_t)slot[(size_t)i * n + k] << 10) | ((uint32_t)slot[(size_t)j * n + k] << 20));
+            }
+        }
+        lptr.push_back((uint16_t)lcol.size());
+        uptr.push_back((uint32_t)upd.size());
+        eptr.push_back((uint32_t)ent.size());
+    }
+    // per column position: its column id; per column id: the slot of its diagonal
+    std::vector<uint8_t> colid(n);
+    std::vector<uint16_t> dslot(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        colid[k] = (uint8_t)order[k];
+        dslot[order[k]] = cbase[k];
+    }
+    // products of Jt J into the factor's slots, right-hand side entries (the order of fx_grouped_c.hip's lists)
+    std::vector<uint32_t> pw, pe;
+    for (uint32_t r = 0; r < net; ++r)
+        for (int a = 0; a < 8; ++a) {
+            const int ca = gcol[(size_t)r * 8 + a];
+            if (ca < 0) continue;
+            pe.push_back((gbase[r] + (uint32_t)a) | (r << 10) | ((uint32_t)ca << 20));
+            for (int bb = a; bb < 8; ++bb) {
+                const int cb = gcol[(size_t)r * 8 + bb];
+                if (cb < 0) continue;
+                const uint32_t pi = std::max(pos[(uint32_t)ca], pos[(uint32_t)cb]), pk = std::min(pos[(uint32_t)ca], pos[(uint32_t)cb]);
+                const uint32_t w = (gbase[r] + (uint32_t)a) | ((gbase[r] + (uint32_t)bb) << 10) | ((uint32_t)slot[(size_t)pi * n + pk] << 20);
+                pw.push_back(w);
+                if (a != bb && ca == cb) pw.push_back(w);
+            }
+        }
+    while (pw.size() % 64u) pw.push_back(0xFFFFFFFFu);
+    while (pe.size() % 64u) pe.push_back(0xFFFFFFFFu);
+    std::vector<uint32_t>& w = out.words;
+    w.assign(32, 0);
+    auto put = [&](const void* src, size_t bytes) -> uint32_t {
+        const uint32_t at = (uint32_t)w.size() * 4u;
+        w.resize(w.size() + (bytes + 15u) / 16u * 4u, 0u);
+        if (bytes) memcpy(reinterpret_cast<unsigned char*>(w.data()) + at, src, bytes);
+        return at;
+    };
+    w[11] = put(vcol.data(), vcol.size() * 2);
+    w[12] = put(fidx.data(), fidx.size() * 2);
+    w[13] = put(rtag.data(), rtag.size());
+    w[14] = put(gbase.data(), gbase.size() * 2);
+    w[15] = put(gvar.data(), gvar.size());
+    w[16] = put(dslot.data(), dslot.size() * 2);
+    w[17] = put(cbase.data(), cbase.size() * 2);
+    w[18] = put(rowof.data(), rowof.size());
+    w[19] = put(lcol.data(), lcol.size());
+    w[20] = put(lptr.data(), lptr.size() * 2);
+    w[21] = put(uptr.data(), uptr.size() * 4);
+    w[22] = put(eptr.data(), eptr.size() * 4);
+    w[23] = put(upd.data(), upd.size() * 4);
+    w[24] = put(ent.data(), ent.size() * 4);
+    w[25] = put(pw.data(), pw.size() * 4);
+    w[26] = put(pe.data(), pe.size() * 4);
+    w[27] = put(colid.data(), colid.size());
+    w[0] = 1u;
+    w[1] = nvt;
+    w[2] = net;
+    w[3] = n;
+    w[4] = (uint32_t)pw.size();
+    w[5] = (uint32_t)pe.size();
+    w[6] = (nl + 1u) & ~1u;
+    w[7] = (ng + 1u) & ~1u;
+    w[8] = nlev;
+    w[9] = (uint32_t)upd.size();
+    w[10] = (uint32_t)ent.size();
+    w[31] = (uint32_t)w.size();
+    out.nl = (nl + 1u) & ~1u;
+    out.ng = (ng + 1u) & ~1u;
+    out.nvt = nvt;
+    out.net = net;
+    out.nfree = n;
+    return true;
+}
+
 // The same analysis compiled into a table-driven program for the grouped FX_STEP_QR build (fx_grouped.hip: four Systems per
 // wavefront, one per row of 16 lanes; batches of ONE structure, so one program serves every System). The permuted augmented
 // matrix [J | -r; sqrt(lambda) I | 0] is stored by its symbolic patterns — per column position j the rows of R(:, j) above the
@@ -2413,6 +2618,17 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
         d.gc_ng = gc.ng;
         d.gc_nc = gc.nc;
     }
+    // ... or of its sparse build (fx_grouped_s.hip), for Systems beyond a register-resident factor whose own factor is small
+    GsHostProgram gs;
+    if (d.uniform && d.u_ncomp == 1u && !d.gc_tab && d.u_nvars <= 128u && d.u_nexprs <= 128u &&
+        build_gs_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
+                         d.u_nexprs, gs)) {
+        FX_UP(gs_tab, gs.words.data(), gs.words.size())
+        d.gs_words = (uint32_t)gs.words.size();
+        d.gs_nl = gs.nl;
+        d.gs_ng = gs.ng;
+        d.gs_nfree = gs.nfree;
+    }
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy
     FX_UP(vars, (const double*)batch->vars + v0, n_vars)
@@ -2722,6 +2938,10 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         rc = ensure_qr_plans(ctx, db, o.decomposer == 1);
         if (rc) return rc;
     }
+    if (fx::grouped_s_applies(db->d, p)) {  // one structure, a wide component with a small factor: every System of the batch in one launch
+        FX_HIP(fx::launch_solve_grouped_s(db->d, p, ctx->stream));
+        return FX_OK;
+    }
     rc = launch_solve_scheduled(ctx, db, p);
     if (rc) return rc;
     return solve_beyond_one_wavefront(ctx, db, p);
@@ -2740,6 +2960,10 @@ int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) {
         if (p.lm.precision == 32) return fail(FX_ERR_UNSUPPORTED, "FX_STEP_QR is the f64 Levenberg-Marquardt step");
         rc = ensure_qr_plans(ctx, db, false);
         if (rc) return rc;
+    }
+    if (fx::grouped_s_applies(db->d, p)) {  // one structure, a wide component with a small factor: every System of the batch in one launch
+        FX_HIP(fx::launch_solve_grouped_s(db->d, p, ctx->stream));
+        return FX_OK;
     }
     rc = launch_solve_scheduled(ctx, db, p);
     if (rc) return rc;
@@ -2770,7 +2994,7 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     ctx->route(p);
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
-    *build = !fx::grouped_applies(db->d, p) ? -1 : (p.lm.solver == FX_STEP_CHOLESKY && fx::grouped_c_applies(db->d, p)) ? 1 : 0;
+    *build = fx::grouped_s_applies(db->d, p) ? 2 : !fx::grouped_applies(db->d, p) ? -1 : (p.lm.solver == FX_STEP_CHOLESKY && fx::grouped_c_applies(db->d, p)) ? 1 : 0;
     return FX_OK;
 }
 

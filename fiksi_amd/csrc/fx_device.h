@@ -142,6 +142,10 @@ struct DeviceBatch {
     uint32_t* gc_tab;
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
     uint32_t gc_nc;                       // columns per lane of the build the program is for: 1 (up to 16 free variables), 2 (17 ... 32) or 3 (33 ... 48)
+    // the program of its sparse build (fx_grouped_s.hip; build_gs_program): uniform batches with one component of 49 ... 128 free
+    // variables whose Cholesky factor has at most 1023 entries; null otherwise
+    uint32_t* gs_tab;
+    uint32_t gs_words, gs_nl, gs_ng, gs_nfree;  // words; slots of the factor (even); compact Jacobian entries (even); free variables
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
     // only the pose instantiations of the solve kernel may run it
     uint32_t has_pose;
@@ -199,6 +203,9 @@ size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool singl
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t element_size);
+// ... and its sparse build for batches of one structure of 49 ... 128 free variables with a small factor (fx_grouped_s.hip)
+bool grouped_s_applies(const DeviceBatch& b, const LmParams& p);
+hipError_t launch_solve_grouped_s(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // dst[0 .. bytes) = src[0 .. bytes), 16 bytes per thread (both 16-byte aligned, bytes a multiple of 16): pulls a one-shot

@@ -19,6 +19,8 @@ size_t grouped_lds_bytes(const DeviceBatch&, uint32_t, bool) { return 0; }
 bool grouped_c_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped_c(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t grouped_c_lds_bytes(const DeviceBatch&, uint32_t) { return 0; }
+bool grouped_s_applies(const DeviceBatch&, const LmParams&) { return false; }
+hipError_t launch_solve_grouped_s(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_solve_walk(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t presort_temp_bytes(uint32_t) { return 0; }
 hipError_t launch_pull(void*, const void*, size_t, hipStream_t) { return hipErrorNoDevice; }

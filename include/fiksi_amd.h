@@ -327,7 +327,9 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
 /* Diagnostic only: which BUILD of the grouped kernel such a launch would be: -1 = not the grouped kernel, 0 = the general build
  * (one wavefront per SIMD for components of 17 ... 32 free variables), 1 = the build for batches of one structure
  * (fx_grouped_c.hip: the structure's lists shared by a wavefront's four Systems, Jt J by its pattern, two wavefronts per
- * SIMD for that shape; same bits). A context created under FIKSI_AMD_GROUPED_C=0 never takes build 1. Launches nothing. */
+ * SIMD for that shape; same bits), 2 = the sparse build for batches of one structure with a component of 49 ... 128 free
+ * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS).
+ * A context created under FIKSI_AMD_GROUPED_C=0 takes neither 1 nor 2. Launches nothing. */
 int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */
