@@ -95,6 +95,7 @@ extern "C" {
     pub fn fx_ctx_set_routing(ctx: *mut fx_ctx, grouped: c_int, grouped_min_systems: u32) -> c_int;
     pub fn fx_ctx_set_presort(ctx: *mut fx_ctx, enable: c_int, min_systems: u32) -> c_int;
     pub fn fx_ctx_set_hold_passes(ctx: *mut fx_ctx, passes: u32) -> c_int;
+    pub fn fx_ctx_set_one_structure_builds(ctx: *mut fx_ctx, enable: c_int) -> c_int;
     pub fn fx_ctx_set_ladder(ctx: *mut fx_ctx, enable: c_int, tail_systems: u32, min_trials: u32, spread: c_int) -> c_int;
     pub fn fx_ctx_set_wide_routing(ctx: *mut fx_ctx, wide: c_int) -> c_int;
     pub fn fx_ctx_set_host_threads(ctx: *mut fx_ctx, threads: u32) -> c_int;

@@ -106,6 +106,7 @@ SIGNATURES = [
     ("fx_ctx_set_routing", C.c_int, [_vp, C.c_int, C.c_uint32]),
     ("fx_ctx_set_presort", C.c_int, [_vp, C.c_int, C.c_uint32]),
     ("fx_ctx_set_hold_passes", C.c_int, [_vp, C.c_uint32]),
+    ("fx_ctx_set_one_structure_builds", C.c_int, [_vp, C.c_int]),
     ("fx_ctx_set_ladder", C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
     ("fx_ctx_set_wide_routing", C.c_int, [_vp, C.c_int]),
     ("fx_ctx_set_host_threads", C.c_int, [_vp, C.c_uint32]),

@@ -1386,7 +1386,7 @@ struct GsHostProgram {
 static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
                              uint32_t nvt, uint32_t net, GsHostProgram& out) {
     out = GsHostProgram();
-    if (nvt == 0 || nvt > 128u || net == 0 || net > 128u) return false;
+    if (nvt == 0 || nvt > 255u || net == 0 || net > 255u) return false;  // (a byte per variable / row / column id in the tables)
     std::vector<int16_t> vcol(nvt, -1);
     std::vector<uint16_t> fidx;
     for (uint32_t i = 0; i < nvt; ++i) {
@@ -1397,7 +1397,7 @@ static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, 
         }
     }
     const uint32_t n = (uint32_t)fidx.size();
-    if (n <= 48u || n > 128u) return false;
+    if (n <= 48u || n > 255u) return false;
     std::vector<uint8_t> rtag(net), gvar((size_t)net * 8, 0);
     std::vector<uint16_t> gbase(net);
     std::vector<int> gcol((size_t)net * 8, -1);
@@ -2424,6 +2424,12 @@ int fx_ctx_set_routing(fx_ctx* ctx, int grouped, uint32_t grouped_min_systems) {
     return FX_OK;
 }
 
+int fx_ctx_set_one_structure_builds(fx_ctx* ctx, int enable) {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    ctx->grouped_one_structure = enable ? 1 : 0;
+    return FX_OK;
+}
+
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes) {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
     ctx->hold_passes = passes;
@@ -2620,7 +2626,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     }
     // ... or of its sparse build (fx_grouped_s.hip), for Systems beyond a register-resident factor whose own factor is small
     GsHostProgram gs;
-    if (d.uniform && d.u_ncomp == 1u && !d.gc_tab && d.u_nvars <= 128u && d.u_nexprs <= 128u &&
+    if (d.uniform && d.u_ncomp == 1u && !d.gc_tab && d.u_nvars <= 255u && d.u_nexprs <= 255u &&
         build_gs_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
                          d.u_nexprs, gs)) {
         FX_UP(gs_tab, gs.words.data(), gs.words.size())

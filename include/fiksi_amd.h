@@ -236,6 +236,13 @@ int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
  * second row to finish, so that the two take their next Systems side by side — the hand-over blocks cost the wavefront
  * the same for one row as for four. 0: never wait. Scheduling only: every System's result is the same bits either way. */
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
+/* Batches whose Systems all have ONE structure (one component) run builds of the grouped kernel made for them: up to 48 free
+ * variables fx_grouped_c.hip (the structure's lists shared by a wavefront, Jt J by its pattern, up to four wavefronts per SIMD:
+ * the same bits as the general build), 49 ... 255 free variables with a Cholesky factor of at most 1023 entries fx_grouped_s.hip
+ * (the factorisation as a level schedule over tables in LDS: the normal-equation step in a minimum-degree order — the same
+ * counters as the team / wide kernels such batches took before, variables to round-off). enable = 0 keeps such batches on the
+ * general paths (default 1; a context created under FIKSI_AMD_GROUPED_C=0 starts with 0). fx_debug_grouped_build tells. */
+int fx_ctx_set_one_structure_builds(fx_ctx* ctx, int enable);
 /* Grouped kernel, the lambda ladder. The trials that follow a rejected trial of the reference's loop (lm.rs:187-190) read
  * the same point, Jacobian and residuals and differ in lambda only (x 2 each), so a row of a wavefront that has no System
  * of its own tries the next lambda of a System that is still running in its wavefront, in the same pass: up to four

@@ -64,8 +64,11 @@ def test_medium_components_take_one_route_for_every_shard(fiksi, ctx):
 
     b = workloads.hinged_triangles(2000, 16)
     assert int(b["var_off"][1]) == 66
+    ctx.set_one_structure_builds(False)  # (this is about the wide / team choice: the sparse one-structure build would take the batch)
     v1, r1 = ctx.system_solve_batch(b)
     others = [fiksi.Context(0) for _ in range(3)]
+    for c in others:
+        c.set_one_structure_builds(False)
     try:
         for n_ctx in (1, 2, 3):
             v, r, _ = abi.Context.system_solve_batch_multi(others[:n_ctx], b)
@@ -83,5 +86,6 @@ def test_medium_components_take_one_route_for_every_shard(fiksi, ctx):
             abi.Context.system_solve_batch_multi(others, b)
     finally:
         ctx.set_wide_routing(-1)
+        ctx.set_one_structure_builds(True)
         for c in others:
             c.close()

@@ -7,6 +7,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def team_kernels(ctx):
+    """These tests are about the team kernels: batches of one structure with a small factor would take the grouped kernel's
+    sparse build instead (fx_grouped_s.hip; tests/test_gpu_grouped_s.py)."""
+    ctx.set_one_structure_builds(False)
+    yield
+    ctx.set_one_structure_builds(True)
+
+
 def _singles(ctx, batches, opts=None):
     vs, rs = [], []
     for b in batches:

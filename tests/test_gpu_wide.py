@@ -11,8 +11,10 @@ def wide_kernel(ctx):
     """These tests are about the wide kernel: pin it (by default a small batch of such Systems goes to the team kernels,
     which finish one of them in half the time — fx_ctx_set_wide_routing; the last test covers that choice)."""
     ctx.set_wide_routing(1)
+    ctx.set_one_structure_builds(False)  # (batches of one structure would take fx_grouped_s.hip: tests/test_gpu_grouped_s.py)
     yield
     ctx.set_wide_routing(-1)
+    ctx.set_one_structure_builds(True)
 
 
 def _rms(x):
