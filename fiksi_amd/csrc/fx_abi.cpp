@@ -1397,7 +1397,7 @@ static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, 
         }
     }
     const uint32_t n = (uint32_t)fidx.size();
-    if (n <= 48u || n > 255u) return false;
+    if (n <= 32u || n > 255u) return false;
     std::vector<uint8_t> rtag(net), gvar((size_t)net * 8, 0);
     std::vector<uint16_t> gbase(net);
     std::vector<int> gcol((size_t)net * 8, -1);
@@ -2612,28 +2612,32 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     FX_UP(expr_param, batch->expr_param + e0, n_exprs)
     FX_UP(work_counter, (const uint32_t*)nullptr, 1)
     if (sys_class) FX_UP(sys_class, sys_class, n_sys)
-    // a batch of one structure: the program of the grouped kernel's two-wavefronts-per-SIMD build (fx_grouped_c.hip), when
-    // the structure qualifies
-    GcHostProgram gc;
-    if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u &&
-        build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
-                         d.u_nexprs, p.max_free, gc)) {
-        FX_UP(gc_tab, gc.words.data(), gc.words.size())
-        d.gc_words = (uint32_t)gc.words.size();
-        d.gc_nslots = gc.nslots;
-        d.gc_ng = gc.ng;
-        d.gc_nc = gc.nc;
-    }
-    // ... or of its sparse build (fx_grouped_s.hip), for Systems beyond a register-resident factor whose own factor is small
+    // A batch of one structure gets the program of one of the grouped kernel's builds for such batches, when the structure
+    // qualifies: the sparse build (fx_grouped_s.hip) for components beyond a register-resident factor — and from 33 free variables
+    // on when the factor is sparse (at most a quarter of the dense triangle: the reference's bench sketch of 11 triangles, 46
+    // variables, 201 of 1 081 entries: 2.26 ms per 100 000 against 3.14 in the 48-column register build) —, the register build
+    // (fx_grouped_c.hip) otherwise.
     GsHostProgram gs;
-    if (d.uniform && d.u_ncomp == 1u && !d.gc_tab && d.u_nvars <= 255u && d.u_nexprs <= 255u &&
+    GcHostProgram gc;
+    bool sparse_build = false;
+    if (d.uniform && d.u_ncomp == 1u && d.u_nvars <= 255u && d.u_nexprs <= 255u &&
         build_gs_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
-                         d.u_nexprs, gs)) {
+                         d.u_nexprs, gs))
+        sparse_build = gs.nfree > 48u || 4u * gs.nl <= gs.nfree * (gs.nfree + 1u) / 2u;
+    if (sparse_build) {
         FX_UP(gs_tab, gs.words.data(), gs.words.size())
         d.gs_words = (uint32_t)gs.words.size();
         d.gs_nl = gs.nl;
         d.gs_ng = gs.ng;
         d.gs_nfree = gs.nfree;
+    } else if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u &&
+               build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0,
+                                d.u_nvars, d.u_nexprs, p.max_free, gc)) {
+        FX_UP(gc_tab, gc.words.data(), gc.words.size())
+        d.gc_words = (uint32_t)gc.words.size();
+        d.gc_nslots = gc.nslots;
+        d.gc_ng = gc.ng;
+        d.gc_nc = gc.nc;
     }
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy

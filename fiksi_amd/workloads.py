@@ -114,6 +114,48 @@ def ring16(n_systems: int, seed0: int = 1000, inconsistent: bool = False, fix_ga
     }
 
 
+def ring_chords(n_systems: int, n_points: int = 20, step: int = 7, seed0: int = 5000) -> Dict[str, np.ndarray]:
+    """n independent sketches of `n_points` points on a jittered circle with the distances (i, i + 1) and (i, i + step): a
+    structure whose normal matrix fills in when factored (the long chords couple everything), unlike the banded ring16 or the
+    arrow-shaped hinged chains. Consistent targets. 2 n_points variables, 2 n_points expressions."""
+    n, P = int(n_systems), int(n_points)
+    rng = LcgVec(seed0 + np.arange(n, dtype=np.uint64))
+    R = 5.0 + 10.0 * rng.next_f64()
+    truth = np.zeros((n, P, 2))
+    for i in range(P):
+        th = 2.0 * np.pi * (i + 0.3 * (rng.next_f64() - 0.5)) / P
+        ri = R * (1.0 + 0.1 * (rng.next_f64() - 0.5))
+        truth[:, i, 0] = ri * np.cos(th)
+        truth[:, i, 1] = ri * np.sin(th)
+    start = truth.copy()
+    for i in range(P):
+        for c in range(2):
+            start[:, i, c] += 0.03 * R * (2.0 * rng.next_f64() - 1.0)
+    m = 2 * P
+    tag = np.full((n, m), abi.POINT_POINT_DISTANCE, dtype=np.uint8)
+    idx = np.zeros((n, m, 4), dtype=np.uint32)
+    par = np.zeros((n, m))
+    row = 0
+    for hop in (1, step):
+        for i in range(P):
+            j = (i + hop) % P
+            idx[:, row, 0], idx[:, row, 1] = 2 * i, 2 * j
+            d = truth[:, i, :] - truth[:, j, :]
+            par[:, row] = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+            row += 1
+    return {
+        "var_off": (np.arange(n + 1, dtype=np.uint64) * (2 * P)).astype(np.uint32),
+        "expr_off": (np.arange(n + 1, dtype=np.uint64) * m).astype(np.uint32),
+        "vars": start.reshape(-1).copy(),
+        "var_fixed": np.zeros(n * 2 * P, dtype=np.uint8),
+        "expr_tag": tag.reshape(-1),
+        "expr_idx": idx.reshape(-1),
+        "expr_param": par.reshape(-1),
+        "var_comp": np.zeros(n * 2 * P, dtype=np.uint16),
+        "expr_comp": np.zeros(n * m, dtype=np.uint16),
+    }
+
+
 RING16_NNZ = 24 * 4 + 8 * 6  # 144
 # SURVEY.md §8d: algorithmic bytes of one Jacobian-assembly evaluation of one ring16 system:
 # 8*nv (x) + 28*m (tag 4 + idx 16 + param 8) + 8*m (r) + 8*nnz (J values)

@@ -62,7 +62,11 @@ def test_forty_eight_column_build_on_the_references_bench_sketch(fiksi, oracle, 
     b = workloads.hinged_triangles(1030, n_tri)
     assert 32 < int(b["var_off"][1]) <= 48
     routing("1")
-    v1, r1 = _solve(ctx, b)
+    ctx.set_one_structure_builds(False)  # (the general build: a batch of one structure with so sparse a factor takes fx_grouped_s.hip)
+    try:
+        v1, r1 = _solve(ctx, b)
+    finally:
+        ctx.set_one_structure_builds(True)
     routing("0")
     v0, r0 = _solve(ctx, b)
     assert np.array_equal(_bits(v1), _bits(v0))

@@ -17,7 +17,7 @@ def one(n, reps):
     ctx = fiksi_amd.Context(0)
     out = {}
     for name, b in (("ring16", workloads.ring16(n)), ("ring16_fixed_gauge", workloads.ring16(n // 4, fix_gauge=True)),
-                    ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("hinged_11", workloads.hinged_triangles(n, 11)),
+                    ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("ring20_chords", workloads.ring_chords(n, 20, 7)),
                     ("hinged_5", workloads.hinged_triangles(n, 5)), ("hinged_1", workloads.hinged_triangles(n, 1)),
                     ("hinged_3", workloads.hinged_triangles(n, 3)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True))):
         db = ctx.upload(b)

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-CASES = [(13, 20000), (16, 20000), (24, 8192), (31, 8192), (48, 2048), (63, 256)]
+CASES = [(11, 100000), (13, 20000), (16, 20000), (24, 8192), (31, 8192)]
 
 
 def one(reps, dump):
