@@ -392,6 +392,18 @@ def cfg4_prediction(ctx, abi, workloads, batch, full_ms):
     return out
 
 
+def _build_name(db):
+    """Which kernel a resident batch's default solve runs (fx_debug_grouped_build / fx_debug_solve_route)."""
+    b = db.grouped_build()
+    if b == 2:
+        return "lm_solve_grouped_s_kernel (one structure, sparse factor: level-scheduled Cholesky over tables in LDS, fx_grouped_s.hip)"
+    if b == 1:
+        return "lm_solve_grouped_c*_kernel (one structure: lists shared per wavefront, Jt J by its pattern, fx_grouped_c.hip)"
+    if b == 0:
+        return "lm_solve_grouped_kernel (four Systems per wavefront, fx_grouped.hip)"
+    return "one wavefront per System / wide / team kernels (by size)"
+
+
 def reference_bench_group(ctx, abi, workloads, np):
     """fiksi/benches/fiksi_bench.rs:46-73: `solve/hinged_triangles`, sizes 1, 4, 16, 64 (6 / 18 / 66 / 258 variables).
     The reference measures the latency of ONE System::solve per size; here each size is reported (a) as that
@@ -440,7 +452,7 @@ def reference_bench_group(ctx, abi, workloads, np):
         ms = _time_solves(ctx, db, abi.solving_opts(), reps=2)
         res = db.get_results()
         conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
-        entry["batch"] = {"systems": n_batch, "ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3),
+        entry["batch"] = {"systems": n_batch, "ms_per_step": ms, "kernel": _build_name(db), "converged_systems_per_sec": conv / (ms * 1e-3),
                           "converged_fraction": conv / n_batch, "triangles_per_sec": conv * n_tri / (ms * 1e-3)}
         db.free()
         out[f"hinged_triangles_{n_tri}"] = entry

@@ -61,6 +61,7 @@ python3 tools/straggler_probe.py 12500 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}
 python3 tools/shard_times.py 100000 off:0 default 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_cfg4_shard_times.json
 python3 tools/ladder_probe.py 100000 full 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_ladder_probe.json
 python3 tools/grouped_c_ab.py 100000 10 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_grouped_builds_ab.json
+python3 tools/grouped_s_ab.py 5 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_sparse_build_ab.json
 tools/probes/rw_mix_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_hbm_rw_mix.json
 tools/probes/valu_cost_probe.bin 2>> $OUT/misc.err | tail -1 > $OUT/${TAG}_valu_cost.json
 echo "[collect] plain bench line (it quotes the counter files: this run's go to profiles/ first)"
