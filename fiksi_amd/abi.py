@@ -365,7 +365,8 @@ class DeviceBatch:
         return int(r.value)
 
     def grouped_build(self, opts=None) -> int:
-        """-1: not the grouped kernel, 0: its general build, 1: its build for batches of one structure (diagnostic)."""
+        """-1: not the grouped kernel, 0: its general build, 1: its build for batches of one structure, 2: the sparse build for
+        such batches, 3: build 1 over the big structure classes of a batch of several structures (diagnostic)."""
         o = opts if opts is not None else solving_opts()
         r = C.c_int(0)
         check(lib.fx_debug_grouped_build(self.ctx.handle, self._h, C.byref(o), C.byref(r)), "fx_debug_grouped_build")

@@ -817,6 +817,14 @@ struct fx_ctx {
 struct fx_dbatch {
     fx::DeviceBatch d{};
     std::vector<fx_ctx::Block> allocations;
+    // A batch of SEVERAL structures (a few sketches, many parameter sets each): its big structure classes, each solved by a
+    // launch of the grouped kernel's one-structure build over the class's member list (launch_class_solves); `rest`: everyone else
+    std::vector<fx::GcClass> classes;  // (programs inside cl_words, members inside cl_lists)
+    fx::GcClass* cl_desc = nullptr;    // ... on the device
+    uint32_t* cl_words = nullptr;
+    uint32_t* cl_lists = nullptr;
+    uint32_t cl_nc = 0, cl_max_words = 0, cl_max_slots = 0, cl_max_ng = 0, cl_systems = 0;  // the classes' common build, the largest program, their Systems in all
+    uint32_t rest_off = 0, rest_count = 0;
     // host copy of the batch, kept only when some System needs the sparse path
     std::vector<uint32_t> h_var_off, h_expr_off, h_expr_idx;
     std::vector<double> h_vars, h_expr_param;
@@ -2042,8 +2050,73 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
 
 // launch_solve, with the Systems of a big batch of small Systems handed out longest-first (fx_presort.hip) unless the
 // caller chose a schedule (fx_batch_schedule_by_last_solve) or switched it off (fx_ctx_set_presort)
+// A batch of several structures whose big classes have programs (upload_planned): ONE launch of the one-structure build over
+// all of them — a wavefront works through the queue of its class, then loads the next class's program and helps there
+// (fx_grouped_c.hip) —, and the general build over everyone else. Results are each System's own: the bits of the general build.
+// Returns false when the batch or the options do not qualify (nothing launched).
+static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p, int* rc) {
+    fx::DeviceBatch& d = db->d;
+    *rc = FX_OK;
+    if (db->classes.empty() || d.order || !p.grouped_one_structure || !fx::grouped_applies(d, p)) return false;
+    fx::DeviceBatch dc = d;
+    dc.gc_tab = db->cl_words;
+    dc.gc_words = db->cl_max_words;
+    dc.gc_nslots = db->cl_max_slots;
+    dc.gc_ng = db->cl_max_ng;
+    dc.gc_nc = db->cl_nc;
+    dc.gc_classes = db->cl_desc;
+    dc.gc_nclasses = (uint32_t)db->classes.size();
+    dc.order = db->cl_lists;
+    dc.n_systems = db->cl_systems;
+    dc.work_counter = d.work_counter + 1;
+    if (!fx::grouped_c_applies(dc, p)) return false;  // (f32 beyond the 32-column shape, the stamped build, ...: the general build for all)
+    // every list longest-first, as a whole batch would be (fx_presort.hip): the scout pass once, a ranking per list
+    uint32_t* lists = db->cl_lists;
+    if (ctx->presort && d.n_systems >= ctx->presort_min_systems) {
+        const uint32_t n = d.n_systems;
+        if (!db->ps_keys) {
+            db->ps_temp_bytes = fx::presort_temp_bytes(n);
+            int r2 = dev_alloc_copy(ctx, db, &db->ps_keys, (const float*)nullptr, 2 * (size_t)n);
+            if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_ids, (const uint32_t*)nullptr, 2 * (size_t)n);
+            if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_temp, (const unsigned char*)nullptr, db->ps_temp_bytes);
+            if (r2) {
+                *rc = r2;
+                return true;
+            }
+        }
+        std::vector<uint32_t> offs, counts;
+        for (const fx::GcClass& cl : db->classes) {
+            offs.push_back(cl.list_off);
+            counts.push_back(cl.count);
+        }
+        offs.push_back(db->rest_off);
+        counts.push_back(db->rest_count);
+        hipError_t e0 = fx::launch_presort_lists(d, db->ps_keys, db->cl_lists, offs.data(), counts.data(), (uint32_t)offs.size(), db->ps_ids + n, ctx->stream);
+        if (e0 != hipSuccess) {
+            *rc = fail(FX_ERR_HIP, "presort launch failed: %s", hipGetErrorString(e0));
+            return true;
+        }
+        lists = db->ps_ids + n;
+        dc.order = lists;
+    }
+    hipError_t e = fx::launch_solve_grouped_c(dc, p, ctx->stream);
+    if (e == hipSuccess && db->rest_count) {
+        fx::DeviceBatch dr = d;
+        dr.order = lists + db->rest_off;
+        dr.n_systems = db->rest_count;
+        dr.work_counter = d.work_counter + 1 + dc.gc_nclasses;
+        e = fx::launch_solve_grouped_general(dr, p, ctx->stream);
+    }
+    if (e != hipSuccess) *rc = fail(FX_ERR_HIP, "class launch failed: %s", hipGetErrorString(e));
+    return true;
+}
+
 int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     fx::DeviceBatch& d = db->d;
+    {
+        int rc = FX_OK;
+        if (launch_class_solves(ctx, db, p, &rc)) return rc;
+    }
     if (ctx->presort && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
         const uint32_t n = d.n_systems;
         if (!db->ps_keys) {
@@ -2610,7 +2683,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     FX_UP(expr_comp, p.expr_comp.data() + e0, n_exprs)
     FX_UP(expr_idx, p.expr_idx16.data() + 4 * (size_t)e0, 4 * (size_t)n_exprs)
     FX_UP(expr_param, batch->expr_param + e0, n_exprs)
-    FX_UP(work_counter, (const uint32_t*)nullptr, 1)
+    FX_UP(work_counter, (const uint32_t*)nullptr, 16)  // (the batch's queue head, then those of up to eight structure classes and of the rest: launch_class_solves)
     if (sys_class) FX_UP(sys_class, sys_class, n_sys)
     // A batch of one structure gets the program of one of the grouped kernel's builds for such batches, when the structure
     // qualifies: the sparse build (fx_grouped_s.hip) for components beyond a register-resident factor — and from 33 free variables
@@ -2638,6 +2711,65 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
         d.gc_nslots = gc.nslots;
         d.gc_ng = gc.ng;
         d.gc_nc = gc.nc;
+    }
+    // Several structures: the classes with 2 048 members and more (at most eight, the largest first; those of the largest one's
+    // build — columns per lane) get a program each
+    std::vector<uint32_t> cl_words_h, cl_lists_h;
+    if (!d.uniform && sys_class && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u) {
+        constexpr uint32_t CLASS_MIN = 2048u, MAX_CLASSES = 8u;
+        std::unordered_map<uint32_t, uint32_t> count;
+        for (uint32_t s = 0; s < n_sys; ++s) count[sys_class[s]] += 1u;
+        std::vector<std::pair<uint32_t, uint32_t>> big;  // (members, first System)
+        for (auto& kv : count)
+            if (kv.second >= CLASS_MIN) big.push_back({kv.second, kv.first});
+        std::sort(big.begin(), big.end(), [](auto& a, auto& b2) { return a.first != b2.first ? a.first > b2.first : a.second < b2.second; });
+        std::unordered_map<uint32_t, uint32_t> class_slot;  // first System -> index into db->classes
+        for (auto& pr : big) {
+            if (db->classes.size() >= MAX_CLASSES) break;
+            const uint32_t f = pr.second;
+            if (p.sys_ncomp[s0 + f] != 1u) continue;
+            const uint32_t vf = v0 + voff[f], ef = e0 + eoff[f], nvt = voff[f + 1] - voff[f], net = eoff[f + 1] - eoff[f];
+            uint32_t nfree = 0;
+            for (uint32_t i = 0; i < nvt; ++i) nfree += (p.var_info[vf + i] & fx::VAR_FIXED_BIT) ? 0u : 1u;
+            GcHostProgram cp;
+            if (!build_gc_program(p.var_info.data() + vf, p.expr_tagx.data() + ef, p.expr_comp.data() + ef, p.expr_idx16.data() + 4 * (size_t)ef, nvt, net,
+                                  nfree, cp))
+                continue;
+            if (db->classes.empty()) db->cl_nc = cp.nc;
+            if (cp.nc != db->cl_nc) continue;
+            fx::GcClass cl;
+            cl.prog_off = (uint32_t)cl_words_h.size();
+            cl.words = (uint32_t)cp.words.size();
+            cl.list_off = 0;
+            cl.count = pr.first;
+            db->cl_max_words = std::max(db->cl_max_words, cl.words);
+            db->cl_max_slots = std::max(db->cl_max_slots, cp.nslots);
+            db->cl_max_ng = std::max(db->cl_max_ng, cp.ng);
+            cl_words_h.insert(cl_words_h.end(), cp.words.begin(), cp.words.end());
+            class_slot[f] = (uint32_t)db->classes.size();
+            db->classes.push_back(cl);
+        }
+        if (!db->classes.empty()) {
+            uint32_t at = 0;
+            for (auto& cl : db->classes) {
+                cl.list_off = at;
+                at += cl.count;
+            }
+            db->cl_systems = at;
+            db->rest_off = at;
+            cl_lists_h.resize(n_sys);
+            std::vector<uint32_t> fill(db->classes.size(), 0);
+            uint32_t nrest = 0;
+            for (uint32_t s = 0; s < n_sys; ++s) {
+                auto it = class_slot.find(sys_class[s]);
+                if (it == class_slot.end()) cl_lists_h[db->rest_off + nrest++] = s;
+                else cl_lists_h[db->classes[it->second].list_off + fill[it->second]++] = s;
+            }
+            db->rest_count = nrest;
+            reqs.push_back({reinterpret_cast<void**>(&db->cl_words), cl_words_h.data(), cl_words_h.size() * 4});
+            reqs.push_back({reinterpret_cast<void**>(&db->cl_lists), cl_lists_h.data(), cl_lists_h.size() * 4});
+            reqs.push_back({reinterpret_cast<void**>(&db->cl_desc), db->classes.data(), db->classes.size() * sizeof(fx::GcClass)});
+        }
     }
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy
@@ -3005,6 +3137,16 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     p.lm = o.lm;
     p.mode = 1u | (o.perturb ? 2u : 0u) | (o.optimizer == 1 ? fx::MODE_LBFGS : 0u) | (o.decomposer == 1 ? fx::MODE_UNITS : 0u);
     *build = fx::grouped_s_applies(db->d, p) ? 2 : !fx::grouped_applies(db->d, p) ? -1 : (p.lm.solver == FX_STEP_CHOLESKY && fx::grouped_c_applies(db->d, p)) ? 1 : 0;
+    if (*build == 0 && !db->classes.empty() && !db->d.order && p.grouped_one_structure) {  // several structures: launch_class_solves
+        fx::DeviceBatch dc = db->d;
+        dc.gc_tab = db->cl_words;
+        dc.gc_words = db->cl_max_words;
+        dc.gc_nslots = db->cl_max_slots;
+        dc.gc_ng = db->cl_max_ng;
+        dc.gc_nc = db->cl_nc;
+        dc.gc_nclasses = (uint32_t)db->classes.size();
+        if (fx::grouped_c_applies(dc, p)) *build = 3;
+    }
     return FX_OK;
 }
 

@@ -74,6 +74,12 @@ template <int NC> struct GcTable {  // NC columns per lane: Systems of at most N
                               PE = LT + 16 * NC * NV;
 };
 
+// One structure class of a batch of several structures, for a launch of fx_grouped_c.hip over the batch's big classes: its program
+// (words into gc_tab), its members (entries into order)
+struct GcClass {
+    uint32_t prog_off, words, list_off, count;
+};
+
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
 struct DeviceBatch {
     uint32_t n_systems, n_vars, n_exprs;
@@ -142,6 +148,8 @@ struct DeviceBatch {
     uint32_t* gc_tab;
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
     uint32_t gc_nc;                       // columns per lane of the build the program is for: 1 (up to 16 free variables), 2 (17 ... 32) or 3 (33 ... 48)
+    const GcClass* gc_classes;            // a launch over several structure classes (null: one program, the whole batch)
+    uint32_t gc_nclasses;
     // the program of its sparse build (fx_grouped_s.hip; build_gs_program): uniform batches with one component of 49 ... 128 free
     // variables whose Cholesky factor has at most 1023 entries; null otherwise
     uint32_t* gs_tab;
@@ -198,6 +206,8 @@ size_t wide_qr_lds_bytes(uint32_t max_free, uint32_t max_vars, uint32_t max_rows
 // several Systems per wavefront (fx_grouped.hip): batches of components with at most 32 free variables
 bool grouped_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
+// ... its general build whatever programs the batch carries (the Systems of a batch of several structures that belong to no big class)
+hipError_t launch_solve_grouped_general(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool single_pass_blocks);
 // ... its build for batches of one structure, two wavefronts per SIMD (fx_grouped_c.hip)
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p);
@@ -214,6 +224,8 @@ hipError_t launch_pull(void* dst, const void* src, size_t bytes, hipStream_t str
 // scout + sort for the longest-first hand-out of the grouped kernel (fx_presort.hip)
 size_t presort_temp_bytes(uint32_t n);
 hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_presort_lists(const DeviceBatch& b, float* keys, const uint32_t* lists, const uint32_t* offs, const uint32_t* counts, uint32_t n_lists,
+                                uint32_t* out, hipStream_t stream);
 // fx_cluster.hip — the device side of the RecursiveAssembly arm around its cluster solves:
 // scale + LCG perturbation of whole Systems (assemble/mod.rs:58-124) without a solve, one wavefront per System
 // (out_params: the expression parameters as Expression::transform leaves them, expressions.rs:195-211)

@@ -572,7 +572,10 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 if (hl == 0) {
                     tk = atomicAdd(next_system, 1u);
                     last_tk = tk;
-                    if (b.order && tk < b.n_systems) {  // a schedule: presort, or an earlier solve of this batch
+                    if (tk >= b.n_systems) {
+                        tk = 0xFFFFFFFFu;  // the queue is empty (b.n_systems is the QUEUE's length: an order list over a part of the
+                                           // batch — launch_class_solves — holds System numbers beyond it)
+                    } else if (b.order) {  // a schedule: presort, or an earlier solve of this batch; or a part of the batch
                         // the first round of tickets transposed, so that the Systems at the head of the schedule — the
                         // likely stragglers — go to different wavefronts (a straggler's ladder is the rows of ITS wavefront)
                         uint32_t pos = tk;
@@ -583,9 +586,9 @@ __device__ __forceinline__ void grouped_body(const DeviceBatch& b, const LmParam
                 nxt = (uint32_t)__shfl((int)tk, 0, RS);
                 last_tk = (uint32_t)__shfl((int)last_tk, 0, RS);
                 // large Systems belong to the other paths (a batch of one shared structure has none here)
-                if (nxt >= b.n_systems || b.uniform || !b.sys_large[nxt]) break;
+                if (nxt == 0xFFFFFFFFu || b.uniform || !b.sys_large[nxt]) break;
             }
-            if (nxt >= b.n_systems) {
+            if (nxt == 0xFFFFFFFFu) {
                 phase = GP_EXIT;
                 qdone = true;
             } else {
@@ -1546,7 +1549,12 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
 hipError_t launch_solve_grouped(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     if (b.n_systems == 0) return hipSuccess;
     if (p.lm.solver == FX_STEP_QR) return launch_grouped_qr(b, p, stream);
-    if (grouped_c_applies(b, p)) return launch_solve_grouped_c(b, p, stream);  // one structure: two wavefronts per SIMD
+    if (b.uniform && grouped_c_applies(b, p)) return launch_solve_grouped_c(b, p, stream);  // one structure: two wavefronts per SIMD
+    return launch_solve_grouped_general(b, p, stream);
+}
+
+hipError_t launch_solve_grouped_general(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (b.n_systems == 0) return hipSuccess;
     const bool units = (p.mode & MODE_UNITS) != 0;
     const uint32_t nc = grouped_columns(b, units);
     const bool f32 = p.lm.precision == 32;

@@ -61,14 +61,16 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
     const int myrow = lane / RS;
-    {  // the program, once per wavefront
-        const uint4* src = reinterpret_cast<const uint4*>(b.gc_tab);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = lane; i < b.gc_words / 4u; i += 64) dst[i] = src[i];
-        group_sync();
-    }
+    // The program and the queue at hand. A batch of one structure has one of each; a batch of several structures brings a
+    // program, a member list and a queue head per structure CLASS (b.gc_classes; fx_abi.cpp: launch_class_solves): a wavefront
+    // starts on the class its place in the grid falls into — the grid is dealt in proportion to the classes' sizes — and, when
+    // that queue is empty and its Systems are done, loads the next class's program and goes on there: one launch, every
+    // wavefront busy until every queue is empty.
     const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
-    const uint32_t nvt = rfl(TB[1]), net = rfl(TB[2]), nfree = rfl(TB[3]), n_pw = rfl(TB[4]), n_pe = rfl(TB[5]), nslots = rfl(TB[6]);
+    uint32_t nvt = 0, net = 0, nfree = 0, n_pw = 0, n_pe = 0, nslots = 0;
+    uint32_t qn = 0;                  // Systems in the queue
+    const uint32_t* qlist = nullptr;  // ... their numbers (null: the ticket is the number)
+    uint32_t* qhead = next_system;    // ... its head
     // (the tables of fixed size sit at fixed places: fx_device.h, GcTable)
     const int8_t* vcol = reinterpret_cast<const int8_t*>(smem + TK::VCOL);         // [N] variable -> free column or -1
     const uint8_t* fidx = smem + TK::FIDX;                                         // [N] free column -> variable
@@ -77,14 +79,14 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     const uint2* gvar = reinterpret_cast<const uint2*>(smem + TK::GVAR);           // [N] eight variable numbers, a byte each
     const uint4* LT = reinterpret_cast<const uint4*>(smem + TK::LT + (uint32_t)hl * (uint32_t)(NC * N));  // this lane's NC x N slot numbers
     const uint32_t* PE = reinterpret_cast<const uint32_t*>(smem + TK::PE);         // right-hand side: entry | row << 8 | column << 16
-    const uint32_t* PW = reinterpret_cast<const uint32_t*>(smem + TK::PE) + n_pe;  // products: entry a | entry b << 8 | slot << 16
+    const uint32_t* PW = PE;                                                       // products: entry a | entry b << 8 | slot << 16 (behind PE)
 
     unsigned char* const rows0 = smem + L.tab_bytes;
     unsigned char* base = rows0 + (uint32_t)myrow * L.stride;
     T* XS = reinterpret_cast<T*>(base + BK::XS);          // [N] working variables: trial point on the free ones
     T* At = reinterpret_cast<T*>(base + BK::A);           // Jt J by slots (+ lambda on the diagonal per trial)
     T* rhsv = reinterpret_cast<T*>(base + BK::RHS);       // [N] -Jt r
-    T* G = reinterpret_cast<T*>(base + L.off_g);          // compact Jacobian rows of the last evaluated point
+    T* G = At;                                            // compact Jacobian rows of the last evaluated point (behind the slots)
     T* R = reinterpret_cast<T*>(base + BK::R);            // [N]
     T* P = reinterpret_cast<T*>(base + BK::P);            // [N] scaled parameters
     double* VOUT = reinterpret_cast<double*>(base + BK::VOUT);    // [N] unscaled values as written back
@@ -93,14 +95,10 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     const fx_lm_opts o = prm.lm;
     auto gballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & 0xFFFFu; };
 
-    // per lane, fixed for the launch: the variables of its two columns and the slots of their diagonal entries
+    // per lane, fixed for a program: the variables of its columns and the slots of their diagonal entries
     uint32_t my_vi[NC], dslot[NC];
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
-        const uint32_t j = (uint32_t)(hl + RS * q);
-        my_vi[q] = j < nfree ? (uint32_t)fidx[j] : 0u;
-        dslot[q] = (uint32_t)reinterpret_cast<const uint8_t*>(LT)[(uint32_t)(N * q) + j];
-    }
+    for (int q = 0; q < NC; ++q) my_vi[q] = dslot[q] = 0u;
 
     // per-row state (identical in every lane of the row unless noted)
     int phase = GP_NEXT;
@@ -217,35 +215,95 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         }
     };
 
+    const uint32_t ncls = b.gc_nclasses ? b.gc_nclasses : 1u;
+    uint32_t home = 0;
+    if (b.gc_nclasses > 1u) {  // the class this wavefront's place in the grid falls into
+        const unsigned long long at = (unsigned long long)blockIdx.x * b.n_systems;  // (b.n_systems: the classes' Systems in all)
+        unsigned long long acc = 0;
+        for (uint32_t c = 0; c < b.gc_nclasses; ++c) {
+            acc += b.gc_classes[c].count;
+            if (at < acc * gridDim.x) break;
+            home = c + 1u < b.gc_nclasses ? c + 1u : c;
+        }
+    }
+    for (uint32_t ci = 0; ci < ncls; ++ci) {
+    {
+        const uint32_t c = home + ci < ncls ? home + ci : home + ci - ncls;
+        const uint32_t* prog = b.gc_tab;
+        uint32_t words = b.gc_words;
+        qn = b.n_systems;
+        qlist = b.order;
+        qhead = next_system;
+        if (b.gc_nclasses) {
+            const GcClass k = b.gc_classes[c];
+            prog = b.gc_tab + k.prog_off;
+            words = k.words;
+            qn = k.count;
+            qlist = b.order + k.list_off;
+            qhead = next_system + c;
+        }
+        group_sync();
+        const uint4* src = reinterpret_cast<const uint4*>(prog);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = lane; i < words / 4u; i += 64) dst[i] = src[i];
+        group_sync();
+        nvt = rfl(TB[1]);
+        net = rfl(TB[2]);
+        nfree = rfl(TB[3]);
+        n_pw = rfl(TB[4]);
+        n_pe = rfl(TB[5]);
+        nslots = rfl(TB[6]);
+        PW = PE + n_pe;
+        G = At + nslots;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const uint32_t j = (uint32_t)(hl + RS * q);
+            my_vi[q] = j < nfree ? (uint32_t)fidx[j] : 0u;
+            dslot[q] = (uint32_t)reinterpret_cast<const uint8_t*>(LT)[(uint32_t)(N * q) + j];
+        }
+        phase = GP_NEXT;
+        fresh = false;
+        held = 0;
+        lad_rank = 0;
+        lad_width = 1;
+        lad_lead = myrow;
+        lad_members = (uint32_t)myrow * 0x55u;
+        qdone = false;
+        last_tk = 0;
+    }
     for (;;) {
         // near the end of the queue a wavefront that holds a straggler stops taking Systems (fx_grouped.hip)
         bool park = false;
         if (prm.ladder && prm.ladder_tail != 0u) {
             const bool straggler = __ballot(phase == GP_RUN && lad_rank == 0 && !fresh && trials >= prm.ladder_k) != 0ull;
             if (phase == GP_EXIT && !qdone && !straggler) phase = GP_NEXT;
-            park = straggler && last_tk < b.n_systems && b.n_systems - last_tk <= prm.ladder_tail;
+            park = straggler && last_tk < qn && qn - last_tk <= prm.ladder_tail;
         }
         // ================= NEXT: take a System, scale and perturb it (assemble/mod.rs:32-44, 91-111) =================
         if (phase == GP_NEXT && park) phase = GP_EXIT;
         if (phase == GP_NEXT) {
             uint32_t tk = 0;
             if (hl == 0) {
-                tk = atomicAdd(next_system, 1u);
+                tk = atomicAdd(qhead, 1u);
                 last_tk = tk;
-                if (b.order && tk < b.n_systems) {
+                if (tk >= qn) {
+                    tk = 0xFFFFFFFFu;  // the queue is empty (a list — a schedule, or the members of a structure class — may hold
+                                       // System numbers beyond the queue's length)
+                } else if (qlist) {
                     uint32_t pos = tk;
                     if (tk < 4u * prm.spread) pos = (tk & 3u) * prm.spread + (tk >> 2);
-                    tk = b.order[pos];
+                    tk = qlist[pos];
                 }
             }
             const uint32_t nxt = (uint32_t)__shfl((int)tk, 0, RS);
             last_tk = (uint32_t)__shfl((int)last_tk, 0, RS);
-            if (nxt >= b.n_systems) {
+            if (nxt == 0xFFFFFFFFu) {
                 phase = GP_EXIT;
                 qdone = true;
             } else {
                 s = nxt;
-                const uint32_t v0 = s * nvt, e0 = s * net;
+                // (a launch over ONE structure class of a batch of several — b.uniform == 0 — reads the System's offsets)
+                const uint32_t v0 = b.uniform ? s * nvt : b.var_off[s], e0 = b.uniform ? s * net : b.expr_off[s];
                 double c_var[NC], c_param[NC];
                 int tagk[NC], colk[NC];
 #pragma unroll
@@ -545,9 +603,10 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
             if (assemble) {
                 if (win_row != myrow) {  // the accepted point's Jacobian rows and residuals are another row's
                     const unsigned char* wb = rows0 + (uint32_t)win_row * L.stride;
-                    const uint4* gs = reinterpret_cast<const uint4*>(wb + L.off_g);
+                    const uint32_t off_g = BK::A + nslots * (uint32_t)sizeof(T);
+                    const uint4* gs = reinterpret_cast<const uint4*>(wb + off_g);
                     uint4* gd = reinterpret_cast<uint4*>(G);
-                    const uint32_t ng2 = (L.stride - L.off_g) / 16u;
+                    const uint32_t ng2 = (L.stride - off_g) / 16u;
                     for (uint32_t i = hl; i < ng2; i += RS) gd[i] = gs[i];
                     const T* rs = reinterpret_cast<const T*>(wb + BK::R);
 #pragma unroll
@@ -594,7 +653,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         // ================= FINISH: write back scale * x (assemble/mod.rs:161-166), the closing check
         // (constraints/mod.rs:96-109), the result record =================
         if (finish_now) {
-            const uint32_t v0 = s * nvt, e0 = s * net;
+            const uint32_t v0 = b.uniform ? s * nvt : b.var_off[s], e0 = b.uniform ? s * net : b.expr_off[s];
             double c_param[NC];  // the unscaled parameters of expressions hl, hl + 16
 #pragma unroll
             for (int k = 0; k < NC; ++k) c_param[k] = (uint32_t)(RS * k + hl) < net ? b.expr_param[e0 + (uint32_t)(RS * k + hl)] : 0.0;
@@ -644,6 +703,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
 
         if (__ballot(phase != GP_EXIT || (prm.ladder && !qdone)) == 0ull) break;
     }
+    }  // the next class's queue
 }
 
 // 16 free variables and fewer (the reference's bench sketches of one to three triangles): one column per lane, four wavefronts
@@ -687,7 +747,7 @@ size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t es) {
 
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
     if (!p.grouped_one_structure) return false;  // (a context created under FIKSI_AMD_GROUPED_C=0: A / B measurements, tests)
-    if (!b.gc_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
+    if (!b.gc_tab || !(b.uniform ? b.u_ncomp == 1u : b.gc_nclasses != 0u) || !b.work_counter || b.has_pose) return false;
     if (p.prof || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
     const bool f32 = p.lm.precision == 32;
     if (f32 && b.gc_nc != 2u) return false;  // (f32: the 32-column instantiation only)
@@ -710,7 +770,7 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
                    : b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
                                    : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
+    e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t) * (b.gc_nclasses ? b.gc_nclasses : 1u), stream);  // the queue heads
     if (e != hipSuccess) return e;
     uint32_t waves = (b.n_systems + 3u) / 4u;
     if (waves > 256u * 16u) waves = 256u * 16u;
@@ -723,8 +783,8 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
         const uint32_t by_simd = b.gc_nc == 1u ? 16u : b.gc_nc == 2u ? 8u : 4u;
         uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
         if (resident > waves) resident = waves;
-        if (b.order && p.spread) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
-        if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
+        if (b.order && p.spread && !b.gc_nclasses) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
+        if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident / (b.gc_nclasses ? b.gc_nclasses : 1u);
     }
     if (f32) hipLaunchKernelGGL(lm_solve_grouped_c_f32_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     else if (b.gc_nc == 1u) hipLaunchKernelGGL(lm_solve_grouped_c1_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);

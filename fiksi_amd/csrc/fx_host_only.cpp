@@ -15,6 +15,7 @@ hipError_t launch_solve_wide_qr(const DeviceBatch&, const LmParams&, hipStream_t
 size_t wide_qr_lds_bytes(uint32_t, uint32_t, uint32_t, uint32_t) { return 0; }
 bool grouped_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_solve_grouped_general(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t grouped_lds_bytes(const DeviceBatch&, uint32_t, bool) { return 0; }
 bool grouped_c_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped_c(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
@@ -25,6 +26,7 @@ hipError_t launch_solve_walk(const DeviceBatch&, const LmParams&, hipStream_t) {
 size_t presort_temp_bytes(uint32_t) { return 0; }
 hipError_t launch_pull(void*, const void*, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_presort(const DeviceBatch&, float*, uint32_t*, void*, size_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_presort_lists(const DeviceBatch&, float*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_prepare(const DeviceBatch&, uint32_t, double*, double*, double*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_unscale(double, const double*, const uint8_t*, double*, uint32_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_unscale_strided(const double*, uint32_t, uint32_t, const double*, const uint8_t*, double*, hipStream_t) { return hipErrorNoDevice; }

@@ -71,15 +71,17 @@ __global__ __launch_bounds__(256) void presort_scout_kernel(DeviceBatch b, float
 // in front of its own — and writes the entry of rank i to position i * nc + c of the order. Keys are non-negative floats, so
 // their bit patterns order like the numbers: an entry is the 64-bit word (key bits << 32 | 511 - index), unique per entry, and
 // "in front of" is one unsigned compare (two entries per 16-byte LDS read, which every lane reads from the same address).
+// (`list`: the n Systems to order are list[0 .. n) — the members of one structure class — instead of 0 .. n)
 __global__ __launch_bounds__(PS_CHUNK) void presort_chunk_kernel(uint32_t n, uint32_t nc, const float* __restrict__ keys,
-                                                                 uint32_t* __restrict__ order) {
+                                                                 uint32_t* __restrict__ order, const uint32_t* __restrict__ list) {
     __shared__ ulonglong2 k2[PS_CHUNK / 2];
     unsigned long long* k = reinterpret_cast<unsigned long long*>(k2);
     const uint32_t t = threadIdx.x, c = blockIdx.x;
-    const uint32_t s = c + t * nc;
+    const uint32_t e = c + t * nc;
+    const uint32_t s = e < n ? (list ? list[e] : e) : 0xFFFFFFFFu;
     // (the padding: zero — nothing is behind it, and no real entry counts it: a real entry's low word is >= 0 and ties cannot
     // be in front)
-    const unsigned long long mine = s < n ? ((unsigned long long)__float_as_uint(keys[s]) << 32) | (unsigned long long)(PS_CHUNK - 1u - t) : 0ull;
+    const unsigned long long mine = e < n ? ((unsigned long long)__float_as_uint(keys[s]) << 32) | (unsigned long long)(PS_CHUNK - 1u - t) : 0ull;
     k[t] = mine;
     __syncthreads();
     uint32_t rank = 0;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(PS_CHUNK) void presort_chunk_kernel(uint32_t n, uin
         rank += v.x > mine ? 1u : 0u;
         rank += v.y > mine ? 1u : 0u;
     }
-    if (s < n) order[rank * nc + c] = s;
+    if (e < n) order[rank * nc + c] = s;
 }
 
 size_t presort_temp_bytes(uint32_t) { return 16; }
@@ -100,7 +102,21 @@ hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void
     if (n == 0) return hipSuccess;
     const uint32_t nc = (n + PS_CHUNK - 1u) / PS_CHUNK;
     hipLaunchKernelGGL(presort_scout_kernel, dim3((n * 16u + 255u) / 256u), dim3(256), 0, stream, b, keys);
-    hipLaunchKernelGGL(presort_chunk_kernel, dim3(nc), dim3(PS_CHUNK), 0, stream, n, nc, keys, ids + n);
+    hipLaunchKernelGGL(presort_chunk_kernel, dim3(nc), dim3(PS_CHUNK), 0, stream, n, nc, keys, ids + n, (const uint32_t*)nullptr);
+    return hipGetLastError();
+}
+
+// the same for parts of the batch: the scout pass over all of it, then list i of `lists` (its Systems at lists + offs[i], counts[i]
+// of them) ranked on its own into out + offs[i]
+hipError_t launch_presort_lists(const DeviceBatch& b, float* keys, const uint32_t* lists, const uint32_t* offs, const uint32_t* counts, uint32_t n_lists,
+                                uint32_t* out, hipStream_t stream) {
+    if (b.n_systems == 0) return hipSuccess;
+    hipLaunchKernelGGL(presort_scout_kernel, dim3((b.n_systems * 16u + 255u) / 256u), dim3(256), 0, stream, b, keys);
+    for (uint32_t i = 0; i < n_lists; ++i) {
+        if (!counts[i]) continue;
+        const uint32_t nc = (counts[i] + PS_CHUNK - 1u) / PS_CHUNK;
+        hipLaunchKernelGGL(presort_chunk_kernel, dim3(nc), dim3(PS_CHUNK), 0, stream, counts[i], nc, keys, out + offs[i], lists + offs[i]);
+    }
     return hipGetLastError();
 }
 

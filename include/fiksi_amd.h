@@ -336,7 +336,8 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
  * (fx_grouped_c.hip: the structure's lists shared by a wavefront's four Systems, Jt J by its pattern, two wavefronts per
  * SIMD for that shape; same bits), 2 = the sparse build for batches of one structure with a component of 49 ... 128 free
  * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS).
- * A context created under FIKSI_AMD_GROUPED_C=0 takes neither 1 nor 2. Launches nothing. */
+ * 3 = a batch of SEVERAL structures whose big structure classes (2 048 Systems and more, up to eight) run build 1 in one launch,
+ * everyone else the general build. A context created under FIKSI_AMD_GROUPED_C=0 takes none of 1, 2, 3. Launches nothing. */
 int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */

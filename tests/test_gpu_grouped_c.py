@@ -71,7 +71,7 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
     for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "ring16_f32",
                  "ring16_inconsistent_f32", "hinged_5_f32", "hinged_1", "hinged_3", "hinged_4", "hinged_5", "hinged_7", "ring20_chords", "ring23_chords"):
         assert taken[name] == 1, taken
-    # not of one structure: the general build; f32 has the 32-column instantiation only
+    # not of one structure, and no class of 2 048 Systems: the general build; f32 has the 32-column instantiation only
     db = ctx.upload(workloads.ring16_two_structures(2000))
     assert db.grouped_build() == 0
     db.free()
@@ -126,3 +126,36 @@ def test_resident_batch_solved_again_and_in_chunks(fiksi, ctx, ctx_general):
     v2, r2 = ctx.system_solve_batch(b)  # (a big host batch goes up and is solved in two chunks)
     assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
     assert np.array_equal(_bits(v2), _bits(v0)) and r2.tobytes() == r0.tobytes()
+
+
+def test_batches_of_several_structures_run_their_big_classes_on_this_build(fiksi, ctx, ctx_general):
+    """A few sketches, many parameter sets each: every structure class of 2 048 Systems and more gets a program, and ONE launch
+    works through all of them (a wavefront loads the next class's program when its own class's queue is empty); the Systems of
+    small classes take the general build. Every bit as in the general build alone — resident, through the host-buffer call, with
+    and without the longest-first order within the classes, with the ladder off / everywhere."""
+    from fiksi_amd import workloads
+
+    from helpers import mixed_sketch
+
+    cases = [workloads.ring16_two_structures(6000),
+             workloads.concat([workloads.ring16(2500), workloads.hinged_triangles(3000, 5), workloads.ring16(2100, fix_gauge=True),
+                               workloads.hinged_triangles(700, 3), workloads.hinged_triangles(2048, 7),
+                               workloads.concat([mixed_sketch(s).flatten() for s in range(40)])])]
+    try:
+        for b in cases:
+            v0, r0 = ctx_general.system_solve_batch(b)
+            for ladder in ((True, 0xFFFFFFFF, 8, True), (False, 0, 16, False), (True, 1 << 30, 0, True)):
+                ctx.set_ladder(*ladder)
+                for presort in (True, False):
+                    ctx.set_presort(presort, 1)
+                    v1, r1 = ctx.system_solve_batch(b)
+                    assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes(), (ladder, presort)
+                    db = ctx.upload(b)
+                    assert db.grouped_build() == 3
+                    db.system_solve()
+                    db.system_solve()
+                    assert np.array_equal(_bits(db.get_vars()), _bits(v0)) and db.get_results().tobytes() == r0.tobytes(), (ladder, presort)
+                    db.free()
+    finally:
+        ctx.set_ladder()
+        ctx.set_presort(True, 8192)

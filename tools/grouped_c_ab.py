@@ -1,5 +1,6 @@
 """A / B of the grouped kernel's one-structure build (fx_grouped_c.hip) against the general build on the same resident
-batch: time per solve and a digest of every result record and solved variable (the two must agree bit for bit).
+batch — batches of one structure, and batches of a few structures (a launch over their structure classes): time per solve and a
+digest of every result record and solved variable (the two must agree bit for bit).
     python3 tools/grouped_c_ab.py [n_systems] [reps]          # both builds, one child process each (FIKSI_AMD_GROUPED_C=0 / 1)"""
 import hashlib
 import json
@@ -19,7 +20,11 @@ def one(n, reps):
     for name, b in (("ring16", workloads.ring16(n)), ("ring16_fixed_gauge", workloads.ring16(n // 4, fix_gauge=True)),
                     ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("ring20_chords", workloads.ring_chords(n, 20, 7)),
                     ("hinged_5", workloads.hinged_triangles(n, 5)), ("hinged_1", workloads.hinged_triangles(n, 1)),
-                    ("hinged_3", workloads.hinged_triangles(n, 3)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True))):
+                    ("hinged_3", workloads.hinged_triangles(n, 3)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True)),
+                    # batches of SEVERAL structures: one launch over their big structure classes (+ the general build for the rest)
+                    ("two_structures", workloads.ring16_two_structures(n)),
+                    ("three_classes_and_a_small_one", workloads.concat([workloads.ring16(3 * n // 10), workloads.hinged_triangles(3 * n // 10, 5),
+                                                                         workloads.ring16(4 * n // 10, fix_gauge=True), workloads.hinged_triangles(700, 3)]))):
         db = ctx.upload(b)
         o = abi.solving_opts(f32=name.endswith("_f32"))
         db.system_solve(o)
