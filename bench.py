@@ -565,6 +565,16 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
     out["cfg5_share_f64_same_batch"] = {"systems": 125_000, "dtype": "f64", "ms_per_step": ms64, "lm_trials": int(res["trials"].sum()),
                                         "settled_fraction": int(np.count_nonzero(res["exit"] <= 2)) / 125_000}
     db.free()
+    # the headline's sketches in two structures, interleaved (a batch of a few sketches with many parameter sets each): the big
+    # structure classes in one launch of the one-structure build
+    b2 = workloads.ring16_two_structures(n_sys)
+    db = ctx.upload(b2)
+    ms2 = _time_solves(ctx, db, abi.solving_opts())
+    res = db.get_results()
+    conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+    out["ring16_two_structures"] = {"systems": n_sys, "ms_per_step": ms2, "converged_systems_per_sec": conv / (ms2 * 1e-3),
+                                    "converged_fraction": conv / n_sys, "grouped_build": db.grouped_build()}
+    db.free()
     return out
 
 

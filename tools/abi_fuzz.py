@@ -11,7 +11,8 @@ so that the device entry points run their host analysis and their uploads under 
 Targets: fx_batch_validate, fx_jacobian_structure, fx_single_pass_blocks (round 2); fx_qr_symbolic on corrupted column
 patterns, fxs_recursive_plan on random sketches with odd budgets / capacities, and — through the make-believe device —
 fx_batch_upload, fx_system_solve_batch, fx_system_prepare_batch, fx_system_solve_batch_multi, fx_cluster_solve_batch,
-fx_pose_transform_points, fx_unscale_vars_strided (round 4). tests/test_host_sanitizers.py runs it with a fixed seed."""
+fx_pose_transform_points, fx_unscale_vars_strided; batches big enough for the structure classes and the one-structure programs
+of the grouped kernel's builds (build_gc_program, build_gs_program, the class lists) (round 4). tests/test_host_sanitizers.py runs it with a fixed seed."""
 import ctypes as C
 import os
 import sys
@@ -154,6 +155,29 @@ for it in range(n_iter):
         ns, nvs = int(g.u(0, 5.99)), int(g.u(0, 9.99))
         sc, sv, mk, vv = np.ones(max(ns, 1)), np.zeros(max(ns * nvs, 1)), np.ones(max(nvs, 1), dtype=np.uint8), np.zeros(max(ns * nvs, 1))
         note("fx_unscale_vars_strided", lib.fx_unscale_vars_strided(ctxs[0], ptr(sc), ns, nvs, ptr(sv), ptr(mk), ptr(vv)))
+
+# ---------------- batches big enough for the structure-class analysis and the one-structure programs (round 4) ----------------
+if ctxs:
+    for it in range(3):
+        parts = [workloads.ring16(2100 + 7 * it), workloads.hinged_triangles(2060, 5), workloads.ring16(900, fix_gauge=True),
+                 workloads.hinged_triangles(40, 16), workloads.hinged_triangles(300, 11)]
+        for b in (workloads.concat(parts[:3]), workloads.concat(parts), workloads.hinged_triangles(64, 16), workloads.hinged_triangles(40, 11),
+                  workloads.ring_chords(33, 20, 7)):
+            b = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+            mutate(b, it)  # (the first round: the valid batch)
+            try:
+                a = abi.normalize_batch(b)
+            except Exception as e:
+                note("python", type(e).__name__)
+                continue
+            st = abi.as_struct(a)
+            db = C.c_void_p()
+            rc = lib.fx_batch_upload(ctxs[0], C.byref(st), C.byref(db))
+            note("fx_batch_upload (classes / programs)", rc)
+            if rc == 0:
+                o = abi.solving_opts()
+                note("fx_system_solve_device (classes / programs)", lib.fx_system_solve_device(ctxs[0], db, C.byref(o)))
+                lib.fx_batch_free(ctxs[0], db)
 
 for h in ctxs:
     lib.fx_ctx_destroy(h)
