@@ -56,18 +56,20 @@ static GsLayout make_gs_layout(const DeviceBatch& b) {
 
 __device__ __forceinline__ uint32_t rfl_s(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-__global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, LmParams prm, GsLayout L, uint32_t* __restrict__ next_system) {
+// A workgroup is several wavefronts that share ONE copy of the program (the program is a fifth of a wavefront's LDS for the
+// 66-variable sketch: five wavefronts per CU instead of four); after the copy they never meet again.
+__global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b, LmParams prm, GsLayout L, uint32_t* __restrict__ next_system) {
     using T = double;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
-    const int myrow = lane / RS;
+    const int myrow = (int)(threadIdx.x / RS);  // the row's place in the workgroup (a wavefront's four rows are neighbours)
     {
         const uint4* src = reinterpret_cast<const uint4*>(b.gs_tab);
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = lane; i < b.gs_words / 4u; i += 64) dst[i] = src[i];
-        group_sync();
+        for (uint32_t i = threadIdx.x; i < b.gs_words / 4u; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
     }
     const uint32_t* TB = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t nvt = rfl_s(TB[1]), net = rfl_s(TB[2]), nfree = rfl_s(TB[3]), n_pw = rfl_s(TB[4]), n_pe = rfl_s(TB[5]), nl = rfl_s(TB[6]);
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
 
     unsigned char* const rows0 = smem + L.tab_bytes;
     unsigned char* base = rows0 + (uint32_t)myrow * L.stride;
+    unsigned char* const wrows0 = rows0 + (uint32_t)(threadIdx.x >> 6) * 4u * L.stride;  // the blocks of this wavefront's four rows
     T* XS = reinterpret_cast<T*>(base);               // [nvt] working variables: the trial point on the free ones
     T* XC = reinterpret_cast<T*>(base + L.off_xc);    // [nfree] the current point
     T* RHS = reinterpret_cast<T*>(base + L.off_rhs);  // [nfree] -Jt r of the current point
@@ -113,8 +116,9 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
     uint32_t accepted = 0, trials = 0, outer = 0, exit_code = FX_EXIT_MAX_OUTER;
     bool fresh = false;
     uint32_t held = 0;
-    int lad_rank = 0, lad_width = 1, lad_lead = myrow;
-    uint32_t lad_members = (uint32_t)myrow * 0x55u;
+    const int wrow = lane / RS;  // the row's place in its wavefront (the ladder's rows are a wavefront's)
+    int lad_rank = 0, lad_width = 1, lad_lead = wrow;
+    uint32_t lad_members = (uint32_t)wrow * 0x55u;
     bool qdone = false;
     uint32_t last_tk = 0;
 
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
                     }
                 }
                 if (anyjoin) {
-                    const uint32_t nl_ = (newlead >> (4 * myrow)) & 15u;
+                    const uint32_t nl_ = (newlead >> (4 * wrow)) & 15u;
                     const bool joining = nl_ != 15u;
                     const int grp = joining ? (int)nl_ : lad_lead;
                     const int srcl = grp * RS + hl;
@@ -375,8 +379,8 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
                     lad_members = (mem >> (8 * grp)) & 255u;
                     if (joining) {
                         lad_lead = (int)nl_;
-                        lad_rank = (int)((newrank >> (4 * myrow)) & 15u);
-                        const uint4* lb = reinterpret_cast<const uint4*>(rows0 + nl_ * L.stride);
+                        lad_rank = (int)((newrank >> (4 * wrow)) & 15u);
+                        const uint4* lb = reinterpret_cast<const uint4*>(wrows0 + nl_ * L.stride);
                         uint4* mine = reinterpret_cast<uint4*>(base);
                         for (uint32_t i = hl; i < L.stride / 16u; i += RS) mine[i] = lb[i];
                         fresh = false;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
             int kw = (code != LC_REJECT) ? 0 : 1;
             int code_w = code;
             T sse_w = sse_t;
-            int win_row = myrow;
+            int win_row = wrow;
             if (__ballot(lad_width > 1) != 0ull) {
                 int ck[4];
 #pragma unroll
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
                         lambda *= o.accept_factor;
                         if (lambda < o.lambda_min) lambda = o.lambda_min;
                         // the accepted step is the winning row's: its D
-                        const T* dw = reinterpret_cast<const T*>(rows0 + (uint32_t)win_row * L.stride + L.off_d);
+                        const T* dw = reinterpret_cast<const T*>(wrows0 + (uint32_t)win_row * L.stride + L.off_d);
                         for (uint32_t c = hl; c < nfree; c += RS) {
                             const T x = XC[c] + dw[c];
                             XC[c] = x;
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
                 if (lad_rank > 0) phase = GP_EXIT;
                 lad_rank = 0;
                 lad_width = 1;
-                lad_lead = myrow;
-                lad_members = (uint32_t)myrow * 0x55u;
+                lad_lead = wrow;
+                lad_members = (uint32_t)wrow * 0x55u;
             }
         }
 
@@ -596,40 +600,44 @@ __global__ __launch_bounds__(64) void lm_solve_grouped_s_kernel(DeviceBatch b, L
 // ------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------
+// wavefronts of a workgroup: as many as fit a CU's LDS beside one copy of the program (at most 16)
+static uint32_t gs_waves_per_group(const GsLayout& L) {
+    const uint32_t room = 160u * 1024u - L.tab_bytes, per_wave = 4u * L.stride;
+    uint32_t k = per_wave ? room / per_wave : 1u;
+    return k < 1u ? 1u : k > 16u ? 16u : k;
+}
+
 bool grouped_s_applies(const DeviceBatch& b, const LmParams& p) {
     if (!p.grouped_one_structure || p.route_grouped == 0) return false;
     if (!b.gs_tab || !b.uniform || b.u_ncomp != 1u || !b.work_counter || b.has_pose) return false;
     if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
     if (p.prof || p.lm.precision == 32 || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
     const GsLayout L = make_gs_layout(b);
-    return (size_t)L.tab_bytes + 4u * (size_t)L.stride <= (160u * 1024u) / 2u;  // two wavefronts per CU at least
+    return (size_t)L.tab_bytes + 8u * (size_t)L.stride <= 160u * 1024u;  // two wavefronts per CU at least
 }
 
 hipError_t launch_solve_grouped_s(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     const GsLayout L = make_gs_layout(b);
-    const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
+    const uint32_t k = gs_waves_per_group(L);
+    const uint32_t per_group = L.tab_bytes + k * 4u * L.stride;
     static const bool trace = getenv("FIKSI_AMD_TRACE") != nullptr;
     if (trace)
-        fprintf(stderr, "[fiksi_amd] grouped kernel, sparse one-structure build: %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of the factor, %u Jacobian entries)\n",
-                per_wave, L.tab_bytes, L.stride, b.gs_nl, b.gs_ng);
+        fprintf(stderr, "[fiksi_amd] grouped kernel, sparse one-structure build: workgroups of %u wavefronts, %u B of LDS each (program %u, 4 x %u per wavefront: %u slots of the factor, %u Jacobian entries)\n",
+                k, per_group, L.tab_bytes, L.stride, b.gs_nl, b.gs_ng);
     static unsigned int raised = 0;
     hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_s_kernel), &raised);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     uint32_t waves = (b.n_systems + 3u) / 4u;
-    if (waves > 256u * 16u) waves = 256u * 16u;
+    uint32_t groups = (waves + k - 1u) / k;
+    if (groups > (uint32_t)cus) groups = (uint32_t)cus;  // one workgroup per CU: every wavefront stays until the queue is empty
     LmParams pl = p;
     pl.spread = 0u;
-    if (p.ladder) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const uint32_t by_lds = (160u * 1024u) / per_wave;
-        uint32_t resident = (uint32_t)cus * (by_lds < 16u ? by_lds : 16u);
-        if (resident > waves) resident = waves;
-        if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident;
-    }
-    hipLaunchKernelGGL(lm_solve_grouped_s_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    if (p.ladder && p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * groups * k;
+    hipLaunchKernelGGL(lm_solve_grouped_s_kernel, dim3(groups), dim3(64u * k), per_group, stream, b, pl, L, b.work_counter);
     return hipGetLastError();
 }
 
