@@ -7,10 +7,10 @@
 // Same algorithm as the other LM kernels (reference: fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193; the step is
 // the normal-equation step of fx_grouped.hip), everything a walk over the tables of the batch's one PROGRAM (fx_abi.cpp:
 // build_gs_program), copied into LDS once per wavefront and shared by its four Systems:
-//   * a System lives in LDS entirely — working point, current point, right-hand side, step, the factor's slots, compact Jacobian
-//     rows, residuals, parameters (6.7 KB for the 66-variable sketch) — and a lane holds a handful of scalars;
-//   * a trial: zero the factor's slots, add the products of Jt J into them (the product list names slots; ds_add_f64), lambda on
-//     the diagonal, factor in place LEVEL by level of the elimination tree (the columns of a level are independent: a lane takes a
+//   * a System lives in LDS entirely — working point, current point, step, the factor's slots, compact Jacobian rows, residuals,
+//     parameters (6.2 KB for the 66-variable sketch) — and a lane holds a handful of scalars;
+//   * a trial: zero the factor's slots, add the products of Jt J into them (the product list names slots; ds_add_f64) and -Jt r
+//     into the step vector, lambda on the diagonal, factor in place LEVEL by level of the elimination tree (the columns of a level are independent: a lane takes a
 //     column, scales it by 1 / sqrt(pivot) — the diagonal slot keeps that reciprocal —, then the level's update triples
 //     L(i, j) -= L(i, k) L(j, k) go sixteen at a time), forward substitution by levels (entries of a level's columns, atomically
 //     into the vector), backward substitution by levels (a lane gathers its column);
@@ -33,7 +33,7 @@ namespace fx {
 
 // a System's block, bytes (all arrays of doubles; VOUT — the unscaled values of the closing check — lies over the factor's slots)
 struct GsLayout {
-    uint32_t tab_bytes, off_xc, off_rhs, off_d, off_r, off_p, off_l, off_g, stride;
+    uint32_t tab_bytes, off_xc, off_d, off_r, off_p, off_l, off_g, stride;
 };
 
 static GsLayout make_gs_layout(const DeviceBatch& b) {
@@ -44,7 +44,6 @@ static GsLayout make_gs_layout(const DeviceBatch& b) {
     auto take = [&](uint32_t doubles) { uint32_t at = o; o += doubles * 8u; return at; };
     L.tab_bytes = (b.gs_words * 4u + 15u) & ~15u;
     L.off_xc = take(n);
-    L.off_rhs = take(n);
     L.off_d = take(n);
     L.off_r = take(m);
     L.off_p = take(m);
@@ -97,8 +96,7 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
     unsigned char* const wrows0 = rows0 + (uint32_t)(threadIdx.x >> 6) * 4u * L.stride;  // the blocks of this wavefront's four rows
     T* XS = reinterpret_cast<T*>(base);               // [nvt] working variables: the trial point on the free ones
     T* XC = reinterpret_cast<T*>(base + L.off_xc);    // [nfree] the current point
-    T* RHS = reinterpret_cast<T*>(base + L.off_rhs);  // [nfree] -Jt r of the current point
-    T* D = reinterpret_cast<T*>(base + L.off_d);      // [nfree] the step (right-hand side -> y -> delta, in place)
+    T* D = reinterpret_cast<T*>(base + L.off_d);      // [nfree] the step (-Jt r -> y -> delta, in place)
     T* R = reinterpret_cast<T*>(base + L.off_r);      // [net]
     T* P = reinterpret_cast<T*>(base + L.off_p);      // [net] scaled parameters
     T* Lv = reinterpret_cast<T*>(base + L.off_l);     // the factor's slots (diagonal slots: 1 / L_kk)
@@ -151,10 +149,9 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
         group_sync();
         return row_sum(part);
     };
-    // -Jt r of the point whose rows are in G / R
+    // -Jt r of the point whose rows are in G / R, into D (every trial anew: a copy of it kept per System would cost a wavefront
+    // per CU for most shapes — LDS is what bounds this build)
     auto form_rhs = [&]() {
-        for (uint32_t c = hl; c < nfree; c += RS) RHS[c] = T(0);
-        group_sync();
         for (uint32_t t0 = 0; t0 < n_pe; t0 += RS * 4u) {
             uint32_t w[4];
             T g1[4], rr[4];
@@ -168,9 +165,8 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (w[u] != 0xFFFFFFFFu) lds_add(&RHS[w[u] >> 20], g1[u] * rr[u]);
+                if (w[u] != 0xFFFFFFFFu) lds_add(&D[w[u] >> 20], g1[u] * rr[u]);
         }
-        group_sync();
     };
     // (Jt J + lam I) delta = -Jt r: assembled into the factor's slots, factored and solved level by level; D = delta.
     // Returns false when a pivot is not positive and finite (lm.rs:134-137).
@@ -180,7 +176,9 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
             z.x = z.y = 0.0;
             for (uint32_t i = hl; i < nl / 2u; i += RS) reinterpret_cast<double2*>(Lv)[i] = z;
         }
+        for (uint32_t c = hl; c < nfree; c += RS) D[c] = T(0);
         group_sync();
+        form_rhs();
         for (uint32_t t0 = 0; t0 < n_pw; t0 += RS * 4u) {
             uint32_t w[4];
             T g1[4], g2[4];
@@ -197,10 +195,7 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
                 if (w[u] != 0xFFFFFFFFu) lds_add(&Lv[w[u] >> 20], g1[u] * g2[u]);
         }
         group_sync();
-        for (uint32_t c = hl; c < nfree; c += RS) {
-            Lv[dslot[c]] += lam;
-            D[c] = RHS[c];
-        }
+        for (uint32_t c = hl; c < nfree; c += RS) Lv[dslot[c]] += lam;
         group_sync();
         bool bad = false;
         for (uint32_t lv = 0; lv < nlev; ++lv) {
@@ -516,7 +511,6 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
                 }
             }
             if (assemble) {
-                form_rhs();
                 // top of the next outer iteration (lm.rs:108-112)
                 if (fresh && (!(sse == sse) || !(sse < Lim<T>::huge()))) {
                     exit_code = FX_EXIT_NAN;
