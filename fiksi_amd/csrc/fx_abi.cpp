@@ -1424,7 +1424,9 @@ static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, 
             gvar[(size_t)r * 8 + e] = (uint8_t)vars8[e];
             gcol[(size_t)r * 8 + e] = e < k ? (int)vcol[vars8[e]] : -1;
         }
-        ng += (uint32_t)k;
+        // (a distance row keeps TWO of its four entries: the other two are their exact negatives — expressions.rs:291-317 —,
+        // and the lists below carry the sign)
+        ng += tag == FX_TAG_PPD ? 2u : (uint32_t)k;
         for (int a = 0; a < k; ++a)
             for (int bb = 0; bb < k; ++bb)
                 if (gcol[(size_t)r * 8 + a] >= 0 && gcol[(size_t)r * 8 + bb] >= 0)
@@ -1521,20 +1523,24 @@ static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, 
     }
     // products of Jt J into the factor's slots, right-hand side entries (the order of fx_grouped_c.hip's lists)
     std::vector<uint32_t> pw, pe;
-    for (uint32_t r = 0; r < net; ++r)
+    for (uint32_t r = 0; r < net; ++r) {
+        const bool ppd = rtag[r] == FX_TAG_PPD;
+        auto gent = [&](int e) -> uint32_t { return gbase[r] + (uint32_t)(ppd && e >= 2 ? e - 2 : e); };  // where entry e's value (or its negative) is kept
+        auto gneg = [&](int e) -> uint32_t { return ppd && e >= 2 ? 1u : 0u; };
         for (int a = 0; a < 8; ++a) {
             const int ca = gcol[(size_t)r * 8 + a];
             if (ca < 0) continue;
-            pe.push_back((gbase[r] + (uint32_t)a) | (r << 10) | ((uint32_t)ca << 20));
+            pe.push_back(gent(a) | (r << 10) | ((uint32_t)ca << 20) | (gneg(a) << 31));
             for (int bb = a; bb < 8; ++bb) {
                 const int cb = gcol[(size_t)r * 8 + bb];
                 if (cb < 0) continue;
                 const uint32_t pi = std::max(pos[(uint32_t)ca], pos[(uint32_t)cb]), pk = std::min(pos[(uint32_t)ca], pos[(uint32_t)cb]);
-                const uint32_t w = (gbase[r] + (uint32_t)a) | ((gbase[r] + (uint32_t)bb) << 10) | ((uint32_t)slot[(size_t)pi * n + pk] << 20);
+                const uint32_t w = gent(a) | (gent(bb) << 10) | ((uint32_t)slot[(size_t)pi * n + pk] << 20) | ((gneg(a) ^ gneg(bb)) << 31);
                 pw.push_back(w);
                 if (a != bb && ca == cb) pw.push_back(w);
             }
         }
+    }
     while (pw.size() % 64u) pw.push_back(0xFFFFFFFFu);
     while (pe.size() % 64u) pe.push_back(0xFFFFFFFFu);
     std::vector<uint32_t>& w = out.words;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
             if constexpr (FULL) {
                 R[row] = r;
                 const uint32_t gb = gbaseT[row];
-                const int kk = tag_nvars(tag);
+                const int kk = tag == FX_TAG_PPD ? 2 : tag_nvars(tag);  // (a distance row: its other two entries are the negatives)
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (e < kk) G[gb + (uint32_t)e] = g[e];
@@ -164,8 +164,10 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
                 rr[u] = -R[(ww >> 10) & 0x3FFu];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (w[u] != 0xFFFFFFFFu) lds_add(&D[w[u] >> 20], g1[u] * rr[u]);
+            for (int u = 0; u < 4; ++u) {
+                const T pr = g1[u] * rr[u];
+                if (w[u] != 0xFFFFFFFFu) lds_add(&D[(w[u] >> 20) & 0xFFu], (w[u] >> 31) ? -pr : pr);  // (bit 31: the entry is kept negated)
+            }
         }
     };
     // (Jt J + lam I) delta = -Jt r: assembled into the factor's slots, factored and solved level by level; D = delta.
@@ -191,8 +193,10 @@ __global__ __launch_bounds__(1024) void lm_solve_grouped_s_kernel(DeviceBatch b,
                 g2[u] = G[(ww >> 10) & 0x3FFu];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (w[u] != 0xFFFFFFFFu) lds_add(&Lv[w[u] >> 20], g1[u] * g2[u]);
+            for (int u = 0; u < 4; ++u) {
+                const T pr = g1[u] * g2[u];
+                if (w[u] != 0xFFFFFFFFu) lds_add(&Lv[(w[u] >> 20) & 0x3FFu], (w[u] >> 31) ? -pr : pr);
+            }
         }
         group_sync();
         for (uint32_t c = hl; c < nfree; c += RS) Lv[dslot[c]] += lam;
