@@ -2694,7 +2694,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     // A batch of one structure gets the program of one of the grouped kernel's builds for such batches, when the structure
     // qualifies: the sparse build (fx_grouped_s.hip) for components beyond a register-resident factor — and from 33 free variables
     // on when the factor is sparse (at most a quarter of the dense triangle: the reference's bench sketch of 11 triangles, 46
-    // variables, 201 of 1 081 entries: 1.81 ms per 100 000 against 3.14 in the 48-column register build) —, the register build
+    // variables, 201 of 1 081 entries: 1.52 ms per 100 000 against 3.14 in the 48-column register build) —, the register build
     // (fx_grouped_c.hip) otherwise.
     GsHostProgram gs;
     GcHostProgram gc;

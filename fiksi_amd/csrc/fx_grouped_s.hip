@@ -8,7 +8,7 @@
 // the normal-equation step of fx_grouped.hip), everything a walk over the tables of the batch's one PROGRAM (fx_abi.cpp:
 // build_gs_program), copied into LDS once per wavefront and shared by its four Systems:
 //   * a System lives in LDS entirely — working point, current point, step, the factor's slots, compact Jacobian rows, residuals,
-//     parameters (6.2 KB for the 66-variable sketch) — and a lane holds a handful of scalars;
+//     parameters (5.5 KB for the 66-variable sketch) — and a lane holds a handful of scalars;
 //   * a trial: zero the factor's slots, add the products of Jt J into them (the product list names slots; ds_add_f64) and -Jt r
 //     into the step vector, lambda on the diagonal, factor in place LEVEL by level of the elimination tree (the columns of a level are independent: a lane takes a
 //     column, scales it by 1 / sqrt(pivot) — the diagonal slot keeps that reciprocal —, then the level's update triples
