@@ -1259,7 +1259,7 @@ struct GcHostProgram {
 };
 template <int NC>
 static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
-                               uint32_t nvt, uint32_t net, GcHostProgram& out) {
+                               uint32_t nvt, uint32_t net, GcHostProgram& out) {  // (free variables: 1 ... NV; the caller picks the smallest build)
     using TK = fx::GcTable<NC>;
     constexpr uint32_t NV = TK::NV;
     out = GcHostProgram();
@@ -1277,7 +1277,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
             fidx[nfree++] = (uint8_t)i;
         }
     }
-    if (nfree == 0 || nfree <= NV - 16u || nfree > NV) return false;
+    if (nfree == 0 || nfree > NV) return false;
     int gcol[NV][8];
     uint32_t ng = 0;
     for (uint32_t r = 0; r < net; ++r) {
@@ -1372,9 +1372,11 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
 }
 static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
                              uint32_t nvt, uint32_t net, uint32_t max_free, GcHostProgram& out) {
-    if (max_free > 32u) return build_gc_program_t<3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
-    if (max_free <= 16u) return build_gc_program_t<1>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
-    return build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
+    // the smallest build that holds the structure: its free variables decide, unless its variables (fixed ones included) or its
+    // expressions need the next one's tables — the columns past the free variables are identity padding either way
+    if (max_free <= 16u && build_gc_program_t<1>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    if (max_free <= 32u && build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    return build_gc_program_t<3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
 }
 
 // The program of the grouped kernel's SPARSE build (fx_grouped_s.hip): batches of one structure whose single component is too

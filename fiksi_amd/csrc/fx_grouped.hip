@@ -1535,6 +1535,7 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
     if (p.lm.solver == FX_STEP_QR) return grouped_qr_applies(b, p, nullptr);
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
+    if (b.uniform && grouped_c_applies(b, p)) return true;  // (the one-structure build needs a fraction of the general build's LDS)
     const bool units = (p.mode & MODE_UNITS) != 0;
     if (units && (!b.sys_unit_off || p.prof)) return false;
     if (p.prof && p.lm.precision == 32) return false;

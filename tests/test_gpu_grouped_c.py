@@ -159,3 +159,28 @@ def test_batches_of_several_structures_run_their_big_classes_on_this_build(fiksi
     finally:
         ctx.set_ladder()
         ctx.set_presort(True, 8192)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_structures_against_the_general_build(fiksi, ctx, ctx_general, seed):
+    """Random connected sketches of 4 ... 24 points (distances over a spanning tree and between random pairs, a few angles,
+    sometimes a fixed point): whichever instantiation the structure takes — one, two or three columns per lane —, every bit of
+    the general build. (A 17 ... 24-point structure with a sparse factor goes to the sparse build instead: its own tests.)"""
+    from helpers import Lcg
+    from test_gpu_grouped_s import _random_graph_batch
+
+    g = Lcg(4000 + 7919 * seed)
+    n_pts = (4, 6, 8, 9, 12, 14, 16, 18, 21, 24)[seed]
+    b = _random_graph_batch(300, n_pts, (1, 2, 5, 9, 8, 20, 30, 40, 60, 80)[seed], 500 + seed, fix_first=bool(seed & 1), angles=int(g.u(0, 5.99)))
+    db = ctx.upload(b)
+    build = db.grouped_build()
+    db.free()
+    nv, ne = int(b["var_off"][1]), int(b["expr_off"][1])
+    assert build in (1, 2) or ne > 48 or nv > 48, (build, nv, ne)  # (the tables of the register builds hold 48 expressions)
+    v1, r1 = ctx.system_solve_batch(b)
+    v0, r0 = ctx_general.system_solve_batch(b)
+    if build != 2:
+        assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
+    else:
+        same = (r0["accepted"] == r1["accepted"]) & (r0["trials"] == r1["trials"]) & (r0["exit"] == r1["exit"])
+        assert same.mean() >= 0.9
