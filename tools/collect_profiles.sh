@@ -46,6 +46,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
 python3 tools/pmc_sq_summary.py $OUT/pmc_sq $OUT/${TAG}_pmc_sq.json 100000 "tools/solve_only.py 100000 2" > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/qr_sq -- python3 tools/qr_once.py 100000 2 > $OUT/qr_sq.log 2>&1
 python3 tools/pmc_sq_summary.py $OUT/qr_sq $OUT/${TAG}_qr_pmc_sq.json 100000 "tools/qr_once.py 100000 2" > /dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sparse_sq -- python3 tools/hinged_batch.py 16 20000 2 > $OUT/sparse_sq.log 2>&1
+python3 tools/pmc_sq_summary.py $OUT/sparse_sq $OUT/${TAG}_sparse_pmc_sq.json 20000 "tools/hinged_batch.py 16 20000 2" > /dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/cfg2_sq -- python3 tools/cfg2_resident.py 1 > $OUT/cfg2_sq.log 2>&1
 python3 tools/pmc_sq_summary.py $OUT/cfg2_sq $OUT/${TAG}_cfg2_pmc_sq.json 1 "tools/cfg2_resident.py 1" > /dev/null
 echo "[collect] K1 store policy A / B"
