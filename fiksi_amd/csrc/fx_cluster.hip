@@ -127,6 +127,28 @@ __global__ __launch_bounds__(256) void pull_kernel(uint4* __restrict__ dst, cons
     if (i < n16) dst[i] = src[i];
 }
 
+// dst[i] = dst[i mod period] for period <= i < total: a batch of one structure sends its structure arrays' first System over the
+// bus and fills in the others here (units of four bytes when everything is a multiple of four, of one byte otherwise)
+template <typename U>
+__global__ __launch_bounds__(256) void replicate_kernel(U* __restrict__ dst, uint32_t period, unsigned long long total) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x + period;
+    if (i < total) dst[i] = dst[i % period];
+}
+
+hipError_t launch_replicate(void* dst, size_t period_bytes, size_t total_bytes, hipStream_t stream) {
+    if (period_bytes == 0 || total_bytes <= period_bytes) return hipSuccess;
+    if (period_bytes % 4u == 0 && total_bytes % 4u == 0) {
+        const unsigned long long total = total_bytes / 4u, todo = total - period_bytes / 4u;
+        hipLaunchKernelGGL(replicate_kernel<uint32_t>, dim3((unsigned)((todo + 255ull) / 256ull)), dim3(256), 0, stream, static_cast<uint32_t*>(dst),
+                           (uint32_t)(period_bytes / 4u), total);
+    } else {
+        const unsigned long long todo = total_bytes - period_bytes;
+        hipLaunchKernelGGL(replicate_kernel<uint8_t>, dim3((unsigned)((todo + 255ull) / 256ull)), dim3(256), 0, stream, static_cast<uint8_t*>(dst),
+                           (uint32_t)period_bytes, (unsigned long long)total_bytes);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_pull(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     const uint32_t n16 = (uint32_t)(bytes / 16u);
     if (n16 == 0) return hipSuccess;

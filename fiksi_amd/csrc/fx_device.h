@@ -221,6 +221,7 @@ hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_
 // dst[0 .. bytes) = src[0 .. bytes), 16 bytes per thread (both 16-byte aligned, bytes a multiple of 16): pulls a one-shot
 // batch's image out of host-coherent memory in one burst (fx_cluster.hip)
 hipError_t launch_pull(void* dst, const void* src, size_t bytes, hipStream_t stream);
+hipError_t launch_replicate(void* dst, size_t period_bytes, size_t total_bytes, hipStream_t stream);
 // scout + sort for the longest-first hand-out of the grouped kernel (fx_presort.hip)
 size_t presort_temp_bytes(uint32_t n);
 hipError_t launch_presort(const DeviceBatch& b, float* keys, uint32_t* ids, void* temp, size_t temp_bytes, hipStream_t stream);

@@ -25,6 +25,7 @@ hipError_t launch_solve_grouped_s(const DeviceBatch&, const LmParams&, hipStream
 hipError_t launch_solve_walk(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t presort_temp_bytes(uint32_t) { return 0; }
 hipError_t launch_pull(void*, const void*, size_t, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_replicate(void*, size_t, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_presort(const DeviceBatch&, float*, uint32_t*, void*, size_t, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_presort_lists(const DeviceBatch&, float*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_prepare(const DeviceBatch&, uint32_t, double*, double*, double*, hipStream_t) { return hipErrorNoDevice; }
