@@ -202,3 +202,26 @@ def test_random_structures_against_the_general_paths(fiksi, ctx, seed):
         assert np.array_equal(r0["scale"], r1["scale"]) and np.allclose(r0["sse0"], r1["sse0"], rtol=1e-12, atol=0)
     else:  # not taken: the very same path either way
         assert np.array_equal(_bits(v0), _bits(v1)) and r0.tobytes() == r1.tobytes()
+
+
+def test_without_perturbation_and_through_the_lm_entry_point(fiksi, ctx):
+    """`perturb = False` (no LCG draws) and fx_lm_solve_batch (no scaling, no perturbation: the bare Levenberg-Marquardt of
+    lm.rs on the batch's values) take the sparse build too: the counters of the general paths, positions to round-off."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.hinged_triangles(200, 16)
+    for call in ("system_no_perturb", "lm"):
+        outs = []
+        for enable in (True, False):
+            ctx.set_one_structure_builds(enable)
+            try:
+                if call == "lm":
+                    outs.append(ctx.lm_solve_batch(b))
+                else:
+                    outs.append(ctx.system_solve_batch(b, abi.solving_opts(perturb=False)))
+            finally:
+                ctx.set_one_structure_builds(True)
+        (v1, r1), (v0, r0) = outs
+        for f in ("accepted", "trials", "exit"):
+            assert np.array_equal(r0[f], r1[f]), (call, f)
+        assert np.max(np.abs(v0 - v1)) < 1e-9, call
