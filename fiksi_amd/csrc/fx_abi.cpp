@@ -823,6 +823,7 @@ struct fx_dbatch {
     fx::GcClass* cl_desc = nullptr;    // ... on the device
     uint32_t* cl_words = nullptr;
     uint32_t* cl_lists = nullptr;
+    uint32_t cl_max_words_all = 0;
     uint32_t cl_nc = 0, cl_max_words = 0, cl_max_slots = 0, cl_max_ng = 0, cl_systems = 0;  // the classes' common build, the largest program, their Systems in all
     uint32_t rest_off = 0, rest_count = 0;
     // host copy of the batch, kept only when some System needs the sparse path
@@ -1246,7 +1247,8 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 // the lower triangle (all NV diagonal entries included: the columns past the free variables are identity padding), one slot of
 // zero behind them. Words:
 // [0] version [1] variables [2] expressions [3] free variables [4] products (padded to 64) [5] right-hand-side entries (padded
-// to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [17] words in all;
+// to 64) [6] slots (even, the zero slot included) [7] compact Jacobian entries (even) [8] the zero slot [17] words in all [18] words
+// of the part the f64 builds copy [9 ... 12] byte offsets of the f32 build's gather tables behind it;
 // then, at the byte offsets of fx_device.h's GcTable: vcol (i8 [NV]: variable -> free column, -1 = fixed), fidx (u8 [NV]: free
 // column -> variable), rtag (u8 [NV]), gbase (u16 [NV]: first compact entry of a row), gvar (u8 [NV][8]: the variables a row
 // reads, gradient order), the load table (u8 [16][NC NV]: lane l's element i of column l + 16 q at [l][NV q + i] — the slot of
@@ -1255,7 +1257,7 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 // one column twice — the order fx_grouped.hip builds its lists in, and so the order of the additions).
 struct GcHostProgram {
     std::vector<uint32_t> words;
-    uint32_t nslots = 0, ng = 0, nc = 0;
+    uint32_t nslots = 0, ng = 0, nc = 0, words_f64 = 0;  // (words_f64: the part the f64 builds use)
 };
 template <int NC>
 static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
@@ -1356,6 +1358,30 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
     placed = put(pe.data(), pe.size() * 4u) == TK::PE && placed;
     (void)put(pw.data(), pw.size() * 4u);
     if (!placed) return false;
+    w[18] = (uint32_t)w.size();  // what the f64 builds copy; behind it, for the f32 build:
+    // the same products and right-hand-side entries by TARGET — slot by slot, column by column, each target's in list order — for
+    // an assembly without LDS float atomics (ds_add_f32 costs 192 cycles an instruction on gfx950, ds_add_f64 14:
+    // tools/probes/lds_atomic_f32_probe.hip). u16 each: entry a | entry b << 8; entry | row << 8.
+    {
+        std::vector<std::vector<uint16_t>> by_slot(nslots), by_col(NV);
+        for (uint32_t x : pw)
+            if (x != 0xFFFFFFFFu) by_slot[x >> 16].push_back((uint16_t)(x & 0xFFFFu));
+        for (uint32_t x : pe)
+            if (x != 0xFFFFFFFFu) by_col[x >> 16].push_back((uint16_t)(x & 0xFFFFu));
+        std::vector<uint16_t> sptr(1, 0), spw, cptr(1, 0), cpe;
+        for (auto& v : by_slot) {
+            spw.insert(spw.end(), v.begin(), v.end());
+            sptr.push_back((uint16_t)spw.size());
+        }
+        for (auto& v : by_col) {
+            cpe.insert(cpe.end(), v.begin(), v.end());
+            cptr.push_back((uint16_t)cpe.size());
+        }
+        w[9] = put(sptr.data(), sptr.size() * 2u);
+        w[10] = put(spw.data(), spw.size() * 2u);
+        w[11] = put(cptr.data(), cptr.size() * 2u);
+        w[12] = put(cpe.data(), cpe.size() * 2u);
+    }
     w[0] = 1u;
     w[1] = nvt;
     w[2] = net;
@@ -1368,6 +1394,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
     w[17] = (uint32_t)w.size();
     out.nslots = nslots;
     out.ng = (ng + 3u) & ~3u;
+    out.words_f64 = w[18];
     return true;
 }
 static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
@@ -2069,6 +2096,7 @@ static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& 
     fx::DeviceBatch dc = d;
     dc.gc_tab = db->cl_words;
     dc.gc_words = db->cl_max_words;
+    dc.gc_words_all = db->cl_max_words_all;
     dc.gc_nslots = db->cl_max_slots;
     dc.gc_ng = db->cl_max_ng;
     dc.gc_nc = db->cl_nc;
@@ -2720,7 +2748,8 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
                build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0,
                                 d.u_nvars, d.u_nexprs, p.max_free, gc)) {
         FX_UP(gc_tab, gc.words.data(), gc.words.size())
-        d.gc_words = (uint32_t)gc.words.size();
+        d.gc_words = gc.words_f64;
+        d.gc_words_all = (uint32_t)gc.words.size();
         d.gc_nslots = gc.nslots;
         d.gc_ng = gc.ng;
         d.gc_nc = gc.nc;
@@ -2752,10 +2781,12 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
             if (cp.nc != db->cl_nc) continue;
             fx::GcClass cl;
             cl.prog_off = (uint32_t)cl_words_h.size();
-            cl.words = (uint32_t)cp.words.size();
+            cl.words = cp.words_f64;
+            cl.words_all = (uint32_t)cp.words.size();
             cl.list_off = 0;
             cl.count = pr.first;
             db->cl_max_words = std::max(db->cl_max_words, cl.words);
+            db->cl_max_words_all = std::max(db->cl_max_words_all, cl.words_all);
             db->cl_max_slots = std::max(db->cl_max_slots, cp.nslots);
             db->cl_max_ng = std::max(db->cl_max_ng, cp.ng);
             cl_words_h.insert(cl_words_h.end(), cp.words.begin(), cp.words.end());
@@ -3158,6 +3189,7 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         fx::DeviceBatch dc = db->d;
         dc.gc_tab = db->cl_words;
         dc.gc_words = db->cl_max_words;
+        dc.gc_words_all = db->cl_max_words_all;
         dc.gc_nslots = db->cl_max_slots;
         dc.gc_ng = db->cl_max_ng;
         dc.gc_nc = db->cl_nc;

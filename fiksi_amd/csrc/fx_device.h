@@ -77,7 +77,7 @@ template <int NC> struct GcTable {  // NC columns per lane: Systems of at most N
 // One structure class of a batch of several structures, for a launch of fx_grouped_c.hip over the batch's big classes: its program
 // (words into gc_tab), its members (entries into order)
 struct GcClass {
-    uint32_t prog_off, words, list_off, count;
+    uint32_t prog_off, words, words_all, list_off, count;  // (words: what the f64 builds copy of the program; words_all: the f32 build)
 };
 
 // A batch resident in HBM. All arrays are struct-of-arrays over the concatenated Systems.
@@ -146,7 +146,8 @@ struct DeviceBatch {
     // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_abi.cpp: build_gc_program): null unless the
     // batch is uniform with one component of at most 48 free variables
     uint32_t* gc_tab;
-    uint32_t gc_words, gc_nslots, gc_ng;  // words of the program; slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
+    uint32_t gc_words, gc_nslots, gc_ng;  // words of the program (the f64 builds' part); slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
+    uint32_t gc_words_all;                // ... with the f32 build's gather tables
     uint32_t gc_nc;                       // columns per lane of the build the program is for: 1 (up to 16 free variables), 2 (17 ... 32) or 3 (33 ... 48)
     const GcClass* gc_classes;            // a launch over several structure classes (null: one program, the whole batch)
     uint32_t gc_nclasses;

@@ -42,7 +42,7 @@ struct GcLayout {
 
 static GcLayout make_gc_layout(const DeviceBatch& b, uint32_t es) {
     GcLayout L;
-    L.tab_bytes = (b.gc_words * 4u + 15u) & ~15u;
+    L.tab_bytes = ((es == 4u ? b.gc_words_all : b.gc_words) * 4u + 15u) & ~15u;
     L.off_g = (4u * es + 8u) * 16u * b.gc_nc + 16u + b.gc_nslots * es;  // (slots are a multiple of four: 16-byte aligned)
     L.stride = L.off_g + b.gc_ng * es;
     return L;
@@ -164,6 +164,45 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     // K3: Jt J into its slots and -Jt r from the program's lists (ds_add_f64; entry t is lane t % 16's, 16 consecutive entries
     // per instruction, in list order — fx_grouped.hip's order)
     auto form_normal = [&]() {
+        if constexpr (sizeof(T) == 4) {
+            // f32: every slot's and every column's sum by a gather, in list order — the order the atomics below arrive in — instead
+            // of ds_add_f32, which gfx950 executes at a fourteenth of ds_add_f64's rate (tools/probes/lds_atomic_f32_probe.hip)
+            const uint16_t* sptr = reinterpret_cast<const uint16_t*>(smem + rfl(TB[9]));
+            const uint16_t* SPW = reinterpret_cast<const uint16_t*>(smem + rfl(TB[10]));
+            const uint16_t* cptr = reinterpret_cast<const uint16_t*>(smem + rfl(TB[11]));
+            const uint16_t* CPE = reinterpret_cast<const uint16_t*>(smem + rfl(TB[12]));
+            for (uint32_t sl = hl; sl < nslots; sl += RS) {
+                const uint32_t t0 = sptr[sl], t1 = sptr[sl + 1];
+                T acc = T(0);
+                for (uint32_t t = t0; t < t1; ++t) {
+                    const uint32_t w = SPW[t];
+                    acc += G[w & 0xFFu] * G[w >> 8];
+                }
+                At[sl] = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const uint32_t j = (uint32_t)(hl + RS * q);
+                const uint32_t t0 = cptr[j], t1 = cptr[j + 1];
+                T acc = T(0);
+                for (uint32_t t = t0; t < t1; ++t) {
+                    const uint32_t w = CPE[t];
+                    acc += G[w & 0xFFu] * -R[w >> 8];
+                }
+                rhsv[j] = acc;
+            }
+            group_sync();
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if ((uint32_t)(hl + RS * q) >= nfree) At[dslot[q]] = T(1);  // identity padding
+            group_sync();
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                diag[q] = At[dslot[q]];
+                rhs_l[q] = rhsv[hl + RS * q];
+            }
+            return;
+        }
         {
             V16 z;
             for (int q = 0; q < Vec16<T>::n; ++q) reinterpret_cast<T*>(&z)[q] = T(0);
@@ -230,14 +269,14 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     {
         const uint32_t c = home + ci < ncls ? home + ci : home + ci - ncls;
         const uint32_t* prog = b.gc_tab;
-        uint32_t words = b.gc_words;
+        uint32_t words = sizeof(T) == 4 ? b.gc_words_all : b.gc_words;
         qn = b.n_systems;
         qlist = b.order;
         qhead = next_system;
         if (b.gc_nclasses) {
             const GcClass k = b.gc_classes[c];
             prog = b.gc_tab + k.prog_off;
-            words = k.words;
+            words = sizeof(T) == 4 ? k.words_all : k.words;
             qn = k.count;
             qlist = b.order + k.list_off;
             qhead = next_system + c;
