@@ -5,16 +5,19 @@
 // build takes 392 and 40 KB and runs one wavefront per SIMD, with the VALU busy half of the time).
 //
 // What makes it fit is that nothing about the structure is per System any more. The host writes one PROGRAM for the batch
-// (fx_abi.cpp: build_gc_program; every System has one component, at most 32 variables and 32 expressions, 17 ... 32 of the
-// variables free — or 48 / 48 / 33 ... 48: three columns per lane, the reference's own bench sketch), the wavefront copies it into LDS once, and the four Systems share it:
+// (fx_abi.cpp: build_gc_program; every System has one component, at most 32 variables and 32 expressions — two matrix columns per
+// lane; 16 / 16: one column, four wavefronts per SIMD; 48 / 48, the reference's own bench sketch: three columns, a wavefront on
+// every SIMD), the wavefront copies it into LDS once, and the four Systems share it:
 //   * the row lists (variables and kind of every expression), the free-variable map, the product lists of Jt J and Jt r —
 //     4 KB once per wavefront instead of 2.4 KB per System (and no list building when a row takes a System);
 //   * Jt J by its PATTERN: a slot per structural non-zero of the lower triangle (ring16: 144 of 528), addressed through the
 //     program — the product lists name slots, and a lane's 64 matrix elements are loaded through a table of slot numbers
 //     (64 bytes per lane; what is not in the pattern reads the zero slot). The factor's fill exists in registers only;
 //   * Jacobian rows compact (an expression's own entries instead of eight).
-// ring16: 3.5 KB per System, 18.2 KB per wavefront, eight wavefronts per CU; f32 (cfg5), the 48-column shape (one wavefront on
-// every SIMD) and the 16-column shape (four per SIMD) are instantiations of the same body.
+// ring16: 3.5 KB per System, 18.2 KB per wavefront, eight wavefronts per CU. The f32 instantiation (cfg5) assembles by gather
+// instead of LDS float atomics (ds_add_f32 runs at a fourteenth of ds_add_f64's rate on gfx950).
+// A batch of SEVERAL structures brings a program per big structure class; one launch works through all of them (a wavefront
+// loads the next class's program when its own class's queue is empty).
 // The per-row state machine, the device-side queue, the lambda ladder, the hold passes are fx_grouped.hip's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
