@@ -2759,13 +2759,15 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
     std::vector<uint32_t> cl_words_h, cl_lists_h;
     if (!d.uniform && sys_class && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u) {
         constexpr uint32_t CLASS_MIN = 2048u, MAX_CLASSES = 8u;
-        std::unordered_map<uint32_t, uint32_t> count;
+        std::vector<uint32_t> count(n_sys, 0u);  // (a class is named by its first System)
         for (uint32_t s = 0; s < n_sys; ++s) count[sys_class[s]] += 1u;
         std::vector<std::pair<uint32_t, uint32_t>> big;  // (members, first System)
-        for (auto& kv : count)
-            if (kv.second >= CLASS_MIN) big.push_back({kv.second, kv.first});
+        for (uint32_t f = 0; f < n_sys; ++f)
+            if (count[f] >= CLASS_MIN) big.push_back({count[f], f});
         std::sort(big.begin(), big.end(), [](auto& a, auto& b2) { return a.first != b2.first ? a.first > b2.first : a.second < b2.second; });
-        std::unordered_map<uint32_t, uint32_t> class_slot;  // first System -> index into db->classes
+        std::vector<uint32_t>& class_slot = count;  // first System -> index into db->classes (reusing the array: NO_SLOT elsewhere)
+        constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+        std::fill(class_slot.begin(), class_slot.end(), NO_SLOT);
         for (auto& pr : big) {
             if (db->classes.size() >= MAX_CLASSES) break;
             const uint32_t f = pr.second;
@@ -2805,9 +2807,9 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
             std::vector<uint32_t> fill(db->classes.size(), 0);
             uint32_t nrest = 0;
             for (uint32_t s = 0; s < n_sys; ++s) {
-                auto it = class_slot.find(sys_class[s]);
-                if (it == class_slot.end()) cl_lists_h[db->rest_off + nrest++] = s;
-                else cl_lists_h[db->classes[it->second].list_off + fill[it->second]++] = s;
+                const uint32_t slot = class_slot[sys_class[s]];
+                if (slot == NO_SLOT) cl_lists_h[db->rest_off + nrest++] = s;
+                else cl_lists_h[db->classes[slot].list_off + fill[slot]++] = s;
             }
             db->rest_count = nrest;
             reqs.push_back({reinterpret_cast<void**>(&db->cl_words), cl_words_h.data(), cl_words_h.size() * 4, 0});
