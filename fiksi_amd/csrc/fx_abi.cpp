@@ -1467,24 +1467,29 @@ static bool build_gs_program(const uint16_t* var_info, const uint8_t* expr_tag, 
     {
         std::vector<uint8_t> g = adj;
         std::vector<uint8_t> gone(n, 0);
+        std::vector<uint32_t> deg(n, 0), nbr;
+        auto degree = [&](uint32_t c) {
+            uint32_t dg = 0;
+            for (uint32_t e = 0; e < n; ++e) dg += (!gone[e] && e != c && g[(size_t)c * n + e]) ? 1u : 0u;
+            return dg;
+        };
+        for (uint32_t c = 0; c < n; ++c) deg[c] = degree(c);
         for (uint32_t step = 0; step < n; ++step) {
             uint32_t best = n, bdeg = 0xFFFFFFFFu;
-            for (uint32_t c = 0; c < n; ++c) {
-                if (gone[c]) continue;
-                uint32_t deg = 0;
-                for (uint32_t e = 0; e < n; ++e) deg += (!gone[e] && e != c && g[(size_t)c * n + e]) ? 1u : 0u;
-                if (deg < bdeg) {
-                    bdeg = deg;
+            for (uint32_t c = 0; c < n; ++c)
+                if (!gone[c] && deg[c] < bdeg) {
+                    bdeg = deg[c];
                     best = c;
                 }
-            }
             gone[best] = 1;
             pos[best] = step;
             order.push_back(best);
+            nbr.clear();
             for (uint32_t a = 0; a < n; ++a)
-                if (!gone[a] && g[(size_t)best * n + a])
-                    for (uint32_t bb = 0; bb < n; ++bb)
-                        if (!gone[bb] && g[(size_t)best * n + bb]) g[(size_t)a * n + bb] = 1;
+                if (!gone[a] && g[(size_t)best * n + a]) nbr.push_back(a);
+            for (uint32_t a : nbr)
+                for (uint32_t bb : nbr) g[(size_t)a * n + bb] = 1;
+            for (uint32_t a : nbr) deg[a] = degree(a);  // (only the eliminated column's neighbours change their degree)
         }
     }
     // ---- the factor's pattern in elimination order: lp[i][k] (positions), with fill
