@@ -824,6 +824,7 @@ struct fx_dbatch {
     uint32_t* cl_words = nullptr;
     uint32_t* cl_lists = nullptr;
     uint32_t cl_max_words_all = 0;
+    uint32_t cl_rc = 0;
     uint32_t cl_nc = 0, cl_max_words = 0, cl_max_slots = 0, cl_max_ng = 0, cl_systems = 0;  // the classes' common build, the largest program, their Systems in all
     uint32_t rest_off = 0, rest_count = 0;
     // host copy of the batch, kept only when some System needs the sparse path
@@ -1257,19 +1258,20 @@ bool build_qr_plan(const uint8_t* expr_tag, const uint16_t* expr_idx16, const ui
 // one column twice — the order fx_grouped.hip builds its lists in, and so the order of the additions).
 struct GcHostProgram {
     std::vector<uint32_t> words;
-    uint32_t nslots = 0, ng = 0, nc = 0, words_f64 = 0;  // (words_f64: the part the f64 builds use)
+    uint32_t nslots = 0, ng = 0, nc = 0, rc = 0, words_f64 = 0;  // (words_f64: the part the f64 builds use)
 };
-template <int NC>
+template <int NC, int RC>
 static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag, const uint16_t* expr_comp, const uint16_t* expr_idx16,
                                uint32_t nvt, uint32_t net, GcHostProgram& out) {  // (free variables: 1 ... NV; the caller picks the smallest build)
-    using TK = fx::GcTable<NC>;
-    constexpr uint32_t NV = TK::NV;
+    using TK = fx::GcTable<NC, RC>;
+    constexpr uint32_t NV = TK::NV, NR = TK::NR;
     out = GcHostProgram();
     out.nc = NC;
-    if (nvt == 0 || nvt > NV || net == 0 || net > NV) return false;
+    out.rc = RC;
+    if (nvt == 0 || nvt > NV || net == 0 || net > NR) return false;
     int8_t vcol[NV];
-    uint8_t fidx[NV] = {0}, rtag[NV] = {0}, gvar[NV][8] = {{0}};
-    uint16_t gbase[NV] = {0};
+    uint8_t fidx[NV] = {0}, rtag[NR] = {0}, gvar[NR][8] = {{0}};
+    uint16_t gbase[NR] = {0};
     uint32_t nfree = 0;
     for (uint32_t i = 0; i < NV; ++i) vcol[i] = -1;
     for (uint32_t i = 0; i < nvt; ++i) {
@@ -1280,7 +1282,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
         }
     }
     if (nfree == 0 || nfree > NV) return false;
-    int gcol[NV][8];
+    int gcol[NR][8];
     uint32_t ng = 0;
     for (uint32_t r = 0; r < net; ++r) {
         if (expr_comp[r] != 0) return false;
@@ -1297,7 +1299,7 @@ static bool build_gc_program_t(const uint16_t* var_info, const uint8_t* expr_tag
         }
         ng += (uint32_t)k;
     }
-    if (ng > 256u) return false;
+    if (ng > 256u) return false;  // (a byte per compact Jacobian entry in the lists)
     // the pattern of the lower triangle, slots in packed-triangle order
     std::vector<int32_t> slot_of(NV * (NV + 1u) / 2u, -1);
     auto tri = [](uint32_t hi, uint32_t lo) { return hi * (hi + 1u) / 2u + lo; };
@@ -1401,9 +1403,12 @@ static bool build_gc_program(const uint16_t* var_info, const uint8_t* expr_tag, 
                              uint32_t nvt, uint32_t net, uint32_t max_free, GcHostProgram& out) {
     // the smallest build that holds the structure: its free variables decide, unless its variables (fixed ones included) or its
     // expressions need the next one's tables — the columns past the free variables are identity padding either way
-    if (max_free <= 16u && build_gc_program_t<1>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
-    if (max_free <= 32u && build_gc_program_t<2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
-    return build_gc_program_t<3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
+    // (... and an over-constrained structure the instantiation with twice the rows)
+    if (max_free <= 16u && build_gc_program_t<1, 1>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    if (max_free <= 16u && build_gc_program_t<1, 2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    if (max_free <= 32u && build_gc_program_t<2, 2>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    if (max_free <= 32u && build_gc_program_t<2, 4>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out)) return true;
+    return build_gc_program_t<3, 3>(var_info, expr_tag, expr_comp, expr_idx16, nvt, net, out);
 }
 
 // The program of the grouped kernel's SPARSE build (fx_grouped_s.hip): batches of one structure whose single component is too
@@ -2105,6 +2110,7 @@ static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& 
     dc.gc_nslots = db->cl_max_slots;
     dc.gc_ng = db->cl_max_ng;
     dc.gc_nc = db->cl_nc;
+    dc.gc_rc = db->cl_rc;
     dc.gc_classes = db->cl_desc;
     dc.gc_nclasses = (uint32_t)db->classes.size();
     dc.order = db->cl_lists;
@@ -2758,6 +2764,7 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
         d.gc_nslots = gc.nslots;
         d.gc_ng = gc.ng;
         d.gc_nc = gc.nc;
+        d.gc_rc = gc.rc;
     }
     // Several structures: the classes with 2 048 members and more (at most eight, the largest first; those of the largest one's
     // build — columns per lane) get a program each
@@ -2784,8 +2791,11 @@ static int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p,
             if (!build_gc_program(p.var_info.data() + vf, p.expr_tagx.data() + ef, p.expr_comp.data() + ef, p.expr_idx16.data() + 4 * (size_t)ef, nvt, net,
                                   nfree, cp))
                 continue;
-            if (db->classes.empty()) db->cl_nc = cp.nc;
-            if (cp.nc != db->cl_nc) continue;
+            if (db->classes.empty()) {
+                db->cl_nc = cp.nc;
+                db->cl_rc = cp.rc;
+            }
+            if (cp.nc != db->cl_nc || cp.rc != db->cl_rc) continue;
             fx::GcClass cl;
             cl.prog_off = (uint32_t)cl_words_h.size();
             cl.words = cp.words_f64;
@@ -3200,6 +3210,7 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         dc.gc_nslots = db->cl_max_slots;
         dc.gc_ng = db->cl_max_ng;
         dc.gc_nc = db->cl_nc;
+        dc.gc_rc = db->cl_rc;
         dc.gc_nclasses = (uint32_t)db->classes.size();
         if (fx::grouped_c_applies(dc, p)) *build = 3;
     }

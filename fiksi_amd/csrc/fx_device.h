@@ -68,9 +68,9 @@ constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs inst
 
 // The program of the grouped kernel's one-structure build (fx_grouped_c.hip; written by fx_abi.cpp: build_gc_program): byte
 // offsets of its tables of fixed size; the right-hand-side list and, behind it, the product list follow at PE
-template <int NC> struct GcTable {  // NC columns per lane: Systems of at most NV = 16 NC variables and expressions
-    static constexpr uint32_t NV = 16u * NC;
-    static constexpr uint32_t VCOL = 80, FIDX = VCOL + NV, RTAG = FIDX + NV, GBASE = RTAG + NV, GVAR = GBASE + 2 * NV, LT = GVAR + 8 * NV,
+template <int NC, int RC> struct GcTable {  // NC columns per lane, RC chunks of 16 rows: Systems of at most NV = 16 NC variables and NR = 16 RC expressions
+    static constexpr uint32_t NV = 16u * NC, NR = 16u * RC;
+    static constexpr uint32_t VCOL = 80, FIDX = VCOL + NV, RTAG = FIDX + NV, GBASE = RTAG + NR, GVAR = GBASE + 2 * NR, LT = GVAR + 8 * NR,
                               PE = LT + 16 * NC * NV;
 };
 
@@ -149,6 +149,7 @@ struct DeviceBatch {
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program (the f64 builds' part); slots of Jt J's pattern (+ the zero slot), compact Jacobian entries
     uint32_t gc_words_all;                // ... with the f32 build's gather tables
     uint32_t gc_nc;                       // columns per lane of the build the program is for: 1 (up to 16 free variables), 2 (17 ... 32) or 3 (33 ... 48)
+    uint32_t gc_rc;                       // ... and its chunks of 16 expressions: gc_nc, or twice that for an over-constrained structure
     const GcClass* gc_classes;            // a launch over several structure classes (null: one program, the whole batch)
     uint32_t gc_nclasses;
     // the program of its sparse build (fx_grouped_s.hip; build_gs_program): uniform batches with one component of 49 ... 128 free

@@ -7,7 +7,8 @@
 // What makes it fit is that nothing about the structure is per System any more. The host writes one PROGRAM for the batch
 // (fx_abi.cpp: build_gc_program; every System has one component, at most 32 variables and 32 expressions — two matrix columns per
 // lane; 16 / 16: one column, four wavefronts per SIMD; 48 / 48, the reference's own bench sketch: three columns, a wavefront on
-// every SIMD), the wavefront copies it into LDS once, and the four Systems share it:
+// every SIMD; an over-constrained structure — up to twice the shape's rows — the same bodies with twice the row chunks), the
+// wavefront copies it into LDS once, and the four Systems share it:
 //   * the row lists (variables and kind of every expression), the free-variable map, the product lists of Jt J and Jt r —
 //     4 KB once per wavefront instead of 2.4 KB per System (and no list building when a row takes a System);
 //   * Jt J by its PATTERN: a slot per structural non-zero of the lower triangle (ring16: 144 of 528), addressed through the
@@ -35,9 +36,10 @@ namespace fx {
 
 // A System's block, bytes: everything of fixed size first, at offsets the instructions carry as immediates (one base register per
 // row), then Jt J's slots and behind them the compact Jacobian rows
-// (NV = 16 NC: the most variables / expressions of a System in the build with NC columns per lane; ES: bytes of the compute type)
-template <int NV, int ES> struct GcBlock {
-    static constexpr uint32_t XS = 0, RHS = ES * NV, R = 2 * ES * NV, P = 3 * ES * NV, VOUT = 4 * ES * NV, STASH = VOUT + 8 * NV, A = STASH + 16;
+// (NV = 16 NC: the most variables of a System in the build with NC columns per lane; NR = 16 RC: the most expressions — an
+// over-constrained structure takes the instantiation with twice the rows; ES: bytes of the compute type)
+template <int NV, int NR, int ES> struct GcBlock {
+    static constexpr uint32_t XS = 0, RHS = ES * NV, R = 2 * ES * NV, P = R + ES * NR, VOUT = P + ES * NR, STASH = VOUT + 8 * NV, A = STASH + 16;
 };
 struct GcLayout {
     uint32_t tab_bytes, off_g, stride;
@@ -46,20 +48,20 @@ struct GcLayout {
 static GcLayout make_gc_layout(const DeviceBatch& b, uint32_t es) {
     GcLayout L;
     L.tab_bytes = ((es == 4u ? b.gc_words_all : b.gc_words) * 4u + 15u) & ~15u;
-    L.off_g = (4u * es + 8u) * 16u * b.gc_nc + 16u + b.gc_nslots * es;  // (slots are a multiple of four: 16-byte aligned)
+    L.off_g = (2u * es + 8u) * 16u * b.gc_nc + 2u * es * 16u * b.gc_rc + 16u + b.gc_nslots * es;  // (slots are a multiple of four: 16-byte aligned)
     L.stride = L.off_g + b.gc_ng * es;
     return L;
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-template <int NC, typename T>
+template <int NC, int RC, typename T>
 __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmParams& prm, const GcLayout& L, uint32_t* __restrict__ next_system,
                                                unsigned char* smem) {
     constexpr int N = RS * NC;
-    using BK = GcBlock<N, (int)sizeof(T)>;
+    using BK = GcBlock<N, RS * RC, (int)sizeof(T)>;
     using V16 = typename Vec16<T>::type;
-    using TK = GcTable<NC>;
+    using TK = GcTable<NC, RC>;
     const int lane = threadIdx.x;
     const int hl = lane & (RS - 1);
     const int gbase = lane & ~(RS - 1);
@@ -139,13 +141,21 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         if constexpr (NC >= 3) s01 = s01 + row_sum(part[2]);
         return s01;
     };
+    // ... over the expressions' chunks: (b0 + b1) + (b2 + b3)
+    auto rows_sum = [&](const auto (&part)[RC]) {
+        auto s01 = row_sum(part[0]);
+        if constexpr (RC >= 2) s01 = s01 + row_sum(part[1]);
+        if constexpr (RC == 3) s01 = s01 + row_sum(part[2]);
+        if constexpr (RC == 4) s01 = s01 + (row_sum(part[2]) + row_sum(part[3]));
+        return s01;
+    };
     // residuals and Jacobian rows of the point in XS
     auto eval_rows = [&]() -> T {
-        T part[NC];
+        T part[RC];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) part[k] = T(0);
+        for (int k = 0; k < RC; ++k) part[k] = T(0);
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
+        for (int k = 0; k < RC; ++k) {
             const uint32_t row = (uint32_t)(hl + RS * k);
             if (row < net) {
                 T v[8], g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -162,7 +172,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
             }
         }
         group_sync();
-        return chunk_sum(part);
+        return rows_sum(part);
     };
     // K3: Jt J into its slots and -Jt r from the program's lists (ds_add_f64; entry t is lane t % 16's, 16 consecutive entries
     // per instruction, in list order — fx_grouped.hip's order)
@@ -346,15 +356,19 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                 s = nxt;
                 // (a launch over ONE structure class of a batch of several — b.uniform == 0 — reads the System's offsets)
                 const uint32_t v0 = b.uniform ? s * nvt : b.var_off[s], e0 = b.uniform ? s * net : b.expr_off[s];
-                double c_var[NC], c_param[NC];
-                int tagk[NC], colk[NC];
+                double c_var[NC], c_param[RC];
+                int tagk[RC], colk[NC];
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     const uint32_t i = (uint32_t)(RS * k + hl);
                     c_var[k] = i < nvt ? b.vars0[v0 + i] : 0.0;
+                    colk[k] = i < nvt ? (int)vcol[i] : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    const uint32_t i = (uint32_t)(RS * k + hl);
                     c_param[k] = i < net ? b.expr_param[e0 + i] : 0.0;
                     tagk[k] = i < net ? (int)rtag[i] : 0;
-                    colk[k] = i < nvt ? (int)vcol[i] : -1;
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 // K0a: system scale, summed strictly in reference order (utils.rs:11-33)
@@ -366,7 +380,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     for (int k = 0; k < NC; ++k)
                         if ((uint32_t)(RS * k) < nvt) seq_add(sum, c_var[k] * c_var[k]);  // (past the end: + 0.0, exact)
 #pragma unroll
-                    for (int k = 0; k < NC; ++k) {
+                    for (int k = 0; k < RC; ++k) {
                         if ((uint32_t)(RS * k) < net) {
                             const bool isd = (uint32_t)(RS * k + hl) < net && (tagk[k] == FX_TAG_PPD || tagk[k] == FX_TAG_PLD);
                             count += (uint32_t)__popc(gballot(isd));
@@ -393,6 +407,10 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                         VOUT[i] = c_var[k];
                         b.vars[v0 + i] = c_var[k];  // fixed variables stay bit-identical
                     }
+                }
+#pragma unroll
+                for (int k = 0; k < RC; ++k) {
+                    const uint32_t i = (uint32_t)(RS * k + hl);
                     if (i < net) {
                         double prm_e = c_param[k];
                         if ((prm.mode & 1u) && (tagk[k] == FX_TAG_PPD || tagk[k] == FX_TAG_PLD)) prm_e = scale_recip * prm_e;
@@ -652,7 +670,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     for (uint32_t i = hl; i < ng2; i += RS) gd[i] = gs[i];
                     const T* rs = reinterpret_cast<const T*>(wb + BK::R);
 #pragma unroll
-                    for (int q = 0; q < NC; ++q) R[hl + RS * q] = rs[hl + RS * q];
+                    for (int k = 0; k < RC; ++k) R[hl + RS * k] = rs[hl + RS * k];
                     group_sync();
                 }
                 form_normal();
@@ -696,9 +714,9 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         // (constraints/mod.rs:96-109), the result record =================
         if (finish_now) {
             const uint32_t v0 = b.uniform ? s * nvt : b.var_off[s], e0 = b.uniform ? s * net : b.expr_off[s];
-            double c_param[NC];  // the unscaled parameters of expressions hl, hl + 16
+            double c_param[RC];  // the unscaled parameters of expressions hl, hl + 16, ...
 #pragma unroll
-            for (int k = 0; k < NC; ++k) c_param[k] = (uint32_t)(RS * k + hl) < net ? b.expr_param[e0 + (uint32_t)(RS * k + hl)] : 0.0;
+            for (int k = 0; k < RC; ++k) c_param[k] = (uint32_t)(RS * k + hl) < net ? b.expr_param[e0 + (uint32_t)(RS * k + hl)] : 0.0;
             const double scale = STASH[0];
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
@@ -710,9 +728,9 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                 }
             }
             group_sync();
-            double part[NC];
+            double part[RC];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
+            for (int k = 0; k < RC; ++k) {
                 const uint32_t i = (uint32_t)(hl + RS * k);
                 part[k] = 0.0;
                 if (i < net) {
@@ -726,7 +744,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     part[k] = r * r;
                 }
             }
-            const double sse_u = chunk_sum(part);
+            const double sse_u = rows_sum(part);
             if (hl == 0) {
                 fx_result res;
                 res.accepted = accepted;
@@ -753,20 +771,20 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lm_solve_grouped_c1_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<1, double>(b, prm, L, next_system, smem);
+    grouped_c_body<1, 1, double>(b, prm, L, next_system, smem);
 }
 // 17 ... 32 free variables: two columns per lane, 256 registers, two wavefronts per SIMD
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<2, double>(b, prm, L, next_system, smem);
+    grouped_c_body<2, 2, double>(b, prm, L, next_system, smem);
 }
 // ... in f32 (fx_lm_opts_default_f32): 178 registers (three wavefronts per SIMD — 168 registers, 24 bytes of scratch — measured
 // the same: 2.79 against 2.77 ms on 125 000 inconsistent ring16 sketches)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_c_f32_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<2, float>(b, prm, L, next_system, smem);
+    grouped_c_body<2, 2, float>(b, prm, L, next_system, smem);
 }
 // 33 ... 48 free variables (the reference's own bench sketch, fiksi_bench.rs:15-40: 46): three columns per lane are 288
 // registers of matrix alone — one wavefront per SIMD, but on every SIMD (the general build's 16 KB of LDS per System leave two
@@ -774,12 +792,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void lm_solve_grouped_c3_kernel(
     DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
     extern __shared__ __align__(16) unsigned char smem[];
-    grouped_c_body<3, double>(b, prm, L, next_system, smem);
+    grouped_c_body<3, 3, double>(b, prm, L, next_system, smem);
+}
+
+// Over-constrained structures — more expressions than the shape's 16 / 32 rows, up to twice as many: the same bodies with twice
+// the row chunks (cfg5's theme: least squares over more constraints than unknowns)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void lm_solve_grouped_c1r_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<1, 2, double>(b, prm, L, next_system, smem);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_cr_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<2, 4, double>(b, prm, L, next_system, smem);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void lm_solve_grouped_cr_f32_kernel(
+    DeviceBatch b, LmParams prm, GcLayout L, uint32_t* __restrict__ next_system) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    grouped_c_body<2, 4, float>(b, prm, L, next_system, smem);
 }
 
 // ------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------
+typedef void (*GcKernel)(DeviceBatch, LmParams, GcLayout, uint32_t*);
+struct GcBuild {
+    GcKernel fn;
+    unsigned int* raised;   // (raise_lds_limit_once's per-device bits)
+    uint32_t waves_per_cu;  // by registers
+};
+// the instantiation for a program's shape (columns per lane, row chunks) and the compute type; fn == nullptr: none
+static GcBuild gc_build_for(uint32_t nc, uint32_t rc, bool f32) {
+    static unsigned int r1 = 0, r1r = 0, r2 = 0, r2r = 0, r3 = 0, rf = 0, rfr = 0;
+    if (f32) {
+        if (nc == 2u && rc == 2u) return {&lm_solve_grouped_c_f32_kernel, &rf, 8u};
+        if (nc == 2u && rc == 4u) return {&lm_solve_grouped_cr_f32_kernel, &rfr, 8u};
+        return {nullptr, nullptr, 0u};
+    }
+    if (nc == 1u && rc == 1u) return {&lm_solve_grouped_c1_kernel, &r1, 16u};
+    if (nc == 1u && rc == 2u) return {&lm_solve_grouped_c1r_kernel, &r1r, 16u};
+    if (nc == 2u && rc == 2u) return {&lm_solve_grouped_c_kernel, &r2, 8u};
+    if (nc == 2u && rc == 4u) return {&lm_solve_grouped_cr_kernel, &r2r, 8u};
+    if (nc == 3u && rc == 3u) return {&lm_solve_grouped_c3_kernel, &r3, 4u};
+    return {nullptr, nullptr, 0u};
+}
+
 // LDS bytes per wavefront, 0 when the batch has no program
 size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t es) {
     if (!b.gc_tab || !b.gc_words) return 0;
@@ -792,25 +850,24 @@ bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
     if (!b.gc_tab || !(b.uniform ? b.u_ncomp == 1u : b.gc_nclasses != 0u) || !b.work_counter || b.has_pose) return false;
     if (p.prof || p.lm.solver != FX_STEP_CHOLESKY || (p.mode & (MODE_UNITS | MODE_LBFGS))) return false;
     const bool f32 = p.lm.precision == 32;
-    if (f32 && b.gc_nc != 2u) return false;  // (f32: the 32-column instantiation only)
-    // two columns per lane: six wavefronts per CU or more (a SIMD with two is what the build is for); three: one per SIMD
+    const GcBuild k = gc_build_for(b.gc_nc, b.gc_rc, f32);
+    if (!k.fn) return false;  // (f32: the 32-column instantiations only)
+    // one column per lane: eight wavefronts per CU or more; two: six (a SIMD with two is what the build is for); three: one per SIMD
     const size_t lds = grouped_c_lds_bytes(b, f32 ? 4u : 8u);
-    return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 1u ? 16u : b.gc_nc == 2u ? 6u : 4u);
+    return lds != 0 && lds <= (160u * 1024u) / (b.gc_nc == 1u ? 8u : b.gc_nc == 2u ? 6u : 4u);
 }
 
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
     const bool f32 = p.lm.precision == 32;
+    const GcBuild k = gc_build_for(b.gc_nc, b.gc_rc, f32);
+    if (!k.fn) return hipErrorInvalidValue;
     const GcLayout L = make_gc_layout(b, f32 ? 4u : 8u);
     const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
     static const bool trace = getenv("FIKSI_AMD_TRACE") != nullptr;
     if (trace)
-        fprintf(stderr, "[fiksi_amd] grouped kernel, one-structure build: %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of Jt J, %u Jacobian entries)\n",
-                per_wave, L.tab_bytes, L.stride, b.gc_nslots, b.gc_ng);
-    static unsigned int raised = 0, raised3 = 0, raised_f = 0, raised1 = 0;
-    hipError_t e = f32           ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_f32_kernel), &raised_f)
-                   : b.gc_nc == 1u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c1_kernel), &raised1)
-                   : b.gc_nc == 2u ? raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c_kernel), &raised)
-                                   : raise_lds_limit_once(reinterpret_cast<const void*>(&lm_solve_grouped_c3_kernel), &raised3);
+        fprintf(stderr, "[fiksi_amd] grouped kernel, one-structure build (%u columns per lane, %u row chunks): %u B of LDS per wavefront (program %u, 4 x %u per System: %u slots of Jt J, %u Jacobian entries)\n",
+                b.gc_nc, b.gc_rc, per_wave, L.tab_bytes, L.stride, b.gc_nslots, b.gc_ng);
+    hipError_t e = raise_lds_limit_once(reinterpret_cast<const void*>(k.fn), k.raised);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(b.work_counter, 0, sizeof(uint32_t) * (b.gc_nclasses ? b.gc_nclasses : 1u), stream);  // the queue heads
     if (e != hipSuccess) return e;
@@ -822,16 +879,12 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint32_t by_lds = (160u * 1024u) / per_wave;
-        const uint32_t by_simd = b.gc_nc == 1u ? 16u : b.gc_nc == 2u ? 8u : 4u;
-        uint32_t resident = (uint32_t)cus * (by_lds < by_simd ? by_lds : by_simd);
+        uint32_t resident = (uint32_t)cus * (by_lds < k.waves_per_cu ? by_lds : k.waves_per_cu);
         if (resident > waves) resident = waves;
         if (b.order && p.spread && !b.gc_nclasses) pl.spread = resident < b.n_systems / 4u ? resident : b.n_systems / 4u;
         if (p.ladder_tail == 0xFFFFFFFFu) pl.ladder_tail = 32u * resident / (b.gc_nclasses ? b.gc_nclasses : 1u);
     }
-    if (f32) hipLaunchKernelGGL(lm_solve_grouped_c_f32_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
-    else if (b.gc_nc == 1u) hipLaunchKernelGGL(lm_solve_grouped_c1_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
-    else if (b.gc_nc == 2u) hipLaunchKernelGGL(lm_solve_grouped_c_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
-    else hipLaunchKernelGGL(lm_solve_grouped_c3_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
+    hipLaunchKernelGGL(k.fn, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     return hipGetLastError();
 }
 

@@ -184,3 +184,22 @@ def test_random_structures_against_the_general_build(fiksi, ctx, ctx_general, se
     else:
         same = (r0["accepted"] == r1["accepted"]) & (r0["trials"] == r1["trials"]) & (r0["exit"] == r1["exit"])
         assert same.mean() >= 0.9
+
+
+@pytest.mark.parametrize("case", ["16_points_45_rows", "16_points_45_rows_f32", "8_points_23_rows", "16_points_37_rows_fixed"])
+def test_over_constrained_structures_take_the_instantiations_with_twice_the_rows(fiksi, ctx, ctx_general, case):
+    """More expressions than the shape's 16 / 32 rows (cfg5's theme: least squares over more constraints than unknowns): the same
+    build with twice the row chunks, every bit of the general build — f64 and f32."""
+    from fiksi_amd import abi
+    from test_gpu_grouped_s import _random_graph_batch
+
+    n_pts, n_extra, fix, f32 = {"16_points_45_rows": (16, 30, False, False), "16_points_45_rows_f32": (16, 30, False, True),
+                                "8_points_23_rows": (8, 16, False, False), "16_points_37_rows_fixed": (16, 20, True, False)}[case]
+    b = _random_graph_batch(400, n_pts, n_extra, 321 + n_extra, fix_first=fix, angles=2)
+    o = abi.solving_opts(f32=f32)
+    db = ctx.upload(b)
+    assert int(b["expr_off"][1]) > 16 * (1 if n_pts == 8 else 2) and db.grouped_build(o) == 1
+    db.free()
+    v1, r1 = ctx.system_solve_batch(b, o)
+    v0, r0 = ctx_general.system_solve_batch(b, o)
+    assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
