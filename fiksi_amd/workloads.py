@@ -114,6 +114,33 @@ def ring16(n_systems: int, seed0: int = 1000, inconsistent: bool = False, fix_ga
     }
 
 
+def ring16_overconstrained(n_systems: int, seed0: int = 1000) -> Dict[str, np.ndarray]:
+    """cfg5's theme taken literally — least squares over MORE constraints than unknowns: the inconsistent ring16 sketch plus 16
+    distances (i, i + 3) whose targets are the start configuration's own distances: 48 expressions on 32 variables."""
+    b = ring16(n_systems, seed0=seed0, inconsistent=True)
+    n, P, m0, m = int(n_systems), 16, 32, 48
+    pos = b["vars"].reshape(n, P, 2)
+    tag = np.zeros((n, m), dtype=np.uint8)
+    idx = np.zeros((n, m, 4), dtype=np.uint32)
+    par = np.zeros((n, m))
+    tag[:, :m0] = b["expr_tag"].reshape(n, m0)
+    idx[:, :m0] = b["expr_idx"].reshape(n, m0, 4)
+    par[:, :m0] = b["expr_param"].reshape(n, m0)
+    for i in range(P):
+        j = (i + 3) % P
+        tag[:, m0 + i] = abi.POINT_POINT_DISTANCE
+        idx[:, m0 + i, 0], idx[:, m0 + i, 1] = 2 * i, 2 * j
+        d = pos[:, i, :] - pos[:, j, :]
+        par[:, m0 + i] = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+    out = dict(b)
+    out["expr_off"] = (np.arange(n + 1, dtype=np.uint64) * m).astype(np.uint32)
+    out["expr_tag"] = tag.reshape(-1)
+    out["expr_idx"] = idx.reshape(-1)
+    out["expr_param"] = par.reshape(-1)
+    out["expr_comp"] = np.zeros(n * m, dtype=np.uint16)
+    return out
+
+
 def ring_chords(n_systems: int, n_points: int = 20, step: int = 7, seed0: int = 5000) -> Dict[str, np.ndarray]:
     """n independent sketches of `n_points` points on a jittered circle with the distances (i, i + 1) and (i, i + step): a
     structure whose normal matrix fills in when factored (the long chords couple everything), unlike the banded ring16 or the

@@ -21,6 +21,7 @@ def one(n, reps):
                     ("ring16_inconsistent", workloads.ring16(n // 4, inconsistent=True)), ("ring20_chords", workloads.ring_chords(n, 20, 7)),
                     ("hinged_5", workloads.hinged_triangles(n, 5)), ("hinged_1", workloads.hinged_triangles(n, 1)),
                     ("hinged_3", workloads.hinged_triangles(n, 3)), ("ring16_inconsistent_f32", workloads.ring16(n + n // 4, inconsistent=True)),
+                    ("ring16_overconstrained", workloads.ring16_overconstrained(n)), ("ring16_overconstrained_f32", workloads.ring16_overconstrained(n)),
                     # batches of SEVERAL structures: one launch over their big structure classes (+ the general build for the rest)
                     ("two_structures", workloads.ring16_two_structures(n)),
                     ("three_classes_and_a_small_one", workloads.concat([workloads.ring16(3 * n // 10), workloads.hinged_triangles(3 * n // 10, 5),
