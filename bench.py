@@ -170,6 +170,9 @@ def main() -> int:
     trials = int(res["trials"].sum())
     trials_per_step = trials  # this rank's launch (the sums below are over all ranks)
 
+    per_rank_s = distributed.gather_times(dist, elapsed, device=reduce_device)
+    per_rank_kernel_ms = distributed.gather_times(dist, kernel_ms / args.steps, device=reduce_device)
+    per_rank_systems = distributed.gather_times(dist, float(n_sys), device=reduce_device)
     elapsed, (converged, accepted, trials, total_sys) = distributed.reduce_throughput(
         dist, elapsed, [converged, accepted, trials, n_sys], device=reduce_device)
 
@@ -198,6 +201,12 @@ def main() -> int:
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / steps,
+            # every rank's own clock around the K steps (the value above divides by the slowest), its solve kernel's mean
+            # launch time by HIP events, and its share of the Systems — both --scaling modes
+            "per_rank_ms": [round(s * 1e3 / steps, 4) for s in per_rank_s],
+            "per_rank_kernel_ms": [round(m, 4) for m in per_rank_kernel_ms],
+            "per_rank_systems": [int(x) for x in per_rank_systems],
+            "slowest_rank": int(max(range(len(per_rank_s)), key=lambda r: per_rank_s[r])),
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

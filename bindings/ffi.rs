@@ -15,7 +15,12 @@ use core::ffi::{c_char, c_int, c_void};
 
 pub const FX_OK: c_int = 0;
 pub const FX_ERR_INVALID: c_int = -1;
+pub const FX_ERR_NO_DEVICE: c_int = -2;
+pub const FX_ERR_HIP: c_int = -3;
+pub const FX_ERR_TOO_LARGE: c_int = -4;
+pub const FX_ERR_NOMEM: c_int = -5;           // out of memory inside a call: a code, never an abort (the process is intact)
 pub const FX_ERR_UNSUPPORTED: c_int = -6;
+pub const FX_ERR_INTERNAL: c_int = -7;        // any other C++ exception, caught at the boundary: nothing unwinds into Rust
 pub const FX_NO_COMPONENT: u16 = 0xFFFF;
 pub const FX_STEP_CHOLESKY: u32 = 0;          // fx_lm_opts.solver
 pub const FX_STEP_CHOLESKY_REFINED: u32 = 1;

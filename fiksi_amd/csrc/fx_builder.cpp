@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <set>
 #include <string>
@@ -18,9 +19,7 @@
 #include "../../include/fiksi_amd_builder.h"
 #include "fx_recursive.h"
 
-namespace fx {
-void set_last_error(const char* msg);  // fx_abi.cpp (fx_host_only.cpp in the sanitizer build): the text of fx_last_error()
-}
+#include "fx_guard.h"  // fx::set_last_error (fx_entry.cpp): the text of fx_last_error(); the guards of the entry points below
 
 namespace {
 
@@ -81,14 +80,30 @@ struct fxs_flat {
 
 namespace {
 
+struct FlatGuard {  // a flat batch made for the length of one call
+    fxs_flat* f;
+    ~FlatGuard() { delete f; }
+};
+
 std::atomic<uint32_t> g_system_counter{0};
 
 int valency_of(int tag) { return tag == FXS_POINT_POINT_COINCIDENCE ? 2 : 1; }
+
+// Room for k more entries, growing geometrically (reserve(size + k) alone would reallocate at every call): what follows a
+// successful make_room is push_backs that cannot throw, so a builder call either happens entirely or not at all.
+template <typename V>
+void make_room(V& v, size_t k) {
+    if (v.capacity() - v.size() < k) v.reserve(std::max(v.size() + k, 2 * v.capacity()));
+}
 
 // System::add_element, lib.rs:363-407 (+ Graph::add_element, graph.rs:160-176)
 int64_t add_element(fxs_system* s, int tag, const double* vars, int nvars, uint32_t a, uint32_t b) {
     uint32_t id = (uint32_t)s->elements.size();
     uint32_t variables_idx = (uint32_t)s->variables.size();
+    make_room(s->variables, (size_t)nvars);
+    make_room(s->variable_to_primitive, (size_t)nvars);
+    make_room(s->element_component, 1);
+    make_room(s->elements, 1);
     for (int i = 0; i < nvars; ++i) {
         s->variables.push_back(vars[i]);
         s->variable_to_primitive.push_back(id);
@@ -101,7 +116,8 @@ int64_t add_element(fxs_system* s, int tag, const double* vars, int nvars, uint3
 }
 
 // Graph::merge_connected_components, graph.rs:178-225 — including its behaviour of re-labelling
-// only the *incident* elements of an absorbed component.
+// only the *incident* elements of an absorbed component. The absorbed components' members are added to
+// the target in place; should that run out of memory half-way, what was added is taken out again and the graph is as before.
 void merge_components(fxs_system* s, uint32_t constraint, const uint32_t* els, int n) {
     int32_t target = 0;
     size_t size_largest = 0;
@@ -115,26 +131,49 @@ void merge_components(fxs_system* s, uint32_t constraint, const uint32_t* els, i
             }
         }
     }
-    if (target == 0) {
+    size_t incoming = (size_t)n + 1;
+    for (int i = 0; i < n; ++i) {
+        const int32_t ci = s->element_component[els[i]];
+        if (ci != 0 && ci != target) incoming += s->components[(size_t)ci - 1].elements.size() + s->components[(size_t)ci - 1].constraints.size();
+    }
+    std::vector<uint32_t> added_el, added_con;
+    added_el.reserve(incoming);
+    added_con.reserve(incoming);
+    const bool fresh = target == 0;
+    if (fresh) {
         s->components.emplace_back();
         target = (int32_t)s->components.size();
     }
-    Component tc = std::move(s->components[(size_t)target - 1]);
-    s->components[(size_t)target - 1] = Component();
+    Component& tc = s->components[(size_t)target - 1];
+    try {
+        for (int i = 0; i < n; ++i) {
+            const int32_t ci = s->element_component[els[i]];
+            if (ci != 0 && ci != target) {
+                const Component& c = s->components[(size_t)ci - 1];
+                for (uint32_t e : c.elements)
+                    if (tc.elements.insert(e).second) added_el.push_back(e);
+                for (uint32_t k : c.constraints)
+                    if (tc.constraints.insert(k).second) added_con.push_back(k);
+            } else if (ci == 0) {
+                if (tc.elements.insert(els[i]).second) added_el.push_back(els[i]);
+            }
+        }
+        if (tc.constraints.insert(constraint).second) added_con.push_back(constraint);
+    } catch (...) {
+        for (uint32_t e : added_el) tc.elements.erase(e);
+        for (uint32_t k : added_con) tc.constraints.erase(k);
+        if (fresh) s->components.pop_back();
+        throw;
+    }
+    // nothing below can throw
     for (int i = 0; i < n; ++i) {
-        int32_t ci = s->element_component[els[i]];
-        if (ci != 0) {
-            Component c = std::move(s->components[(size_t)ci - 1]);
-            s->components[(size_t)ci - 1] = Component();
-            tc.elements.insert(c.elements.begin(), c.elements.end());
-            tc.constraints.insert(c.constraints.begin(), c.constraints.end());
-        } else {
-            tc.elements.insert(els[i]);
+        const int32_t ci = s->element_component[els[i]];
+        if (ci != 0 && ci != target) {
+            s->components[(size_t)ci - 1].elements.clear();
+            s->components[(size_t)ci - 1].constraints.clear();
         }
         s->element_component[els[i]] = target;
     }
-    tc.constraints.insert(constraint);
-    s->components[(size_t)target - 1] = std::move(tc);
 }
 
 bool is_tag(const fxs_system* s, uint32_t el, int tag) { return el < s->elements.size() && s->elements[el].tag == tag; }
@@ -181,7 +220,7 @@ int expr_fields(uint8_t tag) {
 
 extern "C" {
 
-int fxs_system_new(fxs_system** out) {
+int fxs_system_new(fxs_system** out) try {
     if (!out) return FX_ERR_INVALID;
     fxs_system* s = new (std::nothrow) fxs_system();
     if (!s) return FX_ERR_NOMEM;
@@ -189,82 +228,100 @@ int fxs_system_new(fxs_system** out) {
     *out = s;
     return FX_OK;
 }
+FX_CATCH_CODE
 
-void fxs_system_free(fxs_system* s) { delete s; }
+void fxs_system_free(fxs_system* s) try { delete s; } FX_CATCH_VOID
 uint32_t fxs_system_id(const fxs_system* s) { return s ? s->id : 0; }
 uint32_t fxs_num_elements(const fxs_system* s) { return s ? (uint32_t)s->elements.size() : 0; }
 uint32_t fxs_num_constraints(const fxs_system* s) { return s ? (uint32_t)s->constraints.size() : 0; }
 uint32_t fxs_num_variables(const fxs_system* s) { return s ? (uint32_t)s->variables.size() : 0; }
 uint32_t fxs_num_expressions(const fxs_system* s) { return s ? (uint32_t)s->expressions.size() : 0; }
 
-int64_t fxs_length_create(fxs_system* s, double length) {  // elements/mod.rs:280-284
+int64_t fxs_length_create(fxs_system* s, double length) try {  // elements/mod.rs:280-284
     if (!s) return FX_ERR_INVALID;
     return add_element(s, FXS_LENGTH, &length, 1, 0, 0);
 }
+FX_CATCH_CODE
 
-int64_t fxs_point_create(fxs_system* s, double x, double y) {  // elements/mod.rs:321-325
+int64_t fxs_point_create(fxs_system* s, double x, double y) try {  // elements/mod.rs:321-325
     if (!s) return FX_ERR_INVALID;
     double v[2] = {x, y};
     return add_element(s, FXS_POINT, v, 2, 0, 0);
 }
+FX_CATCH_CODE
 
-int64_t fxs_line_create(fxs_system* s, uint32_t point1, uint32_t point2) {  // elements/mod.rs:365-382
+int64_t fxs_line_create(fxs_system* s, uint32_t point1, uint32_t point2) try {  // elements/mod.rs:365-382
     if (!s || !is_tag(s, point1, FXS_POINT) || !is_tag(s, point2, FXS_POINT)) return bfail(FX_ERR_INVALID, "Line::create needs two points");
     return add_element(s, FXS_LINE, nullptr, 0, s->elements[point1].a, s->elements[point2].a);
 }
+FX_CATCH_CODE
 
-int64_t fxs_circle_create(fxs_system* s, uint32_t center, uint32_t radius) {  // elements/mod.rs:437-454
+int64_t fxs_circle_create(fxs_system* s, uint32_t center, uint32_t radius) try {  // elements/mod.rs:437-454
     if (!s || !is_tag(s, center, FXS_POINT) || !is_tag(s, radius, FXS_LENGTH)) return bfail(FX_ERR_INVALID, "Circle::create needs a point and a length");
     return add_element(s, FXS_CIRCLE, nullptr, 0, s->elements[center].a, s->elements[radius].a);
 }
+FX_CATCH_CODE
 
-int fxs_element_tag_of(const fxs_system* s, uint32_t element) {
+int fxs_element_tag_of(const fxs_system* s, uint32_t element) try {
     if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
     return s->elements[element].tag;
 }
+FX_CATCH_CODE
 
-int fxs_element_fix(fxs_system* s, uint32_t element) {  // elements/mod.rs:60-65
+int fxs_element_fix(fxs_system* s, uint32_t element) try {  // elements/mod.rs:60-65
     if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
     uint32_t v[4];
     int n = element_variables(s, element, v);
-    for (int i = 0; i < n; ++i) s->fixed_variables.insert(v[i]);
+    bool added[4] = {false, false, false, false};
+    try {
+        for (int i = 0; i < n; ++i) added[i] = s->fixed_variables.insert(v[i]).second;
+    } catch (...) {  // (all of the element's variables or none)
+        for (int i = 0; i < n; ++i)
+            if (added[i]) s->fixed_variables.erase(v[i]);
+        throw;
+    }
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_element_unfix(fxs_system* s, uint32_t element) {  // elements/mod.rs:80-85
+int fxs_element_unfix(fxs_system* s, uint32_t element) try {  // elements/mod.rs:80-85
     if (!s || element >= s->elements.size()) return FX_ERR_INVALID;
     uint32_t v[4];
     int n = element_variables(s, element, v);
     for (int i = 0; i < n; ++i) s->fixed_variables.erase(v[i]);
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_element_get_value(const fxs_system* s, uint32_t element, double out[4]) {  // elements/mod.rs:88-100
+int fxs_element_get_value(const fxs_system* s, uint32_t element, double out[4]) try {  // elements/mod.rs:88-100
     if (!s || !out || element >= s->elements.size()) return FX_ERR_INVALID;
     uint32_t v[4];
     int n = element_variables(s, element, v);
     for (int i = 0; i < n; ++i) out[i] = s->variables[v[i]];
     return n;
 }
+FX_CATCH_CODE
 
-int fxs_point_update_value(fxs_system* s, uint32_t element, double x, double y) {  // elements/mod.rs:560-568
+int fxs_point_update_value(fxs_system* s, uint32_t element, double x, double y) try {  // elements/mod.rs:560-568
     if (!s || !is_tag(s, element, FXS_POINT)) return FX_ERR_INVALID;
     s->variables[s->elements[element].a] = x;
     s->variables[s->elements[element].a + 1] = y;
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_length_update_value(fxs_system* s, uint32_t element, double length) {  // elements/mod.rs:572-578
+int fxs_length_update_value(fxs_system* s, uint32_t element, double length) try {  // elements/mod.rs:572-578
     if (!s || !is_tag(s, element, FXS_LENGTH)) return FX_ERR_INVALID;
     s->variables[s->elements[element].a] = length;
     return FX_OK;
 }
+FX_CATCH_CODE
 
 int fxs_constraint_valency(int tag) { return (tag < 0 || tag > FXS_LINE_CIRCLE_TANGENCY) ? FX_ERR_INVALID : valency_of(tag); }
 
 // constraints::*::create, constraints/mod.rs:317-891: graph.add_constraint(valency, incident
 // primitive elements) then System::add_constraint(tag, expressions) (lib.rs:412-445).
-int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32_t n, double param) {
+int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32_t n, double param) try {
     if (!s || !el) return FX_ERR_INVALID;
     static const int kArgs[11][4] = {
         {FXS_POINT, FXS_POINT, -1, -1},                 // PointPointCoincidence
@@ -318,6 +375,8 @@ int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32
     }
 
     uint32_t cid = (uint32_t)s->constraints.size();
+    make_room(s->constraints, 1);  // (everything that can fail comes first: the call happens entirely or not at all)
+    make_room(s->expressions, 2);
     merge_components(s, cid, inc, ni);  // graph.rs:235-254
     uint32_t expressions_idx = (uint32_t)s->expressions.size();
     Constraint con{tag, expressions_idx, (uint8_t)ni, {0, 0, 0, 0, 0, 0}};
@@ -351,14 +410,16 @@ int64_t fxs_constraint_create(fxs_system* s, int tag, const uint32_t* el, uint32
     }
     return cid;
 }
+FX_CATCH_CODE
 
-int fxs_constraint_tag_of(const fxs_system* s, uint32_t constraint) {
+int fxs_constraint_tag_of(const fxs_system* s, uint32_t constraint) try {
     if (!s || constraint >= s->constraints.size()) return FX_ERR_INVALID;
     return s->constraints[constraint].tag;
 }
+FX_CATCH_CODE
 
 // ConstraintHandle::update_parameter, constraints/mod.rs:992-1046 (the four parameterised kinds)
-int fxs_constraint_update_parameter(fxs_system* s, uint32_t constraint, double value) {
+int fxs_constraint_update_parameter(fxs_system* s, uint32_t constraint, double value) try {
     if (!s || constraint >= s->constraints.size()) return FX_ERR_INVALID;
     const Constraint& c = s->constraints[constraint];
     switch (c.tag) {
@@ -372,8 +433,9 @@ int fxs_constraint_update_parameter(fxs_system* s, uint32_t constraint, double v
             return FX_ERR_INVALID;
     }
 }
+FX_CATCH_CODE
 
-int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* element_comp, uint16_t* constraint_comp) {
+int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* element_comp, uint16_t* constraint_comp) try {
     if (!s) return FX_ERR_INVALID;
     std::vector<const Component*> live;
     live_components(s, live);
@@ -390,9 +452,10 @@ int fxs_components(const fxs_system* s, uint32_t* n_components, uint16_t* elemen
     }
     return FX_OK;
 }
+FX_CATCH_CODE
 
 int fxs_export_graph(const fxs_system* s, uint8_t* element_kind, uint32_t* element_idx, uint8_t* constraint_valency,
-                     uint32_t* constraint_expr, uint8_t* constraint_n_incident, uint32_t* constraint_incident) {
+                     uint32_t* constraint_expr, uint8_t* constraint_n_incident, uint32_t* constraint_incident) try {
     if (!s) return FX_ERR_INVALID;
     for (size_t i = 0; i < s->elements.size(); ++i) {
         if (element_kind) element_kind[i] = (uint8_t)s->elements[i].tag;
@@ -408,8 +471,9 @@ int fxs_export_graph(const fxs_system* s, uint8_t* element_kind, uint32_t* eleme
     }
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_recursive_plan(const fxs_system* s, uint64_t budget, uint32_t* out, uint32_t capacity, uint32_t* length, uint32_t* flags) {
+int fxs_recursive_plan(const fxs_system* s, uint64_t budget, uint32_t* out, uint32_t capacity, uint32_t* length, uint32_t* flags) try {
     if (!s || !length) return FX_ERR_INVALID;
     std::vector<const Component*> live;
     live_components(s, live);
@@ -430,20 +494,19 @@ int fxs_recursive_plan(const fxs_system* s, uint64_t budget, uint32_t* out, uint
         for (size_t i = 0; i < words.size() && i < capacity; ++i) out[i] = words[i];
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out) {
+int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out) try {
     if (!out || (n && !systems)) return FX_ERR_INVALID;
-    fxs_flat* f = new (std::nothrow) fxs_flat();
+    std::unique_ptr<fxs_flat> hold(new (std::nothrow) fxs_flat());  // (freed on every early way out, by code or by exception)
+    fxs_flat* f = hold.get();
     if (!f) return FX_ERR_NOMEM;
     f->var_off.push_back(0);
     f->expr_off.push_back(0);
     std::vector<const Component*> live;
     for (uint32_t k = 0; k < n; ++k) {
         const fxs_system* s = systems[k];
-        if (!s) {
-            delete f;
-            return FX_ERR_INVALID;
-        }
+        if (!s) return FX_ERR_INVALID;
         size_t v0 = f->vars.size(), e0 = f->expr_tag.size();
         f->vars.insert(f->vars.end(), s->variables.begin(), s->variables.end());
         f->var_fixed.resize(v0 + s->variables.size(), 0);
@@ -458,10 +521,7 @@ int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out) {
         // assemble/mod.rs:91-111: a component's variables are those of its elements;
         // :136-145: its rows are the expressions of its constraints.
         live_components(s, live);
-        if (live.size() >= 0x7FFF) {
-            delete f;
-            return FX_ERR_TOO_LARGE;
-        }
+        if (live.size() >= 0x7FFF) return FX_ERR_TOO_LARGE;
         for (size_t c = 0; c < live.size(); ++c) {
             for (uint32_t e : live[c]->elements) {
                 uint32_t v[4];
@@ -486,14 +546,15 @@ int fxs_flatten(const fxs_system* const* systems, uint32_t n, fxs_flat** out) {
     f->batch.expr_param = f->expr_param.data();
     f->batch.var_comp = f->var_comp.data();
     f->batch.expr_comp = f->expr_comp.data();
-    *out = f;
+    *out = hold.release();
     return FX_OK;
 }
+FX_CATCH_CODE
 
 const fx_batch* fxs_flat_batch(const fxs_flat* f) { return f ? &f->batch : nullptr; }
-void fxs_flat_free(fxs_flat* f) { delete f; }
+void fxs_flat_free(fxs_flat* f) try { delete f; } FX_CATCH_VOID
 
-int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) {
+int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) try {
     if (!f || (n && !systems) || n != f->batch.n_systems) return FX_ERR_INVALID;
     for (uint32_t k = 0; k < n; ++k) {
         fxs_system* s = systems[k];
@@ -503,6 +564,7 @@ int fxs_flat_scatter(const fxs_flat* f, fxs_system* const* systems, uint32_t n) 
     }
     return FX_OK;
 }
+FX_CATCH_CODE
 
 }  // extern "C"
 
@@ -760,7 +822,7 @@ int solve_recursive_assembly(fxs_system* const* systems, uint32_t n_sys, fx_ctx*
 extern "C" {
 
 int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const fx_solving_opts* opts,
-                      fx_result* results) {
+                      fx_result* results) try {
     if (opts && opts->decomposer == 2) {
         // RecursiveAssembly plans from a System's elements; Systems of one structure (one sketch, many parameter sets)
         // share the plan and every device call — groups in order of their first System
@@ -809,26 +871,28 @@ int fxs_systems_solve(fxs_system* const* systems, uint32_t n, fx_ctx* ctx, const
     fxs_flat* f = nullptr;
     int rc = fxs_flatten(systems, n, &f);
     if (rc) return rc;
+    FlatGuard guard{f};
     rc = fx_system_solve_batch(ctx, &f->batch, opts, results);
     if (!rc) rc = fxs_flat_scatter(f, systems, n);
-    fxs_flat_free(f);
     return rc;
 }
+FX_CATCH_CODE
 
-int fxs_system_solve(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result) {
+int fxs_system_solve(fxs_system* s, fx_ctx* ctx, const fx_solving_opts* opts, fx_result* result) try {
     fxs_system* one[1] = {s};
     return fxs_systems_solve(one, 1, ctx, opts, result);
 }
+FX_CATCH_CODE
 
-int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* out) {
+int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* out) try {
     if (!s || !out) return FX_ERR_INVALID;
     const fxs_system* one[1] = {s};
     fxs_flat* f = nullptr;
     int rc = fxs_flatten(one, 1, &f);
     if (rc) return rc;
+    FlatGuard guard{f};
     std::vector<double> r(s->expressions.size() + 1, 0.);
     rc = fx_constraint_residuals(ctx, &f->batch, r.data());
-    fxs_flat_free(f);
     if (rc) return rc;
     for (size_t c = 0; c < s->constraints.size(); ++c) {
         const Constraint& con = s->constraints[c];
@@ -845,16 +909,17 @@ int fxs_system_constraint_residuals(const fxs_system* s, fx_ctx* ctx, double* ou
     }
     return FX_OK;
 }
+FX_CATCH_CODE
 
-int fxs_system_analyze(const fxs_system* s, fx_ctx* ctx, uint32_t* ids, uint32_t* n) {
+int fxs_system_analyze(const fxs_system* s, fx_ctx* ctx, uint32_t* ids, uint32_t* n) try {
     if (!s || !ids || !n) return FX_ERR_INVALID;
     const fxs_system* one[1] = {s};
     fxs_flat* f = nullptr;
     int rc = fxs_flatten(one, 1, &f);
     if (rc) return rc;
+    FlatGuard guard{f};
     std::vector<uint8_t> dep(s->expressions.size() + 1, 0);
     rc = fx_analyze_batch(ctx, &f->batch, dep.data());
-    fxs_flat_free(f);
     if (rc) return rc;
     // expression -> constraint (System::expression_to_constraint, lib.rs:301-302)
     uint32_t count = 0;
@@ -866,5 +931,6 @@ int fxs_system_analyze(const fxs_system* s, fx_ctx* ctx, uint32_t* ids, uint32_t
     *n = count;
     return FX_OK;
 }
+FX_CATCH_CODE
 
 }  // extern "C"

@@ -152,8 +152,9 @@ struct DeviceBatch {
     uint32_t gc_rc;                       // ... and its chunks of 16 expressions: gc_nc, or twice that for an over-constrained structure
     const GcClass* gc_classes;            // a launch over several structure classes (null: one program, the whole batch)
     uint32_t gc_nclasses;
-    // the program of its sparse build (fx_grouped_s.hip; build_gs_program): uniform batches with one component of 49 ... 128 free
-    // variables whose Cholesky factor has at most 1023 entries; null otherwise
+    // the program of its sparse build (fx_grouped_s.hip; build_gs_program): uniform batches with one component of 33 ... 255 free
+    // variables (33 ... 48: a factor of at most a quarter of the dense triangle), at most 255 variables / expressions, a Cholesky
+    // factor of at most 1023 slots and at most 1023 compact Jacobian entries; null otherwise
     uint32_t* gs_tab;
     uint32_t gs_words, gs_nl, gs_ng, gs_nfree;  // words; slots of the factor (even); compact Jacobian entries (even); free variables
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
@@ -215,7 +216,7 @@ size_t grouped_lds_bytes(const DeviceBatch& b, uint32_t element_size, bool singl
 bool grouped_c_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t element_size);
-// ... and its sparse build for batches of one structure of 49 ... 128 free variables with a small factor (fx_grouped_s.hip)
+// ... and its sparse build for batches of one structure of 33 ... 255 free variables with a small factor (fx_grouped_s.hip)
 bool grouped_s_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_grouped_s(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components

@@ -1,5 +1,5 @@
 // Grouped fused solve, the SPARSE build for batches of one structure (gfx950, wave64): four Systems per wavefront, one per row
-// of 16 lanes, for components too wide for a register-resident factor (49 ... 128 free variables) whose Cholesky factor is small —
+// of 16 lanes, for components too wide for a register-resident factor (33 ... 255 free variables: from 33 on when the factor is sparse, always from 49 on) whose Cholesky factor is small —
 // the reference's bench sketch of 16 hinged triangles (fiksi_bench.rs:15-40, 46-73) has 66 variables, 48 distances, and a factor
 // of 291 entries under a minimum-degree order: a dense 66 x 66 factorisation would do eight times the work, and the team kernels
 // of the sparse path (one workgroup per System, a wavefront walking a column at a time through barriers) take 54 us per trial of it.

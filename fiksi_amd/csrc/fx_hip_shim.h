@@ -41,11 +41,23 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::strcpy(p->gcnArchName, "gfx950");
     return hipSuccess;
 }
+// (live blocks of the make-believe device: the allocation-failure sweep checks that a failed call gives everything back)
+inline long& fx_shim_live_blocks() {
+    static long live = 0;
+    return live;
+}
 inline hipError_t hipMalloc(void** p, size_t n) {
     *p = fx_shim_fake() ? std::malloc(n ? n : 1) : nullptr;
+    if (*p) __atomic_add_fetch(&fx_shim_live_blocks(), 1, __ATOMIC_RELAXED);
     return *p ? hipSuccess : (fx_shim_fake() ? hipErrorOutOfMemory : hipErrorNoDevice);
 }
-inline hipError_t hipFree(void* p) { if (fx_shim_fake()) std::free(p); return hipSuccess; }
+inline hipError_t hipFree(void* p) {
+    if (fx_shim_fake() && p) {
+        std::free(p);
+        __atomic_sub_fetch(&fx_shim_live_blocks(), 1, __ATOMIC_RELAXED);
+    }
+    return hipSuccess;
+}
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {

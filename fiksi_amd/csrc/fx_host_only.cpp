@@ -1,8 +1,12 @@
 // `make asan`: the library's host-side logic as a plain g++ translation unit with -fsanitize=address,undefined.
-// fx_abi.cpp is compiled as it is against the stubs of fx_hip_shim.h; the kernel launchers it calls are defined
+// The host sources (fx_analyze / fx_programs / fx_upload / fx_solve / fx_entry .cpp) are compiled as they are against the stubs of fx_hip_shim.h; the kernel launchers it calls are defined
 // here as "no device" stubs, and the sparse path's entry points likewise. Test infrastructure, not a product path.
 #define FX_HOST_ONLY 1
-#include "fx_abi.cpp"
+#include "fx_analyze.cpp"
+#include "fx_programs.cpp"
+#include "fx_upload.cpp"
+#include "fx_solve.cpp"
+#include "fx_entry.cpp"
 
 namespace fx {
 hipError_t launch_solve(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
@@ -46,3 +50,49 @@ hipError_t sparse_solve_group(const fx_batch*, const DeviceBatch&, const uint32_
     return hipErrorNoDevice;
 }
 }  // namespace fx
+
+// ---- allocation-failure injection (tools/alloc_fail_sweep.py, tests/test_host_sanitizers.py) ----------------------------
+// This build's own operator new / delete (bound inside the library: -Wl,-Bsymbolic-functions): they count, and the n-th
+// allocation after fx_test_fail_alloc_at(n) fails — std::bad_alloc from the throwing forms, NULL from the nothrow ones —
+// so that a test can walk a failure through every allocation of an entry point and see an error code come back, the process
+// alive, and nothing kept: no block of host memory (fx_test_live_allocations), no block of the make-believe device
+// (fx_test_live_device_blocks). The memory still comes from malloc, so AddressSanitizer sees every byte.
+namespace {
+long g_fail_countdown = 0;  // 0: off
+long g_alloc_count = 0;
+long g_live = 0;
+void* counted_alloc(size_t n, bool nothrow) {
+    __atomic_add_fetch(&g_alloc_count, 1, __ATOMIC_RELAXED);
+    if (__atomic_load_n(&g_fail_countdown, __ATOMIC_RELAXED) > 0 && __atomic_sub_fetch(&g_fail_countdown, 1, __ATOMIC_RELAXED) == 0) {
+        if (nothrow) return nullptr;
+        throw std::bad_alloc();
+    }
+    void* p = std::malloc(n ? n : 1);
+    if (!p) {
+        if (nothrow) return nullptr;
+        throw std::bad_alloc();
+    }
+    __atomic_add_fetch(&g_live, 1, __ATOMIC_RELAXED);
+    return p;
+}
+void counted_free(void* p) noexcept {
+    if (!p) return;
+    __atomic_sub_fetch(&g_live, 1, __ATOMIC_RELAXED);
+    std::free(p);
+}
+}  // namespace
+void* operator new(size_t n) { return counted_alloc(n, false); }
+void* operator new[](size_t n) { return counted_alloc(n, false); }
+void* operator new(size_t n, const std::nothrow_t&) noexcept { return counted_alloc(n, true); }
+void* operator new[](size_t n, const std::nothrow_t&) noexcept { return counted_alloc(n, true); }
+void operator delete(void* p) noexcept { counted_free(p); }
+void operator delete[](void* p) noexcept { counted_free(p); }
+void operator delete(void* p, size_t) noexcept { counted_free(p); }
+void operator delete[](void* p, size_t) noexcept { counted_free(p); }
+
+extern "C" {
+void fx_test_fail_alloc_at(long n) { __atomic_store_n(&g_fail_countdown, n, __ATOMIC_RELAXED); }
+long fx_test_alloc_count(void) { return __atomic_load_n(&g_alloc_count, __ATOMIC_RELAXED); }
+long fx_test_live_allocations(void) { return __atomic_load_n(&g_live, __ATOMIC_RELAXED); }
+long fx_test_live_device_blocks(void) { return __atomic_load_n(&fx_shim_live_blocks(), __ATOMIC_RELAXED); }
+}

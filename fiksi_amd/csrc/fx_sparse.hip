@@ -268,6 +268,7 @@ struct Arena {
             }
         void* d = nullptr;
         const size_t size = std::max<size_t>(bytes, size_t(4) << 20);
+        chunks.reserve(chunks.size() + 1);  // (so that the chunk cannot be lost between hipMalloc and the list)
         err = hipMalloc(&d, size);
         if (err != hipSuccess) return nullptr;
         chunks.push_back({static_cast<char*>(d), size});
@@ -562,21 +563,24 @@ hipError_t launch_team_t(uint32_t n, size_t lds_bytes, hipStream_t stream, const
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint32_t bit = 1u << (dev & 31);
-    if (LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)TEAM_LDS_VALUES_MAX);
-        if (e != hipSuccess) return e;
-        raised_on.fetch_or(bit, std::memory_order_relaxed);
-    }
     // a narrow team's partial sums of team_sumsq: a power of two that covers the block's rows and columns, behind the rest
+    // (up to 8 KB — the sixteen-wavefront team keeps them in a static buffer of that size)
+    constexpr size_t RED_MAX = NW != TEAM_NWAVES ? size_t(TEAM_THREADS) * 8u : 0u;
     uint32_t red_n = 0, red_off = 0;
     if (NW != TEAM_NWAVES) {
         red_n = 64u;
         while (red_n < std::max(B.m, B.nv) && red_n < (uint32_t)TEAM_THREADS) red_n <<= 1;
         red_off = (uint32_t)((lds_bytes + 7u) / 8u);
         lds_bytes = (size_t)red_off * 8u + (size_t)red_n * 8u;
-        if (lds_bytes > TEAM_LDS_VALUES_MAX + 8192u) return hipErrorInvalidValue;
-        if (!LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) raised_on.fetch_or(bit, std::memory_order_relaxed);
+        if (lds_bytes > TEAM_LDS_VALUES_MAX + RED_MAX) return hipErrorInvalidValue;
+    }
+    // the function's dynamic-LDS limit covers everything a launch of this instantiation may ask for: the values (the caller
+    // takes the LDSV build up to TEAM_LDS_VALUES_MAX) AND a narrow team's sums behind them
+    if (LDSV && !(raised_on.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sp_lm_team_kernel<POSE, LDSV, BLOB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(TEAM_LDS_VALUES_MAX + RED_MAX));
+        if (e != hipSuccess) return e;
+        raised_on.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((sp_lm_team_kernel<POSE, LDSV, BLOB, NW>), dim3(n), dim3(64 * NW), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off,
                        lds_l, lds_v, blob, blob_words, prof, red_off, red_n);

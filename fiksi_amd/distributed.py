@@ -4,7 +4,7 @@ the max-over-ranks time, done with torch.distributed (backend "nccl" == RCCL ove
 box, "gloo" in the CPU tests)."""
 from __future__ import annotations
 
-from typing import Dict, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 
 def rank_seed(base_seed: int, rank: int, systems_per_rank: int) -> int:
@@ -26,6 +26,14 @@ def reduce_throughput(dist, elapsed_s: float, counters: Sequence[int], device=No
     return float(t.item()), [int(x) for x in c.tolist()]
 
 
-def throughput(total_counters: Dict[str, int], steps: int, elapsed_s: float) -> Dict[str, float]:
-    """Whole-job rates from the summed per-step counters."""
-    return {k: v * steps / elapsed_s for k, v in total_counters.items()}
+def gather_times(dist, elapsed_s: float, device=None) -> List[float]:
+    """Every rank's elapsed time, in rank order, on every rank (a one-element list without a process group): an N-GPU run is
+    as slow as its slowest rank, and the bench line says which one that was."""
+    if dist is None or not dist.is_initialized():
+        return [float(elapsed_s)]
+    import torch
+
+    mine = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
+    everyone = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
+    dist.all_gather(everyone, mine)
+    return [float(x.item()) for x in everyone]

@@ -50,8 +50,10 @@ typedef enum fx_status {
     FX_ERR_NO_DEVICE = -2,   /* no usable HIP device (no CPU fallback exists)                   */
     FX_ERR_HIP = -3,         /* a HIP runtime call failed; see fx_last_error                    */
     FX_ERR_TOO_LARGE = -4,   /* a system exceeds FX_MAX_LARGE_SYSTEM_VARS                       */
-    FX_ERR_NOMEM = -5,
-    FX_ERR_UNSUPPORTED = -6
+    FX_ERR_NOMEM = -5,       /* host or device memory ran out; the call had no effect that must be undone */
+    FX_ERR_UNSUPPORTED = -6,
+    FX_ERR_INTERNAL = -7     /* anything else that went wrong inside the library (a C++ exception caught at
+                                the boundary); the process is intact, see fx_last_error                    */
 } fx_status;
 
 /* Variant order of `enum Expression`, fiksi/src/constraints/expressions.rs:28-40. */
@@ -238,11 +240,18 @@ int fx_ctx_set_presort(fx_ctx* ctx, int enable, uint32_t min_systems);
 int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
 /* Batches whose Systems all have ONE structure (one component) run builds of the grouped kernel made for them: up to 48 free
  * variables fx_grouped_c.hip (the structure's lists shared by a wavefront, Jt J by its pattern, up to four wavefronts per SIMD:
- * the same bits as the general build), 49 ... 255 free variables with a Cholesky factor of at most 1023 entries fx_grouped_s.hip
+ * the same bits as the general build); 33 ... 255 free variables — from 33 on when the Cholesky factor has at most a quarter of the
+ * dense triangle's entries, always from 49 on; at most 255 variables and 255 expressions, a factor of at most 1023 slots, at most
+ * 1023 compact Jacobian entries — fx_grouped_s.hip
  * (the factorisation as a level schedule over tables in LDS: the normal-equation step in a minimum-degree order — the same
  * counters as the team / wide kernels such batches took before, variables to round-off). enable = 0 keeps such batches on the
  * general paths (default 1; a context created under FIKSI_AMD_GROUPED_C=0 starts with 0). fx_debug_grouped_build tells. */
 int fx_ctx_set_one_structure_builds(fx_ctx* ctx, int enable);
+/* (These builds need a batch — or, under fx_system_solve_batch_multi, a SHARD — of at least 8 Systems (2 for fx_grouped_c.hip's
+ * one-structure detection). fx_grouped_c.hip gives the general build's bits, so its routing never shows; fx_grouped_s.hip sums in a
+ * minimum-degree order and agrees with the team / wide kernels to round-off only, so a shard of fewer than 8 Systems of 33 ... 255
+ * variables each takes another kernel than its siblings and differs from them in the last bits. Shards that small mean more
+ * devices than work; pin fx_ctx_set_one_structure_builds(ctx, 0) on every context if the last bits must not depend on it.) */
 /* Grouped kernel, the lambda ladder. The trials that follow a rejected trial of the reference's loop (lm.rs:187-190) read
  * the same point, Jacobian and residuals and differ in lambda only (x 2 each), so a row of a wavefront that has no System
  * of its own tries the next lambda of a System that is still running in its wavefront, in the same pass: up to four
@@ -334,8 +343,9 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
 /* Diagnostic only: which BUILD of the grouped kernel such a launch would be: -1 = not the grouped kernel, 0 = the general build
  * (one wavefront per SIMD for components of 17 ... 32 free variables), 1 = the build for batches of one structure
  * (fx_grouped_c.hip: the structure's lists shared by a wavefront's four Systems, Jt J by its pattern, two wavefronts per
- * SIMD for that shape; same bits), 2 = the sparse build for batches of one structure with a component of 49 ... 128 free
- * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS).
+ * SIMD for that shape; same bits), 2 = the sparse build for batches of one structure with a component of 33 ... 255 free
+ * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS; the limits:
+ * fx_ctx_set_one_structure_builds).
  * 3 = a batch of SEVERAL structures whose big structure classes (2 048 Systems and more, up to eight) run build 1 in one launch,
  * everyone else the general build. A context created under FIKSI_AMD_GROUPED_C=0 takes none of 1, 2, 3. Launches nothing. */
 int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);

@@ -15,6 +15,11 @@ def cfg3(fiksi, ctx):
     from fiksi_amd import workloads
 
     b = workloads.ring16(N)
+    db = ctx.upload(b)
+    # the headline batch runs on lm_solve_grouped_c_kernel (fx_grouped_c.hip), and the oracle comparisons below are about THAT
+    # kernel: a routing change must fail here, not silently move them elsewhere
+    assert db.grouped_build() == 1
+    db.free()
     v, res = ctx.system_solve_batch(b)
     return b, v, res
 

@@ -138,14 +138,25 @@ def test_single_pass_blocks_on_the_grouped_kernel(fiksi, oracle, ctx, routing, s
         assert np.all(d <= 1e-9 + 0.25 * np.abs(r0["sse"][same & ok]))
 
 
-def test_against_the_oracle_on_the_headline_shape(fiksi, oracle, ctx, routing):
-    """The comparison tests/test_gpu_parity.py makes for the one-System-per-wavefront kernel, on the grouped one."""
+@pytest.mark.parametrize("build", [0, 1])
+def test_against_the_oracle_on_the_headline_shape(fiksi, oracle, ctx, routing, build):
+    """The comparison tests/test_gpu_parity.py makes for the one-System-per-wavefront kernel, on the grouped one — on its
+    general build (fx_grouped.hip, build 0) and on the build for batches of one structure the headline batch takes
+    (fx_grouped_c.hip, build 1), each asserted BY NAME through fx_debug_grouped_build before the solve that is compared."""
     from fiksi_amd import workloads
     from test_gpu_parity import _compare_solves
 
     b = workloads.ring16(2048)
     routing("1")
-    v, res = _solve(ctx, b)
+    ctx.set_one_structure_builds(bool(build))
+    try:
+        db = ctx.upload(b)
+        assert db.grouped_build() == build
+        db.system_solve()
+        v, res = db.get_vars().copy(), db.get_results().copy()
+        db.free()
+    finally:
+        ctx.set_one_structure_builds(True)
     v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
     assert np.array_equal(res["scale"], res_o["scale"])  # K0: bit-identical
     _compare_solves(res, res_o, v, v_o, b, oracle)

@@ -203,3 +203,66 @@ def test_over_constrained_structures_take_the_instantiations_with_twice_the_rows
     v1, r1 = ctx.system_solve_batch(b, o)
     v0, r0 = ctx_general.system_solve_batch(b, o)
     assert np.array_equal(_bits(v1), _bits(v0)) and r1.tobytes() == r0.tobytes()
+
+
+def _solve_on_build(ctx, b, o, want_build):
+    """Upload, make sure the solve WILL take the build this test is about (fx_debug_grouped_build), solve resident."""
+    db = ctx.upload(b)
+    try:
+        assert db.grouped_build(o) == want_build, (db.grouped_build(o), want_build)
+        db.system_solve(o)
+        return db.get_vars(), db.get_results()
+    finally:
+        db.free()
+
+
+@pytest.mark.parametrize("case", ["c1_hinged_1", "c1_hinged_3", "c_ring16", "c_ring16_fixed_gauge", "c_every_kind", "c3_ring20_chords",
+                                  "cr_16_points_45_rows", "c1r_8_points_23_rows"])
+def test_each_instantiation_against_the_oracle_directly(fiksi, oracle, ctx, case):
+    """The one-structure instantiations (one / two / three columns per lane, and those with twice the row chunks) are held to
+    the ORACLE here, not to another kernel: every System of the batch through tests/helpers.py: compare_outcomes with the tight
+    bars (same path -> |dSSE| <= 1e-10 + 1e-6 SSE and per-constraint residuals; otherwise the same verdict), and
+    the test first asserts — by name, through fx_debug_grouped_build — that the solve it is about to check runs on
+    lm_solve_grouped_c*_kernel, so that a routing change cannot move the comparison off this kernel unnoticed."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import compare_outcomes
+    from test_gpu_grouped_s import _random_graph_batch
+
+    b = {"c1_hinged_1": lambda: workloads.hinged_triangles(1500, 1), "c1_hinged_3": lambda: workloads.hinged_triangles(1200, 3),
+         "c_ring16": lambda: workloads.ring16(3000), "c_ring16_fixed_gauge": lambda: workloads.ring16(1500, fix_gauge=True),
+         "c_every_kind": lambda: _mixed_uniform(800, False), "c3_ring20_chords": lambda: workloads.ring_chords(600, 20, 7),
+         "cr_16_points_45_rows": lambda: _random_graph_batch(400, 16, 30, 351, fix_first=False, angles=2),
+         "c1r_8_points_23_rows": lambda: _random_graph_batch(400, 8, 16, 337, fix_first=False, angles=2)}[case]()
+    o = abi.solving_opts()
+    v, res = _solve_on_build(ctx, b, o, 1)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    same, verdict = compare_outcomes(b, v, res, v_o, res_o, oracle, tight=True)
+    floor = 0.9 if case in ("c_every_kind", "cr_16_points_45_rows", "c1r_8_points_23_rows") else 0.97
+    assert same >= floor and verdict >= 0.995, (case, same, verdict)
+
+
+@pytest.mark.parametrize("case", ["ring16", "ring16_inconsistent", "16_points_45_rows"])
+def test_the_f32_instantiations_against_the_oracle_directly(fiksi, oracle, ctx, case):
+    """lm_solve_grouped_c_f32_kernel / ..._cr_f32_kernel (asserted by name) against the f64 oracle with cfg5's stated f32
+    tolerances (tests/test_gpu_parity.py): the same verdict on >= 99 % of the Systems; final scaled SSE within 1e-3 relative
+    (+ 1e-7) on 95 % — within 1e-4 relative where no System reaches zero residual."""
+    from fiksi_amd import abi, workloads
+
+    from test_gpu_grouped_s import _random_graph_batch
+
+    b = {"ring16": lambda: workloads.ring16(2048), "ring16_inconsistent": lambda: workloads.ring16(2048, inconsistent=True),
+         "16_points_45_rows": lambda: _random_graph_batch(400, 16, 30, 351, fix_first=False, angles=2)}[case]()
+    o = abi.solving_opts(f32=True)
+    v, res = _solve_on_build(ctx, b, o, 1)
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    assert np.array_equal(res["scale"], res_o["scale"])  # K0 stays f64
+    n = len(res)
+    r_o = oracle.residuals_batch(b, v_o).reshape(n, -1)
+    assert ((res["sse_unscaled"] < 1e-4) == ((r_o * r_o).sum(1) < 1e-4)).mean() >= 0.99
+    if case == "ring16_inconsistent":
+        rel = np.abs(res["sse"] - res_o["sse"]) / res_o["sse"]
+        assert np.percentile(rel, 95) <= 1e-4 and np.median(rel) <= 1e-5
+    else:
+        rel = np.abs(res["sse"] - res_o["sse"]) / (1e-7 + res_o["sse"])
+        assert np.percentile(rel, 95) <= 1e-3

@@ -126,6 +126,9 @@ def test_system_solve_ring16_matches_oracle(fiksi, oracle, ctx):
     from fiksi_amd import workloads
 
     b = workloads.ring16(2048)
+    db = ctx.upload(b)
+    assert db.grouped_build() == 1  # (the default route of this batch: the grouped kernel's one-structure build, fx_grouped_c.hip)
+    db.free()
     v, res = ctx.system_solve_batch(b)
     v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
     _compare_solves(res, res_o, v, v_o, b, oracle)
