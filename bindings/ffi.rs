@@ -103,6 +103,7 @@ extern "C" {
     pub fn fx_ctx_set_one_structure_builds(ctx: *mut fx_ctx, enable: c_int) -> c_int;
     pub fn fx_ctx_set_ladder(ctx: *mut fx_ctx, enable: c_int, tail_systems: u32, min_trials: u32, spread: c_int) -> c_int;
     pub fn fx_ctx_set_wide_routing(ctx: *mut fx_ctx, wide: c_int) -> c_int;
+    pub fn fx_ctx_set_sparse_fronts(ctx: *mut fx_ctx, enable: c_int, ranks: u32) -> c_int;
     pub fn fx_ctx_set_host_threads(ctx: *mut fx_ctx, threads: u32) -> c_int;
     pub fn fx_ctx_synchronize(ctx: *mut fx_ctx) -> c_int;
     pub fn fx_ctx_device_name(ctx: *mut fx_ctx, buf: *mut c_char, len: usize) -> c_int;

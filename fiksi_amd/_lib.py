@@ -109,6 +109,7 @@ SIGNATURES = [
     ("fx_ctx_set_one_structure_builds", C.c_int, [_vp, C.c_int]),
     ("fx_ctx_set_ladder", C.c_int, [_vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int]),
     ("fx_ctx_set_wide_routing", C.c_int, [_vp, C.c_int]),
+    ("fx_ctx_set_sparse_fronts", C.c_int, [_vp, C.c_int, C.c_uint32]),
     ("fx_ctx_set_host_threads", C.c_int, [_vp, C.c_uint32]),
     ("fx_ctx_synchronize", C.c_int, [_vp]),
     ("fx_ctx_device_name", C.c_int, [_vp, C.c_char_p, C.c_size_t]),

@@ -220,6 +220,11 @@ class Context:
         """Components of 65 ... 128 free variables: 1 wide kernel, 0 team kernels, -1 by cost (fx_ctx_set_wide_routing)."""
         check(lib.fx_ctx_set_wide_routing(self._h, wide), "fx_ctx_set_wide_routing")
 
+    def set_sparse_fronts(self, enable: bool = True, ranks: int = 0):
+        """Systems beyond one wavefront: the multifrontal build where the structure allows it (default), or the column walkers;
+        ranks: lambda trials per launch of a large System alone (0: by the room on the chip, at most 4)."""
+        check(lib.fx_ctx_set_sparse_fronts(self._h, 1 if enable else 0, ranks), "fx_ctx_set_sparse_fronts")
+
     def set_host_threads(self, threads: int = 0):
         """Host threads for the sparse path's loops when a batch holds several large Systems (fx_ctx_set_host_threads)."""
         check(lib.fx_ctx_set_host_threads(self._h, threads), "fx_ctx_set_host_threads")

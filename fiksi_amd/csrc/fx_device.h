@@ -178,6 +178,10 @@ struct LmParams {
     // queue is empty; 0xFFFFFFFF: the launcher's default, eight Systems per resident row). spread: nonzero = the first round
     // of tickets of a scheduled hand-out is dealt one per wavefront (the launcher puts the number of wavefronts there).
     uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, spread = 1u;
+    // Systems beyond one wavefront: the multifrontal build (fx_front.h) where the structure's fronts fit a row of 16 lanes;
+    // 0 keeps the column walkers of fx_sparse_team.h (fx_ctx_set_sparse_fronts)
+    uint32_t sparse_fronts = 1u;
+    uint32_t sparse_front_ranks = 0u;  // lambda trials a launch of its parts + top kernels makes side by side (0: as many as the chip has room for, at most 4)
 };
 
 #ifndef FX_HOST_ONLY

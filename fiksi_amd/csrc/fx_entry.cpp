@@ -173,6 +173,15 @@ int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide) try {
 }
 FX_CATCH_CODE
 
+int fx_ctx_set_sparse_fronts(fx_ctx* ctx, int enable, uint32_t ranks) try {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    if (ranks > 4u) return fail(FX_ERR_INVALID, "ranks must be 0 (by the room on the chip) ... 4");
+    ctx->sparse_fronts = enable ? 1u : 0u;
+    ctx->sparse_front_ranks = ranks;
+    return FX_OK;
+}
+FX_CATCH_CODE
+
 int fx_ctx_set_host_threads(fx_ctx* ctx, uint32_t threads) try {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
     ctx->host_threads = threads ? std::min(threads, 64u) : 8u;

@@ -153,6 +153,7 @@ struct fx_ctx {
     uint32_t hold_passes = 2u;             // fx_ctx_set_hold_passes
     uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, ladder_spread = 1u;  // fx_ctx_set_ladder
     int wide_routing = -1;                 // fx_ctx_set_wide_routing
+    uint32_t sparse_fronts = 1u, sparse_front_ranks = 0u;  // fx_ctx_set_sparse_fronts
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: groups of large Systems (one structure each) solved side by side
     std::vector<hipStream_t> worker_streams;  // ... a stream per extra host thread
     // Page-locked staging for one-shot solves up to 8 MB of batch (System::solve on one sketch ... some ten thousand small
@@ -240,6 +241,8 @@ struct fx_ctx {
         p.ladder_k = ladder_k;
         p.ladder_tail = ladder_tail;
         p.spread = ladder_spread;
+        p.sparse_fronts = sparse_fronts;
+        p.sparse_front_ranks = sparse_front_ranks;
     }
     static constexpr size_t MAX_CACHED_BYTES = size_t(4) << 30;  // beyond this, released blocks go back to the driver
 

@@ -35,6 +35,7 @@
 #include "fx_expr.h"
 #include "fx_lbfgs.h"
 #include "fx_sparse.h"
+#include "fx_grouped_rows.h"
 #include "fx_sparse_plan.h"
 #include "fx_wave.h"
 
@@ -235,6 +236,7 @@ struct SpRowsOfL {               // L by rows (strictly lower part), for the for
 };
 
 #include "fx_sparse_team.h"
+#include "fx_front.h"
 
 // ------------------------------------------------------------------------------------------------
 // host: structure
@@ -332,6 +334,13 @@ struct BlockOnDevice {
     uint32_t n_fslots = 0, n_bslots = 0;
     size_t lds_part_bytes = 0, lds_top_bytes = 0;
     double plan_ms = 0.0;
+    // the multifrontal build (fx_front.h; 0 bytes: the structure has a front beyond a row of lanes, or its data no room in LDS)
+    const uint32_t* mf_solo_blob = nullptr;
+    uint32_t mf_solo_words = 0, mf_solo_red = 0, mf_solo_rows = 0;
+    size_t mf_solo_lds = 0;
+    MfParts mfp{};
+    size_t mf_up_lds = 0, mf_down_lds = 0;
+    uint32_t mf_l_doubles = 0, mf_gu_doubles = 0;  // global memory per System: the parts' columns of L, their roots' contributions
 };
 
 struct CompOnDevice {          // one connected component that holds variables (assemble/mod.rs:81-111)
@@ -352,6 +361,7 @@ struct SparsePlanCache {
     std::vector<CompOnDevice> comps;
     std::vector<std::unique_ptr<BlockOnDevice>> blocks;  // in visiting order
     uint32_t max_m = 0, max_nv = 0, max_nnz_j = 0, max_nnz_a = 0, max_nnz_l = 0, max_fslots = 0, max_bslots = 0;
+    uint32_t max_mf_l = 0, max_mf_gu = 0;            // the multifrontal build's global storage (fx_front.h)
     Arena values;                                    // the group solves' value slabs, kept between calls (one solve at a time)
     size_t keep_values = size_t(256) << 20;          // ... up to this many bytes (sparse_cache_keep_slab)
     bool ready = false;
@@ -399,6 +409,7 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
     cache->comps.clear();  // (an earlier attempt may have failed half-way)
     cache->blocks.clear();
     cache->max_m = cache->max_nv = cache->max_nnz_j = cache->max_nnz_a = cache->max_nnz_l = cache->max_fslots = cache->max_bslots = 0;
+    cache->max_mf_l = cache->max_mf_gu = 0;
     if (!cache->pool) cache->pool.reset(new Pool(&cache->arena));
     Pool& sp = *cache->pool;
     sp.stream = stream;
@@ -535,6 +546,76 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
                 cache->max_fslots = std::max(cache->max_fslots, blk->n_fslots);
                 cache->max_bslots = std::max(cache->max_bslots, blk->n_bslots);
             }
+            // the multifrontal build: one workgroup per System when everything of the factor fits its LDS ...
+            constexpr size_t MF_LDS_MAX = size_t(156) << 10;
+            const size_t even = ~size_t(1);
+            auto tiles_bytes = [](uint32_t rows2) { return (((size_t)rows2 * MF_TILE + 1) & ~size_t(1)) * 8; };
+            if (Q.fronts_solo.ok) {
+                const sparse_plan::FrontPlan& fp = Q.fronts_solo;
+                uint32_t red = 64u;
+                while (red < std::max(Q.m, Q.nv) && red < 1024u) red <<= 1;
+                const size_t fixed = (size_t)fp.words.size() * 4 + (((size_t)Q.nnz_a + 1) & even) * 8 + 2 * (((size_t)Q.nv + 1) & even) * 8 +
+                                     ((size_t)fp.max_l_doubles + fp.max_u_doubles + MF_LS + 1) * 8 + (size_t)red * 8;
+                uint32_t rows2 = mf_tile_rows(fp.max_level_fronts);  // as many tiles as the widest level takes, or as fit
+                while (rows2 > 4u && fixed + tiles_bytes(rows2) > MF_LDS_MAX) rows2 -= 4u;
+                if (fixed + tiles_bytes(rows2) <= MF_LDS_MAX) {
+                    blk->mf_solo_blob = sp.up(fp.words);
+                    blk->mf_solo_words = (uint32_t)fp.words.size();
+                    blk->mf_solo_red = red;
+                    blk->mf_solo_rows = rows2;
+                    blk->mf_solo_lds = fixed + tiles_bytes(rows2);
+                }
+            }
+            // ... a large System alone: its parts side by side and the top (the same segments as the walkers' parts schedule)
+            if (blk->has_parts && Q.fronts_parts.ok) {
+                const sparse_plan::FrontPlan& fp = Q.fronts_parts;
+                const uint32_t np = Q.parts.nparts;
+                std::vector<uint32_t> seg_l((size_t)fp.nseg + 1, 0);
+                uint32_t widest_part = 0, widest_top = 0;
+                size_t fixed_part = 0, fixed_top = 0, down = 0;
+                for (uint32_t sgm = 0; sgm < fp.nseg; ++sgm) {
+                    const uint32_t* w = fp.words.data() + fp.seg_off[sgm];
+                    seg_l[sgm + 1] = seg_l[sgm] + w[11];
+                    (sgm == np ? widest_top : widest_part) = std::max(sgm == np ? widest_top : widest_part, w[14]);
+                    // up: the blob, the entries of A, the right-hand side, the contribution slots; down: the blob, x, the L blocks
+                    const size_t up = (size_t)w[13] * 4 + (((size_t)w[2] + 1) & even) * 8 + (((size_t)w[3] + 1) & even) * 8 + ((size_t)w[12] + MF_LS + 1) * 8;
+                    const size_t dn = (size_t)w[13] * 4 + (((size_t)w[3] + 1) & even) * 8 + (size_t)w[11] * 8;
+                    if (sgm == np) {
+                        fixed_top = up;  // (the top sweeps down inside the same launch: top_dn below)
+                    } else {
+                        fixed_part = std::max(fixed_part, up);
+                        down = std::max(down, dn);
+                    }
+                }
+                uint32_t rows_part = mf_tile_rows(widest_part), rows_top = mf_tile_rows(widest_top);
+                while (rows_part > 4u && fixed_part + tiles_bytes(rows_part) > MF_LDS_MAX) rows_part -= 4u;
+                while (rows_top > 4u && fixed_top + tiles_bytes(rows_top) > MF_LDS_MAX) rows_top -= 4u;
+                size_t top_dn = 0;
+                {
+                    const uint32_t* w = fp.words.data() + fp.seg_off[np];
+                    top_dn = (size_t)w[13] * 4 + (((size_t)w[3] + 1) & even) * 8 + (size_t)w[11] * 8;
+                }
+                const size_t up = std::max(std::max(fixed_part + tiles_bytes(rows_part), fixed_top + tiles_bytes(rows_top)), top_dn);
+                down = std::max<size_t>(down, 8192);  // (the last block's sums)
+                if (up <= MF_LDS_MAX && down <= MF_LDS_MAX) {
+                    MfParts& X = blk->mfp;
+                    X.blobs = sp.up(fp.words);
+                    X.blob_off = sp.up(fp.seg_off);
+                    X.seg_l = sp.up(seg_l);
+                    X.erow_ptr = blk->px.erow_ptr;
+                    X.erows = blk->px.erows;
+                    X.nparts = np;
+                    X.top_rows = rows_top;
+                    X.part_rows = rows_part;
+                    X.prof = nullptr;
+                    blk->mf_up_lds = up;
+                    blk->mf_down_lds = down;
+                    blk->mf_l_doubles = seg_l[fp.nseg];
+                    blk->mf_gu_doubles = fp.global_u_doubles + 2 * MF_LS;
+                    cache->max_mf_l = std::max(cache->max_mf_l, blk->mf_l_doubles);
+                    cache->max_mf_gu = std::max(cache->max_mf_gu, blk->mf_gu_doubles);
+                }
+            }
             if (sp.err != hipSuccess) return sp.err;
             cache->max_m = std::max(cache->max_m, Q.m);
             cache->max_nv = std::max(cache->max_nv, Q.nv);
@@ -627,6 +708,30 @@ hipError_t raise_lds_limits() {
     return e;
 }
 
+// ... and so may the multifrontal kernels (fx_front.h)
+hipError_t raise_mf_lds_limits() {
+    static std::atomic<uint32_t> raised_on{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint32_t bit = 1u << (dev & 31);
+    if (raised_on.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    hipError_t e = hipSuccess;
+    for (const void* f : {reinterpret_cast<const void*>(&mf_parts_up_kernel<false>), reinterpret_cast<const void*>(&mf_parts_up_kernel<true>),
+                          reinterpret_cast<const void*>(&mf_parts_down_kernel<false>), reinterpret_cast<const void*>(&mf_parts_down_kernel<true>),
+                          reinterpret_cast<const void*>(&mf_lm_solo_kernel<false>), reinterpret_cast<const void*>(&mf_lm_solo_kernel<true>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  // (beside a few bytes of static LDS: 160 KB in all)
+    if (e == hipSuccess) raised_on.fetch_or(bit, std::memory_order_relaxed);
+    return e;
+}
+hipError_t launch_mf_solo(bool pose, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
+                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, const uint32_t* blob, uint32_t blob_words, uint32_t red_n, uint32_t trows) {
+    hipError_t e = raise_mf_lds_limits();
+    if (e != hipSuccess) return e;
+    if (pose) hipLaunchKernelGGL(mf_lm_solo_kernel<true>, dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows);
+    else hipLaunchKernelGGL(mf_lm_solo_kernel<false>, dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows);
+    return hipGetLastError();
+}
+
 void trace_block(const BlockOnDevice& blk, uint32_t trials, double ms) {
     const ComponentPlan& P = blk.P;
     for (const TeamSchedule* t : {&P.solo, &P.parts}) {
@@ -673,6 +778,9 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     const int do_scale = (prm.mode & 1u) ? 1 : 0;
     const bool lbfgs = (prm.mode & MODE_LBFGS) != 0;
     const bool refined = !lbfgs && o.solver != FX_STEP_CHOLESKY;  // (FX_STEP_QR beyond one wavefront: the refined step)
+    // FIKSI_AMD_FRONTS=0 keeps the column walkers of fx_sparse_team.h (A / B, and the tests that compare the two)
+    static const bool fronts_env = [] { const char* s = std::getenv("FIKSI_AMD_FRONTS"); return !(s && s[0] == '0'); }();
+    const bool fronts = fronts_env && prm.sparse_fronts != 0;
 
     // ---- the value slab of one System, in doubles; System k of the group starts k * stride further
     auto pad = [](size_t n) { return (n + 15) & ~size_t(15); };
@@ -684,10 +792,24 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     };
     const size_t o_vars0 = take(nvt), o_xs0 = take(nvt), o_xs1 = take(nvt), o_snap = take(nvt), o_param = take(net), o_sparam = take(net),
                  o_scal = take(16), o_r0 = take(cache->max_m), o_r1 = take(cache->max_m), o_j0 = take(cache->max_nnz_j),
-                 o_j1 = take(cache->max_nnz_j), o_a = take(std::max(cache->max_nnz_a, cache->max_nv)), o_l = take(lbfgs ? 0 : cache->max_nnz_l),
+                 o_j1 = take(cache->max_nnz_j), o_a = take(std::max(cache->max_nnz_a, cache->max_nv)), o_l = take(lbfgs ? 0 : std::max(cache->max_nnz_l, cache->max_mf_l)),
                  o_rhs = take(cache->max_nv), o_delta = take(cache->max_nv), o_t = take(refined ? cache->max_m : 0),
                  o_e = take(refined ? cache->max_nv : 0), o_hs = take(lbfgs ? 5 * (size_t)cache->max_nv : 0),
-                 o_hy = take(lbfgs ? 5 * (size_t)cache->max_nv : 0), o_cf = take(cache->max_fslots), o_cb = take(cache->max_bslots);
+                 o_hy = take(lbfgs ? 5 * (size_t)cache->max_nv : 0), o_cf = take(std::max(cache->max_fslots, cache->max_mf_gu)), o_cb = take(cache->max_bslots);
+    // the multifrontal build's lambda ladder (fx_front.h): ranks - 1 more sets of (point, residuals, Jacobian rows) and of (L blocks,
+    // step, contribution blocks). One block, one component only: its trial sets then need no other variable kept in step.
+    uint32_t mf_ranks = 1;
+    if (fronts && !lbfgs && !refined && cache->blocks.size() == 1 && cache->blocks[0]->mf_up_lds && n_sys < TEAM_PARTS_MAX_GROUP) {
+        static const int forced = [] { const char* s = std::getenv("FIKSI_AMD_FRONT_RANKS"); return s ? atoi(s) : 0; }();
+        const uint32_t np = cache->blocks[0]->mfp.nparts;
+        mf_ranks = std::max(1u, std::min<uint32_t>(MF_MAX_RANKS, 256u / std::max(1u, np * n_sys)));  // (a workgroup per CU: the ranks side by side)
+        if (forced >= 1 && forced <= (int)MF_MAX_RANKS) mf_ranks = (uint32_t)forced;
+        if (prm.sparse_front_ranks >= 1u && prm.sparse_front_ranks <= MF_MAX_RANKS) mf_ranks = prm.sparse_front_ranks;
+    }
+    const size_t xr = mf_ranks - 1u;
+    const size_t s_xs = pad(nvt), s_r = pad(cache->max_m), s_j = pad(cache->max_nnz_j), s_l = pad(cache->max_mf_l), s_d = pad(cache->max_nv),
+                 s_gu = pad(cache->max_mf_gu);
+    const size_t o_xsx = take(xr * s_xs), o_rx = take(xr * s_r), o_jx = take(xr * s_j), o_lx = take(xr * s_l), o_dx = take(xr * s_d), o_gux = take(xr * s_gu);
     const size_t stride = at;
 
     // the group in slices that fit a bounded slab (1 GiB)
@@ -700,6 +822,15 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         SpLm* d_lm = pool.alloc<SpLm>(n);
         SpAccum* d_accum = pool.alloc<SpAccum>(n);
         uint32_t* d_tickets = pool.alloc<uint32_t>(n);
+        MfLadder Ld{};
+        Ld.ranks = mf_ranks;
+        Ld.xsx = slab + o_xsx; Ld.rx = slab + o_rx; Ld.jx = slab + o_jx; Ld.lx = slab + o_lx; Ld.dx = slab + o_dx; Ld.gux = slab + o_gux;
+        Ld.xs_step = s_xs; Ld.r_step = s_r; Ld.j_step = s_j; Ld.l_step = s_l; Ld.d_step = s_d; Ld.gu_step = s_gu;
+        Ld.rk = pool.alloc<MfRank>((size_t)n * MF_MAX_RANKS);
+        Ld.tickets = pool.alloc<uint32_t>((size_t)n * (2 * MF_MAX_RANKS + 2));
+        if (pool.err != hipSuccess) return pool.err;
+        (void)hipMemsetAsync(Ld.rk, 0, (size_t)n * MF_MAX_RANKS * sizeof(MfRank), stream);
+        (void)hipMemsetAsync(Ld.tickets, 0, (size_t)n * (2 * MF_MAX_RANKS + 2) * sizeof(uint32_t), stream);
         std::vector<uint64_t> h_off(3 * (size_t)n);  // [out / vars0 offset | parameter offset | system id] per System
         for (uint32_t k = 0; k < n; ++k) {
             h_off[k] = b->var_off[systems[g0 + k]];
@@ -748,6 +879,11 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         hipLaunchKernelGGL(sp_lbfgs_team_kernel<true>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, blk.dev, V, d_accum, flags, d.vars, d_off);
                     else
                         hipLaunchKernelGGL(sp_lbfgs_team_kernel<false>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, blk.dev, V, d_accum, flags, d.vars, d_off);
+                } else if (!two_tier && fronts && !refined && blk.mf_solo_lds) {
+                    // the multifrontal build: the whole loop in one launch, a front per row of 16 lanes (fx_front.h)
+                    e = launch_mf_solo(rows.has_pose != 0, n, blk.mf_solo_lds, stream, rows, blk.dev, V, d_accum, o, flags, d.vars, d_off, blk.mf_solo_blob,
+                                       blk.mf_solo_words, blk.mf_solo_red, blk.mf_solo_rows);
+                    if (e != hipSuccess) return e;
                 } else if (!two_tier) {
                     unsigned long long* d_prof = nullptr;
                     if (team_prof) {
@@ -784,8 +920,14 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         else hipLaunchKernelGGL(spt_eval_kernel<false>, g_rows, dim3(TEAM_THREADS), 0, stream, rows, B, V, d_lm, d_tickets, o, start);
                     };
                     eval(1u);
+                    if (mf_ranks > 2u)  // the ladder's further sets: whole copies of the start point (a trial overwrites the block's own variables)
+                        for (uint32_t k = 0; k < n; ++k)
+                            for (uint32_t s2 = 2; s2 <= mf_ranks; ++s2)
+                                (void)hipMemcpyAsync(slab + (size_t)k * stride + o_xsx + (s2 - 2u) * s_xs, slab + (size_t)k * stride + o_xs0, (size_t)nvt * sizeof(double),
+                                                     hipMemcpyDeviceToDevice, stream);
                     // the plain step with every segment's values in LDS when they fit (they do unless a part is enormous)
-                    const bool lds_build = !refined && blk.lds_part_bytes && blk.lds_part_bytes <= TEAM_LDS_VALUES_MAX && blk.lds_top_bytes <= TEAM_LDS_VALUES_MAX;
+                    const bool mf_build = fronts && !refined && blk.mf_up_lds != 0;
+                    const bool lds_build = !mf_build && !refined && blk.lds_part_bytes && blk.lds_part_bytes <= TEAM_LDS_VALUES_MAX && blk.lds_top_bytes <= TEAM_LDS_VALUES_MAX;
                     SpContrib Cn{slab + o_cf, slab + o_cb, stride};
                     unsigned long long* d_prof = nullptr;
                     if (team_prof && lds_build) {
@@ -797,6 +939,17 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         e = raise_lds_limits();
                         if (e != hipSuccess) return e;
                     }
+                    MfParts mfp = blk.mfp;
+                    if (mf_build) {
+                        e = raise_mf_lds_limits();
+                        if (e != hipSuccess) return e;
+                        if (team_prof) {
+                            d_prof = pool.alloc<unsigned long long>(32);
+                            if (pool.err != hipSuccess) return pool.err;
+                            (void)hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), stream);
+                        }
+                        mfp.prof = d_prof;
+                    }
                     std::vector<SpLm> h_lm(n);
                     for (uint32_t chunk = 4;; chunk = std::min<uint32_t>(2 * chunk, 16)) {
                         e = hipMemcpyAsync(h_lm.data(), d_lm, n * sizeof(SpLm), hipMemcpyDeviceToHost, stream);
@@ -806,6 +959,17 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         for (const SpLm& st : h_lm) all_done = all_done && st.done;
                         if (all_done) break;
                         for (uint32_t t = 0; t < chunk; ++t) {
+                            if (mf_build) {  // (two launches per ROUND of mf_ranks trials: the parts' fronts up — the last part of a rank goes on with
+                                             // its top —, then down + evaluation + the ranks' verdicts in order)
+                                if (rows.has_pose) {
+                                    hipLaunchKernelGGL(mf_parts_up_kernel<true>, dim3(np, n, mf_ranks), dim3(MF_THREADS), blk.mf_up_lds, stream, rows, B, mfp, V, Ld, slab + o_cf, stride, d_lm, o);
+                                    hipLaunchKernelGGL(mf_parts_down_kernel<true>, dim3(np, n, mf_ranks), dim3(MF_THREADS), blk.mf_down_lds, stream, rows, B, mfp, V, Ld, d_lm, o);
+                                } else {
+                                    hipLaunchKernelGGL(mf_parts_up_kernel<false>, dim3(np, n, mf_ranks), dim3(MF_THREADS), blk.mf_up_lds, stream, rows, B, mfp, V, Ld, slab + o_cf, stride, d_lm, o);
+                                    hipLaunchKernelGGL(mf_parts_down_kernel<false>, dim3(np, n, mf_ranks), dim3(MF_THREADS), blk.mf_down_lds, stream, rows, B, mfp, V, Ld, d_lm, o);
+                                }
+                                continue;
+                            }
                             if (!lds_build) hipLaunchKernelGGL(spt_form_kernel, grid_for2(std::max(B.nnz_a, B.nv), n), dim3(256), 0, stream, B, V, d_lm);
                             if (lds_build) {  // (each segment forms its own entries of A and of the right-hand side)
                                 const size_t lds_up = std::max(blk.lds_part_bytes, blk.lds_top_bytes);  // (the last part's workgroup goes on with the top)
@@ -833,8 +997,20 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         e = hipGetLastError();
                         if (e != hipSuccess) return e;
                     }
+                    if (mf_ranks > 1u) {  // the solved point into set 0, where the block's epilogue looks for it
+                        hipLaunchKernelGGL(mf_ladder_finish_kernel, grid_for2(nvt, n), dim3(256), 0, stream, V, Ld, d_lm, nvt);
+                        hipLaunchKernelGGL(mf_ladder_finish_state_kernel, grid_for(n), dim3(256), 0, stream, d_lm, n);
+                    }
                     hipLaunchKernelGGL(spt_block_end_kernel, grid_for2(std::max(B.nv, 1u), n), dim3(256), 0, stream, B, V, d_lm, d_accum, flags, d.vars, d_off);
-                    if (d_prof) {
+                    if (d_prof && mf_build) {
+                        unsigned long long h[32];
+                        (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
+                        (void)hipStreamSynchronize(stream);
+                        fprintf(stderr, "[fiksi_amd]   fronts up by phase (us; thread 0): part 0: tile + A %.1f children %.1f registers + pivots %.1f stores %.1f barrier %.1f | top: %.1f %.1f %.1f %.1f %.1f\n",
+                                h[16] * 0.01, h[17] * 0.01, h[18] * 0.01, h[19] * 0.01, h[20] * 0.01, h[24] * 0.01, h[25] * 0.01, h[26] * 0.01, h[27] * 0.01, h[28] * 0.01);
+                        fprintf(stderr, "[fiksi_amd] mf_parts_up (us over %llu launches): part 0: load %.1f form %.1f fronts up %.1f ticket %.1f | top: load+form %.1f fronts up %.1f "
+                                        "down %.1f rest %.1f\n", h[15], h[0] * 0.01, h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[4] * 0.01, h[5] * 0.01, h[6] * 0.01, h[8] * 0.01);
+                    } else if (d_prof) {
                         unsigned long long h[16];
                         (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
                         (void)hipStreamSynchronize(stream);

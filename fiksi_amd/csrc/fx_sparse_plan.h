@@ -9,6 +9,7 @@
 
 #include "../../include/fiksi_amd.h"
 #include "fx_expr.h"
+#include "fx_front_plan.h"
 
 namespace fx {
 namespace sparse_plan {
@@ -422,6 +423,7 @@ struct ComponentPlan {
     TeamSchedule parts;                                // subtrees dealt to workgroups + the top (large Systems; else empty)
     PartsExtra px;                                     // ... and what its LDS builds need
     SegmentBlobs solo_blob, parts_blobs;               // the schedules' index data, segment by segment, for LDS
+    FrontPlan fronts_solo, fronts_parts;               // the multifrontal build (fx_front_plan.h): one segment / parts + top
 };
 
 // Builds every index structure of one component. `colof[v]` = free column of system variable v
@@ -766,6 +768,9 @@ inline void plan_component(const fx_batch* b, uint32_t s, const std::vector<uint
             X.cmid[j] = k;
         }
     }
+    // --- the multifrontal build: the same tree cut into fronts that fit a row of 16 lanes (ok = false: no such build)
+    build_front_plan(P.nv, P.lcolptr, P.lrow, P.l2a, acolptr, std::vector<uint32_t>(), 0, P.fronts_solo);
+    if (nparts) build_front_plan(P.nv, P.lcolptr, P.lrow, P.l2a, acolptr, col_seg, nparts, P.fronts_parts);
     // --- the segments' index data as LDS-ready blobs
     auto build_blobs = [&](const TeamSchedule& T, bool with_top_lists, SegmentBlobs& out) {
         const uint32_t nseg = T.nseg();

@@ -272,6 +272,18 @@ int fx_ctx_set_ladder(fx_ctx* ctx, int enable, uint32_t tail_systems, uint32_t m
  * hand. Both follow the reference's iteration path; they add in different orders, so the choice shows in the last bits of
  * a result — pin it when results must not depend on how many such Systems share a batch. */
 int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide);
+/* Systems beyond one wavefront (more than 128 free variables in a component, or any System the team kernels take): the
+ * MULTIFRONTAL build (fx_front.h) where the structure allows it — the elimination tree cut into fronts of at most 15
+ * columns, a front factored in the registers of one row of 16 lanes, four fronts per wavefront; chain-like sketches
+ * (BASELINE's 5 000-point sketch, the reference's hinged triangles) qualify, a structure with a larger front keeps the
+ * column walkers of fx_sparse_team.h. The same normal-equation step (lm.rs:28-63) in another summation order: the
+ * reference's iteration path, last bits differ. enable = 0 keeps the walkers (default 1; FIKSI_AMD_FRONTS=0 likewise).
+ * ranks: a large System alone (its tree cut into parts + top, two launches per trial) leaves most of the chip idle, and the
+ * trials that follow a rejected trial of lm.rs:114-190 differ in lambda only — a launch makes `ranks` of them side by side
+ * (lambda x reject_factor^k) and the decision reads their verdicts in order: every counter, lambda and accepted point is the
+ * sequential loop's, in fewer launches (BASELINE's large sketch: 89 trials in the time of ~30). 0 = as many as the chip has
+ * room for (at most 4), 1 = one trial per launch. */
+int fx_ctx_set_sparse_fronts(fx_ctx* ctx, int enable, uint32_t ranks);
 /* Systems beyond the one-wavefront kernels are grouped by structure, and every launch carries a whole group (fx_sparse_team.h).
  * A batch with SEVERAL structures solves its groups side by side on this many host threads, a stream each (default 8; 0 restores
  * the default, 1 = one after the other on the caller's thread and the context's stream). Results do not depend on it.
