@@ -177,6 +177,44 @@ __device__ __forceinline__ void mf_backward_from(const double (&a)[MF_N], double
     }
 }
 
+// The children's contribution blocks into a front's tile: W lanes per child (lane c of the group: column c of the child's block;
+// the block's last column is the right-hand side), 16 / W children per round, child after child in the order of the list. A
+// column's W - 1 rows are in flight at once (a part's root hands its block over through global memory: one round trip per
+// round of children, not one per value), then the additions (ds_add_f64: no read-back) — rows past the block go to the tile's
+// spare row (fx_front_plan.h: the map's padding).
+template <int W>
+__device__ __forceinline__ void mf_add_children(const uint32_t* kids, uint32_t nch, const double* u_loc, const double* u_glob, double* tile, uint32_t ts, int hl, int F) {
+    constexpr int G = (int)MF_N / W;  // children per round
+    const int g = hl / W, lc = hl % W;
+    for (uint32_t c0 = 0; c0 < nch; c0 += (uint32_t)G) {
+        const uint32_t c = c0 + (uint32_t)g;
+        if (c < nch) {
+            const uint32_t* kp = kids + (size_t)c * sparse_plan::MF_CHILD_WORDS;
+            const uint32_t uo = kp[0], nb = kp[1];
+            const uint4 m4 = *reinterpret_cast<const uint4*>(kp + 2);
+            if ((uint32_t)lc <= nb) {
+                const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
+                double uv[W - 1];
+                if (uo >> 31) {
+                    const double* U = u_glob + (uo & 0x7FFFFFFFu) + (uint32_t)lc * MF_LS;
+#pragma unroll
+                    for (int r = 0; r < W - 1; ++r) uv[r] = U[r];
+                } else {
+                    const double* U = u_loc + uo + (uint32_t)lc * MF_LS;
+#pragma unroll
+                    for (int r = 0; r < W - 1; ++r) uv[r] = U[r];
+                }
+                const uint32_t wsel = lc < 4 ? mw[0] : lc < 8 ? mw[1] : lc < 12 ? mw[2] : mw[3];
+                const uint32_t mc = (uint32_t)lc < nb ? (wsel >> (8 * (lc & 3))) & 0xFFu : (uint32_t)F;  // (the block's last column: the right-hand side)
+                double* tcol = tile + mc;
+#pragma unroll
+                for (int r = 0; r < W - 1; ++r) lds_add(&tcol[((mw[r / 4] >> (8 * (r % 4))) & 0xFFu) * ts], uv[r]);
+            }
+        }
+        group_sync();
+    }
+}
+
 // The sweep up of one segment by the calling workgroup: its fronts level by level, a row of 16 lanes per front.
 //   s_a / s_rhs: the segment's entries of A and of the right-hand side (LDS); l: the fronts' L blocks (LDS, or global memory
 //   when the sweep down is another launch or needs the room); u_loc / u_glob: contribution blocks (fx_front_plan.h: layout);
@@ -195,6 +233,7 @@ __device__ __forceinline__ bool mf_sweep_up(const MfSeg& sg, const double* s_a, 
     };
     const int lane = threadIdx.x & 63, hl = lane & 15;
     const uint32_t rid = (threadIdx.x >> 4);  // this lane row's place among the workgroup's rows
+    constexpr uint32_t ts = MF_TS;
     double* const tile = tiles + (size_t)(rid < rows ? rid : 0u) * MF_TILE;
     bool bad = false;
     for (uint32_t q = 0; q < sg.nlev; ++q) {
@@ -232,15 +271,15 @@ __device__ __forceinline__ bool mf_sweep_up(const MfSeg& sg, const double* s_a, 
                     for (int u = 0; u < 4; ++u)
                         if (r[u] != 0xFFFFFFFFu) {
                             const uint32_t li = r[u] & 15u, lj = (r[u] >> 4) & 15u;
-                            tile[li * MF_TS + lj] = v[u];
-                            tile[lj * MF_TS + li] = v[u];
+                            tile[li * ts + lj] = v[u];
+                            tile[lj * ts + li] = v[u];
                         }
                 }
             }
             group_sync();
             if (on && hl < npiv) {
-                lds_add(&tile[hl * (int)MF_TS + hl], lambda);
-                tile[hl * (int)MF_TS + F] = s_rhs[fc[hl] - sg.c0];
+                lds_add(&tile[(uint32_t)hl * ts + (uint32_t)hl], lambda);
+                tile[(uint32_t)hl * ts + (uint32_t)F] = s_rhs[fc[hl] - sg.c0];
             }
             group_sync();
             mark(0);
@@ -248,31 +287,12 @@ __device__ __forceinline__ bool mf_sweep_up(const MfSeg& sg, const double* s_a, 
             // in program order, so a tile entry gets the same sum every time); lane c adds column c of the child's block: its
             // fifteen rows in flight at once (a part's root hands its block over through global memory: one round trip per child,
             // not one per value), then the additions (ds_add_f64: no read-back) — rows past the block go to the tile's spare row
+            // Children with small blocks go several at a time: a group of W lanes per child (W = 4 / 8 / 16 by the widest block), the
+            // additions of one instruction into one entry arrive in lane order — the same order every time.
             if (on) {
-                const uint32_t* kp = sg.kids + d[4];
-                for (uint32_t c = 0; c < nch; ++c, kp += sparse_plan::MF_CHILD_WORDS) {
-                    const uint32_t uo = kp[0], nb = kp[1];
-                    const uint4 m4 = *reinterpret_cast<const uint4*>(kp + 2);
-                    if ((uint32_t)hl <= nb) {
-                        const uint32_t mw[4] = {m4.x, m4.y, m4.z, m4.w};
-                        double uv[MF_FMAX];
-                        if (uo >> 31) {
-                            const double* U = u_glob + (uo & 0x7FFFFFFFu) + (uint32_t)hl * MF_LS;
-#pragma unroll
-                            for (int r = 0; r < (int)MF_FMAX; ++r) uv[r] = U[r];
-                        } else {
-                            const double* U = u_loc + uo + (uint32_t)hl * MF_LS;
-#pragma unroll
-                            for (int r = 0; r < (int)MF_FMAX; ++r) uv[r] = U[r];
-                        }
-                        const uint32_t wsel = hl < 4 ? mw[0] : hl < 8 ? mw[1] : hl < 12 ? mw[2] : mw[3];
-                        const uint32_t mc = (uint32_t)hl < nb ? (wsel >> (8 * (hl & 3))) & 0xFFu : (uint32_t)F;  // (the block's last column: the right-hand side)
-                        double* tcol = tile + mc;
-#pragma unroll
-                        for (int r = 0; r < (int)MF_FMAX; ++r) lds_add(&tcol[((mw[r / 4] >> (8 * (r % 4))) & 0xFFu) * MF_TS], uv[r]);
-                    }
-                    group_sync();
-                }
+                if (flags & sparse_plan::MF_KIDS_W4) mf_add_children<4>(sg.kids + d[4], nch, u_loc, u_glob, tile, ts, hl, F);
+                else if (flags & sparse_plan::MF_KIDS_W8) mf_add_children<8>(sg.kids + d[4], nch, u_loc, u_glob, tile, ts, hl, F);
+                else mf_add_children<16>(sg.kids + d[4], nch, u_loc, u_glob, tile, ts, hl, F);
             }
             group_sync();
             mark(1);
@@ -369,10 +389,25 @@ __host__ __device__ inline uint32_t mf_tile_rows(uint32_t widest) {
 // ---- the whole LM loop of one block, one workgroup per System (fx_sparse_team.h: sp_lm_team_kernel with the walkers
 // replaced by the fronts; the entries of A stay in LDS from an accepted step to the next) --------------------------------
 // dynamic LDS, doubles: [blob][s_a: na][s_rhs: nc][s_x: nc][contribution slots + 16][tiles][L][sums: red_n]
-template <bool POSE>
+// MODE 1: the L blocks in global memory instead (a factor of some hundred columns: they would not fit beside the rest) — stores on
+// the way up, one trip per level on the way down; MODE 2: the contribution blocks too (one more trip per level on the way up) —
+// LDS then keeps enough staging tiles for a level's fronts to go side by side.
+template <bool POSE, int MODE>
 __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum, fx_lm_opts o,
                                                                 uint32_t flags, double* __restrict__ vars_base, const uint64_t* __restrict__ out_off,
-                                                                const uint32_t* __restrict__ blob, uint32_t blob_words, uint32_t red_n, uint32_t trows) {
+                                                                const uint32_t* __restrict__ blob, uint32_t blob_words, uint32_t red_n, uint32_t trows,
+                                                                double* __restrict__ u_glob_base, size_t u_stride, unsigned long long* prof) {
+    constexpr bool LG = MODE >= 1, UG = MODE >= 2;
+    // prof (diagnostics, FIKSI_AMD_TEAM_PROF=1; else null): workgroup 0 adds up the 100 MHz ticks of its phases
+    const bool stamp = prof && blockIdx.x == 0 && threadIdx.x == 0;
+    unsigned long long t_prev = stamp ? wall_clock64() : 0ull;
+    auto mark = [&](int slot) {
+        if (stamp) {
+            const unsigned long long now = wall_clock64();
+            prof[slot] += now - t_prev;
+            t_prev = now;
+        }
+    };
     extern __shared__ double s_dyn[];
     __shared__ uint32_t s_bad;
     const uint32_t sys = blockIdx.x, tid = threadIdx.x;
@@ -387,28 +422,38 @@ __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpB
     double* const s_a = p;      p += (sg.na + 1u) & ~1u;
     double* const s_rhs = p;    p += (sg.nc + 1u) & ~1u;
     double* const s_x = p;      p += (sg.nc + 1u) & ~1u;
-    double* const s_u = p;      p += ((sg.u_doubles + MF_LS + 1u) & ~1u);
+    double* const s_u = UG ? u_glob_base + sys * u_stride : p;
+    if (!UG) p += ((sg.u_doubles + MF_LS + 1u) & ~1u);
     double* const tiles = p;    p += (size_t)trows * MF_TILE + (trows * MF_TILE & 1u);
-    double* const s_l = p;      p += sg.l_doubles;
+    double* const s_l = LG ? V.l : p;
+    if (!LG) p += sg.l_doubles;
     double* const s_red = p;
 
     for (uint32_t row = tid; row < m; row += MF_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, V.xs0, V.r0, V.j0);
     __syncthreads();
     SpLm st;
     lm_state_init(st, team_sumsq<MF_NW>(V.r0, m, s_red, red_n), o);
+    mark(0);
     while (!st.done) {
         const double* jc = st.cur ? V.j1 : V.j0;
         const double* rc = st.cur ? V.r1 : V.r0;
         if (st.need_form) mf_form(B, jc, rc, sg, s_a, s_rhs, nullptr, nullptr, true);  // (a rejected trial finds both in LDS)
         if (tid == 0) s_bad = 0;
         __syncthreads();
-        const bool ok = mf_sweep_up(sg, s_a, s_rhs, st.lambda, s_l, s_u, s_u, tiles, trows);  // (one segment: no block goes through global memory)
+        mark(1);
+        const bool ok = mf_sweep_up(sg, s_a, s_rhs, st.lambda, s_l, s_u, s_u, tiles, trows, stamp ? prof + 8 : nullptr);  // (one segment: no block goes through global memory)
         if (!ok && (tid & 63) == 0) atomicOr(&s_bad, 1u);
         __syncthreads();
         st.flag = s_bad;
         __syncthreads();
+        mark(2);
         if (!st.flag) {
+            if (LG) {  // (the L blocks have left for global memory; the same CU reads them back through its L1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             mf_sweep_down(sg, s_l, s_x, V.delta, trows);
+            mark(3);
             st.dn2 = team_sumsq<MF_NW>(s_x, nv, s_red, red_n);
             const double* xc = st.cur ? V.xs1 : V.xs0;
             double* xt = st.cur ? V.xs0 : V.xs1;
@@ -422,10 +467,13 @@ __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpB
             for (uint32_t row = tid; row < m; row += MF_THREADS) team_eval_row<POSE>(rows, sparam, B.jac, row, xt, rt, jt);
             __syncthreads();
             st.sse_t = team_sumsq<MF_NW>(rt, m, s_red, red_n);
+            mark(5);
         }
         lm_state_control(st, o);
     }
     team_block_epilogue(B, V, st.cur, flags, vars_base + out_off[sys], tid, MF_THREADS);
+    mark(6);
+    if (stamp) prof[7] += st.trials;
     if (tid == 0) {
         SpAccum& ac = accum[sys];
         ac.accepted += st.accepted;

@@ -24,10 +24,12 @@ constexpr uint32_t MF_TS = MF_N + 1;       // a staging tile in LDS: 17 rows of 
 constexpr uint32_t MF_TILE = MF_TS * MF_TS;  // takes what a child's padding adds — it is never read)
 constexpr uint32_t MF_LS = MF_N + 1;       // doubles between the columns of an L / contribution block: 17, not 16 — sixteen lanes that store or
                                            // load their columns side by side then fall into sixteen different LDS banks (a stride of 128 bytes: into one)
-constexpr uint32_t MF_HDR = 16;            // words of a segment blob's header
+constexpr uint32_t MF_HDR = 20;            // words of a segment blob's header
 constexpr uint32_t MF_FRONT_WORDS = 8;     // words of a front's record
 constexpr uint32_t MF_CHILD_WORDS = 6;     // words of a child's entry
 constexpr uint32_t MF_U_GLOBAL = 1u;       // front flag: the contribution block goes to global memory (a part's root: its parent is in the top)
+constexpr uint32_t MF_KIDS_W8 = 2u;        // front flags: every child's block has at most 7 (3) rows — two (four) children are added at a time, a group of
+constexpr uint32_t MF_KIDS_W4 = 4u;        // 8 (4) lanes each (a hinge point shared by 60 triangles is one front with 60 children)
 
 // Storage of a front, laid out so that a lane stores its 16 registers with ONE address and sixteen immediate offsets, no
 // test per register (what the test would keep out lands in padding):
@@ -41,7 +43,7 @@ constexpr uint32_t MF_U_GLOBAL = 1u;       // front flag: the contribution block
 //   [0] fronts [1] levels [2] entries of A in the segment [3] columns [4] first entry of A [5] first column
 //   [6 .. 10] word offsets of: lev_ptr, fronts, recs, cols, children [11] doubles of L storage [12] doubles of local
 //   contribution storage (slots reused: a block lives from its front's level to its parent's) [13] words in all [14] most fronts
-//   in a level [15] doubles of global contribution storage it writes
+//   in a level [15] doubles of global contribution storage it writes [16] the segment's largest front + 2 (diagnostics)
 //   lev_ptr[levels + 1] | fronts[.][8]: npiv | nbnd << 8 | nchild << 16 | flags << 24, rec_off, nrec, cols_off, child_off,
 //   l_off, u_off, id (of the whole plan) | recs: li | lj << 4 | (entry of A - first) << 8 | cols: the front's columns
 //   (pivots in elimination order, then the boundary ascending; numbers of the whole factor) | children, 6 words per child:
@@ -56,6 +58,7 @@ struct FrontPlan {
     uint32_t global_u_doubles = 0;                   // the parts' roots (global memory)
     uint32_t max_blob_words = 0, top_blob_words = 0;
     uint32_t max_seg_a = 0, max_seg_cols = 0, top_a = 0, top_cols = 0;
+    uint32_t max_ts = 0;                             // the largest staging tile's side
     std::vector<uint32_t> words;    // all segments' blobs, each 16-byte aligned
     std::vector<uint32_t> seg_off;  // [nseg + 1]
     std::vector<uint32_t> seg_a;    // [nseg + 1] first entry of A of each segment (A entries are by column: contiguous)
@@ -223,7 +226,11 @@ inline void build_front_plan(uint32_t nv, const std::vector<uint32_t>& lcolptr, 
         u_at = (u_at + 1u) & ~1u;
         const uint32_t a0 = out.seg_a[s], na = out.seg_a[s + 1] - a0, c0 = out.seg_col[s], nc = out.seg_col[s + 1] - c0;
         if (na >= (1u << 24)) return;
+        uint32_t ts = 3;  // the staging tile's side: the largest front, its right-hand side's column, a spare row; odd (LDS banks)
+        for (uint32_t f : ids) ts = std::max(ts, fr[f].npiv + fr[f].nbnd + 2u);
+        ts |= 1u;
         std::vector<uint32_t> w(MF_HDR, 0);
+        w[16] = ts;
         w[0] = (uint32_t)ids.size();
         w[1] = nlev;
         w[2] = na;
@@ -254,7 +261,10 @@ inline void build_front_plan(uint32_t nv, const std::vector<uint32_t>& lcolptr, 
             const Front& F = fr[ids[q]];
             uint32_t* d = &w[fr_at + q * MF_FRONT_WORDS];
             if (F.children.size() > 255u) return;
-            d[0] = F.npiv | (F.nbnd << 8) | ((uint32_t)F.children.size() << 16) | (F.flags << 24);
+            uint32_t kflags = 0, widest = 0;
+            for (uint32_t c : F.children) widest = std::max(widest, fr[c].nbnd);
+            if (!F.children.empty()) kflags = widest <= 3u ? MF_KIDS_W4 : widest <= 7u ? MF_KIDS_W8 : 0u;
+            d[0] = F.npiv | (F.nbnd << 8) | ((uint32_t)F.children.size() << 16) | ((F.flags | kflags) << 24);
             d[1] = (uint32_t)recs.size();
             d[2] = (uint32_t)F.recs.size();
             d[3] = (uint32_t)cols.size();
@@ -302,6 +312,7 @@ inline void build_front_plan(uint32_t nv, const std::vector<uint32_t>& lcolptr, 
             out.max_seg_cols = std::max(out.max_seg_cols, nc);
         }
         out.max_levels = std::max(out.max_levels, nlev);
+        out.max_ts = std::max(out.max_ts, ts);
         out.max_l_doubles = std::max(out.max_l_doubles, l_at);
         out.max_u_doubles = std::max(out.max_u_doubles, u_at);
         out.words.insert(out.words.end(), w.begin(), w.end());

@@ -337,6 +337,7 @@ struct BlockOnDevice {
     // the multifrontal build (fx_front.h; 0 bytes: the structure has a front beyond a row of lanes, or its data no room in LDS)
     const uint32_t* mf_solo_blob = nullptr;
     uint32_t mf_solo_words = 0, mf_solo_red = 0, mf_solo_rows = 0;
+    int mf_solo_mode = 0;     // 1: its L blocks in global memory (they do not fit LDS beside the rest); 2: the contribution blocks too
     size_t mf_solo_lds = 0;
     MfParts mfp{};
     size_t mf_up_lds = 0, mf_down_lds = 0;
@@ -549,21 +550,29 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
             // the multifrontal build: one workgroup per System when everything of the factor fits its LDS ...
             constexpr size_t MF_LDS_MAX = size_t(156) << 10;
             const size_t even = ~size_t(1);
-            auto tiles_bytes = [](uint32_t rows2) { return (((size_t)rows2 * MF_TILE + 1) & ~size_t(1)) * 8; };
+            auto tiles_bytes = [](uint32_t rows2, uint32_t) { return (((size_t)rows2 * MF_TILE + 1) & ~size_t(1)) * 8; };
             if (Q.fronts_solo.ok) {
                 const sparse_plan::FrontPlan& fp = Q.fronts_solo;
                 uint32_t red = 64u;
                 while (red < std::max(Q.m, Q.nv) && red < 1024u) red <<= 1;
-                const size_t fixed = (size_t)fp.words.size() * 4 + (((size_t)Q.nnz_a + 1) & even) * 8 + 2 * (((size_t)Q.nv + 1) & even) * 8 +
-                                     ((size_t)fp.max_l_doubles + fp.max_u_doubles + MF_LS + 1) * 8 + (size_t)red * 8;
-                uint32_t rows2 = mf_tile_rows(fp.max_level_fronts);  // as many tiles as the widest level takes, or as fit
-                while (rows2 > 4u && fixed + tiles_bytes(rows2) > MF_LDS_MAX) rows2 -= 4u;
-                if (fixed + tiles_bytes(rows2) <= MF_LDS_MAX) {
+                const size_t base = (size_t)fp.words.size() * 4 + (((size_t)Q.nnz_a + 1) & even) * 8 + 2 * (((size_t)Q.nv + 1) & even) * 8 + (size_t)red * 8;
+                const size_t l_bytes = (size_t)fp.max_l_doubles * 8, u_bytes = ((size_t)fp.max_u_doubles + MF_LS + 1) * 8;
+                // everything in LDS when a fair number of staging tiles still fits beside it; else the L blocks in global memory; else
+                // the contribution blocks too
+                const uint32_t want = std::min(16u, mf_tile_rows(fp.max_level_fronts));
+                for (int mode = 0; mode < 3 && !blk->mf_solo_lds; ++mode) {
+                    const size_t fixed = base + (mode < 1 ? l_bytes : 0) + (mode < 2 ? u_bytes : 0);
+                    uint32_t rows2 = mf_tile_rows(fp.max_level_fronts);  // as many tiles as the widest level takes, or as fit
+                    while (rows2 > 4u && fixed + tiles_bytes(rows2, fp.max_ts) > MF_LDS_MAX) rows2 -= 4u;
+                    if (fixed + tiles_bytes(rows2, fp.max_ts) > MF_LDS_MAX || (mode < 2 && rows2 < want)) continue;
                     blk->mf_solo_blob = sp.up(fp.words);
                     blk->mf_solo_words = (uint32_t)fp.words.size();
                     blk->mf_solo_red = red;
                     blk->mf_solo_rows = rows2;
-                    blk->mf_solo_lds = fixed + tiles_bytes(rows2);
+                    blk->mf_solo_mode = mode;
+                    blk->mf_solo_lds = fixed + tiles_bytes(rows2, fp.max_ts);
+                    if (mode >= 1) cache->max_mf_l = std::max(cache->max_mf_l, fp.max_l_doubles);
+                    if (mode >= 2) cache->max_mf_gu = std::max(cache->max_mf_gu, fp.max_u_doubles + 2 * MF_LS);
                 }
             }
             // ... a large System alone: its parts side by side and the top (the same segments as the walkers' parts schedule)
@@ -571,12 +580,13 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
                 const sparse_plan::FrontPlan& fp = Q.fronts_parts;
                 const uint32_t np = Q.parts.nparts;
                 std::vector<uint32_t> seg_l((size_t)fp.nseg + 1, 0);
-                uint32_t widest_part = 0, widest_top = 0;
+                uint32_t widest_part = 0, widest_top = 0, ts_part = 3, ts_top = 3;
                 size_t fixed_part = 0, fixed_top = 0, down = 0;
                 for (uint32_t sgm = 0; sgm < fp.nseg; ++sgm) {
                     const uint32_t* w = fp.words.data() + fp.seg_off[sgm];
                     seg_l[sgm + 1] = seg_l[sgm] + w[11];
                     (sgm == np ? widest_top : widest_part) = std::max(sgm == np ? widest_top : widest_part, w[14]);
+                    (sgm == np ? ts_top : ts_part) = std::max(sgm == np ? ts_top : ts_part, w[16]);
                     // up: the blob, the entries of A, the right-hand side, the contribution slots; down: the blob, x, the L blocks
                     const size_t up = (size_t)w[13] * 4 + (((size_t)w[2] + 1) & even) * 8 + (((size_t)w[3] + 1) & even) * 8 + ((size_t)w[12] + MF_LS + 1) * 8;
                     const size_t dn = (size_t)w[13] * 4 + (((size_t)w[3] + 1) & even) * 8 + (size_t)w[11] * 8;
@@ -588,14 +598,14 @@ hipError_t ensure_plan(const fx_batch* b, uint32_t s, bool single_pass, hipStrea
                     }
                 }
                 uint32_t rows_part = mf_tile_rows(widest_part), rows_top = mf_tile_rows(widest_top);
-                while (rows_part > 4u && fixed_part + tiles_bytes(rows_part) > MF_LDS_MAX) rows_part -= 4u;
-                while (rows_top > 4u && fixed_top + tiles_bytes(rows_top) > MF_LDS_MAX) rows_top -= 4u;
+                while (rows_part > 4u && fixed_part + tiles_bytes(rows_part, ts_part) > MF_LDS_MAX) rows_part -= 4u;
+                while (rows_top > 4u && fixed_top + tiles_bytes(rows_top, ts_top) > MF_LDS_MAX) rows_top -= 4u;
                 size_t top_dn = 0;
                 {
                     const uint32_t* w = fp.words.data() + fp.seg_off[np];
                     top_dn = (size_t)w[13] * 4 + (((size_t)w[3] + 1) & even) * 8 + (size_t)w[11] * 8;
                 }
-                const size_t up = std::max(std::max(fixed_part + tiles_bytes(rows_part), fixed_top + tiles_bytes(rows_top)), top_dn);
+                const size_t up = std::max(std::max(fixed_part + tiles_bytes(rows_part, ts_part), fixed_top + tiles_bytes(rows_top, ts_top)), top_dn);
                 down = std::max<size_t>(down, 8192);  // (the last block's sums)
                 if (up <= MF_LDS_MAX && down <= MF_LDS_MAX) {
                     MfParts& X = blk->mfp;
@@ -718,17 +728,29 @@ hipError_t raise_mf_lds_limits() {
     hipError_t e = hipSuccess;
     for (const void* f : {reinterpret_cast<const void*>(&mf_parts_up_kernel<false>), reinterpret_cast<const void*>(&mf_parts_up_kernel<true>),
                           reinterpret_cast<const void*>(&mf_parts_down_kernel<false>), reinterpret_cast<const void*>(&mf_parts_down_kernel<true>),
-                          reinterpret_cast<const void*>(&mf_lm_solo_kernel<false>), reinterpret_cast<const void*>(&mf_lm_solo_kernel<true>)})
+                          reinterpret_cast<const void*>(&mf_lm_solo_kernel<false, 0>), reinterpret_cast<const void*>(&mf_lm_solo_kernel<true, 0>),
+                          reinterpret_cast<const void*>(&mf_lm_solo_kernel<false, 1>), reinterpret_cast<const void*>(&mf_lm_solo_kernel<true, 1>),
+                          reinterpret_cast<const void*>(&mf_lm_solo_kernel<false, 2>), reinterpret_cast<const void*>(&mf_lm_solo_kernel<true, 2>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);  // (beside a few bytes of static LDS: 160 KB in all)
     if (e == hipSuccess) raised_on.fetch_or(bit, std::memory_order_relaxed);
     return e;
 }
 hipError_t launch_mf_solo(bool pose, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
-                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, const uint32_t* blob, uint32_t blob_words, uint32_t red_n, uint32_t trows) {
+                          const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, const uint32_t* blob, uint32_t blob_words, uint32_t red_n, uint32_t trows,
+                          int mode, double* u_glob, size_t u_stride, unsigned long long* prof) {
     hipError_t e = raise_mf_lds_limits();
     if (e != hipSuccess) return e;
-    if (pose) hipLaunchKernelGGL(mf_lm_solo_kernel<true>, dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows);
-    else hipLaunchKernelGGL(mf_lm_solo_kernel<false>, dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows);
+#define FX_MF_SOLO(P, G) hipLaunchKernelGGL((mf_lm_solo_kernel<P, G>), dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows, u_glob, u_stride, prof)
+    if (pose) {
+        if (mode == 2) FX_MF_SOLO(true, 2);
+        else if (mode == 1) FX_MF_SOLO(true, 1);
+        else FX_MF_SOLO(true, 0);
+    } else {
+        if (mode == 2) FX_MF_SOLO(false, 2);
+        else if (mode == 1) FX_MF_SOLO(false, 1);
+        else FX_MF_SOLO(false, 0);
+    }
+#undef FX_MF_SOLO
     return hipGetLastError();
 }
 
@@ -826,11 +848,15 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         Ld.ranks = mf_ranks;
         Ld.xsx = slab + o_xsx; Ld.rx = slab + o_rx; Ld.jx = slab + o_jx; Ld.lx = slab + o_lx; Ld.dx = slab + o_dx; Ld.gux = slab + o_gux;
         Ld.xs_step = s_xs; Ld.r_step = s_r; Ld.j_step = s_j; Ld.l_step = s_l; Ld.d_step = s_d; Ld.gu_step = s_gu;
-        Ld.rk = pool.alloc<MfRank>((size_t)n * MF_MAX_RANKS);
-        Ld.tickets = pool.alloc<uint32_t>((size_t)n * (2 * MF_MAX_RANKS + 2));
-        if (pool.err != hipSuccess) return pool.err;
-        (void)hipMemsetAsync(Ld.rk, 0, (size_t)n * MF_MAX_RANKS * sizeof(MfRank), stream);
-        (void)hipMemsetAsync(Ld.tickets, 0, (size_t)n * (2 * MF_MAX_RANKS + 2) * sizeof(uint32_t), stream);
+        bool any_parts_build = false;
+        for (const auto& bp : cache->blocks) any_parts_build = any_parts_build || (bp->mf_up_lds != 0 && n < TEAM_PARTS_MAX_GROUP);
+        if (fronts && any_parts_build) {  // (what only the parts + top kernels look at)
+            Ld.rk = pool.alloc<MfRank>((size_t)n * MF_MAX_RANKS);
+            Ld.tickets = pool.alloc<uint32_t>((size_t)n * (2 * MF_MAX_RANKS + 2));
+            if (pool.err != hipSuccess) return pool.err;
+            (void)hipMemsetAsync(Ld.rk, 0, (size_t)n * MF_MAX_RANKS * sizeof(MfRank), stream);
+            (void)hipMemsetAsync(Ld.tickets, 0, (size_t)n * (2 * MF_MAX_RANKS + 2) * sizeof(uint32_t), stream);
+        }
         std::vector<uint64_t> h_off(3 * (size_t)n);  // [out / vars0 offset | parameter offset | system id] per System
         for (uint32_t k = 0; k < n; ++k) {
             h_off[k] = b->var_off[systems[g0 + k]];
@@ -881,9 +907,23 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         hipLaunchKernelGGL(sp_lbfgs_team_kernel<false>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, blk.dev, V, d_accum, flags, d.vars, d_off);
                 } else if (!two_tier && fronts && !refined && blk.mf_solo_lds) {
                     // the multifrontal build: the whole loop in one launch, a front per row of 16 lanes (fx_front.h)
+                    unsigned long long* d_prof = nullptr;
+                    if (team_prof) {
+                        d_prof = pool.alloc<unsigned long long>(16);
+                        if (pool.err != hipSuccess) return pool.err;
+                        (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream);
+                    }
                     e = launch_mf_solo(rows.has_pose != 0, n, blk.mf_solo_lds, stream, rows, blk.dev, V, d_accum, o, flags, d.vars, d_off, blk.mf_solo_blob,
-                                       blk.mf_solo_words, blk.mf_solo_red, blk.mf_solo_rows);
+                                       blk.mf_solo_words, blk.mf_solo_red, blk.mf_solo_rows, blk.mf_solo_mode, slab + o_cf, stride, d_prof);
                     if (e != hipSuccess) return e;
+                    if (team_prof) {
+                        unsigned long long h[16];
+                        (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
+                        (void)hipStreamSynchronize(stream);
+                        fprintf(stderr, "[fiksi_amd] mf_lm_solo, %u Systems, workgroup 0 (us over %llu trials): start %.1f | form %.1f fronts up %.1f (tile + A %.1f children %.1f "
+                                        "registers + pivots %.1f stores %.1f barrier %.1f) down %.1f trial + eval + sums %.1f | epilogue %.1f\n", n, h[7], h[0] * 0.01, h[1] * 0.01,
+                                h[2] * 0.01, h[8] * 0.01, h[9] * 0.01, h[10] * 0.01, h[11] * 0.01, h[12] * 0.01, h[3] * 0.01, h[5] * 0.01, h[6] * 0.01);
+                    }
                 } else if (!two_tier) {
                     unsigned long long* d_prof = nullptr;
                     if (team_prof) {

@@ -100,7 +100,7 @@ bool sweep_up(const uint32_t* w, const double* a_vals, const double* rhs, double
             const uint32_t* kp = kids + d[4];
             for (uint32_t c = 0; c < nch; ++c, kp += MF_CHILD_WORDS) {
                 const uint32_t uo = kp[0] & 0x7FFFFFFFu, nb = kp[1];
-                const double* U = (kp[0] >> 31) ? gu.data() + uo : st.u.data() + uo;
+                const double* U = (kp[0] >> 31) ? gu.data() + uo : st.u.data() + uo;  // (the device adds 16 / W children per round: same sums up to their order)
                 const uint8_t* map = reinterpret_cast<const uint8_t*>(kp + 2);
                 for (uint32_t cc = 0; cc <= nb; ++cc) {      // lane cc: column cc of the child's block
                     const uint32_t mc = cc < nb ? map[cc] : (uint32_t)F;
