@@ -513,17 +513,36 @@ def host_path(ctx, batch, np):
     res = np.zeros(n, dtype=abi.RESULT_DTYPE)
     o = abi.solving_opts()
     st = abi.as_struct(a)
-    times = []
-    for k in range(8):  # the first call is the warm-up; median of seven
-        a["vars"][:] = start
-        t0 = _t.perf_counter()
-        check(lib.fx_system_solve_batch(ctx.handle, C.byref(st), C.byref(o), res.ctypes.data), "fx_system_solve_batch")
-        if k:
-            times.append(_t.perf_counter() - t0)
-    dt = sorted(times)[len(times) // 2]
-    conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
-    return {"entry_point": "fx_system_solve_batch", "systems": n, "ms_per_call": dt * 1e3, "ms_per_call_min": min(times) * 1e3,
-            "ms_per_call_max": max(times) * 1e3, "calls": len(times), "converged_systems_per_sec": conv / dt}
+
+    def run():
+        times = []
+        for k in range(8):  # the first call is the warm-up; median of seven
+            a["vars"][:] = start
+            t0 = _t.perf_counter()
+            check(lib.fx_system_solve_batch(ctx.handle, C.byref(st), C.byref(o), res.ctypes.data), "fx_system_solve_batch")
+            if k:
+                times.append(_t.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
+        conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+        return {"ms_per_call": dt * 1e3, "ms_per_call_min": min(times) * 1e3, "ms_per_call_max": max(times) * 1e3, "calls": len(times),
+                "converged_systems_per_sec": conv / dt}
+
+    out = {"entry_point": "fx_system_solve_batch", "systems": n}
+    out.update(run())  # pageable buffers, no hint: what a caller gets who does nothing
+    plain_bits = (a["vars"].copy(), res.copy())
+    # ... and with the caller's help (fx_host_register on the arrays that travel, FX_HINT_ONE_STRUCTURE): the hint is verified
+    # against every System beside the device's work (fx_analyze.cpp: verify_one_structure), the results must be the same bits
+    ctx.host_register(a["vars"], a["expr_param"], res)
+    ctx.set_batch_hints(one_structure=True)
+    try:
+        helped = run()
+    finally:
+        ctx.set_batch_hints(one_structure=False)
+        ctx.host_unregister(a["vars"], a["expr_param"], res)
+    helped["same_bits_as_the_plain_call"] = bool(np.array_equal(plain_bits[0].view(np.uint64), a["vars"].view(np.uint64)) and
+                                                 plain_bits[1].tobytes() == res.tobytes())
+    out["registered_buffers_and_one_structure_hint"] = helped
+    return out
 
 
 def other_workloads(ctx, abi, workloads, np, n_sys: int):

@@ -132,6 +132,9 @@ extern "C" {
     pub fn fx_debug_solve_route(ctx: *mut fx_ctx, db: *mut fx_dbatch, opts: *const fx_solving_opts, route: *mut c_int) -> c_int;
     pub fn fx_debug_grouped_build(ctx: *mut fx_ctx, db: *mut fx_dbatch, opts: *const fx_solving_opts, build: *mut c_int) -> c_int;
     pub fn fx_system_solve_batch(ctx: *mut fx_ctx, batch: *const fx_batch, opts: *const fx_solving_opts, results: *mut fx_result) -> c_int;
+    pub fn fx_host_register(ctx: *mut fx_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn fx_host_unregister(ctx: *mut fx_ctx, ptr: *mut c_void) -> c_int;
+    pub fn fx_ctx_set_batch_hints(ctx: *mut fx_ctx, hints: u32) -> c_int;
     pub fn fx_lm_solve_batch(ctx: *mut fx_ctx, batch: *const fx_batch, opts: *const fx_lm_opts, results: *mut fx_result) -> c_int;
     pub fn fx_system_solve_batch_multi(ctxs: *const *mut fx_ctx, n_ctx: u32, batch: *const fx_batch, opts: *const fx_solving_opts, results: *mut fx_result, total: *mut fx_throughput) -> c_int;
     pub fn fx_eval_residual_jacobian(ctx: *mut fx_ctx, batch: *const fx_batch, r: *mut f64, jvals: *mut f64) -> c_int;

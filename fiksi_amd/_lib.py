@@ -111,6 +111,9 @@ SIGNATURES = [
     ("fx_ctx_set_wide_routing", C.c_int, [_vp, C.c_int]),
     ("fx_ctx_set_sparse_fronts", C.c_int, [_vp, C.c_int, C.c_uint32]),
     ("fx_ctx_set_host_threads", C.c_int, [_vp, C.c_uint32]),
+    ("fx_ctx_set_batch_hints", C.c_int, [_vp, C.c_uint32]),
+    ("fx_host_register", C.c_int, [_vp, _vp, C.c_size_t]),
+    ("fx_host_unregister", C.c_int, [_vp, _vp]),
     ("fx_ctx_synchronize", C.c_int, [_vp]),
     ("fx_ctx_device_name", C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     ("fx_lm_opts_default", None, [C.POINTER(FxLmOpts)]),

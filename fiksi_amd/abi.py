@@ -18,6 +18,7 @@ assert RESULT_DTYPE.itemsize == C.sizeof(FxResult)
 
 EXIT_SSE, EXIT_STEP, EXIT_FTOL, EXIT_MAX_OUTER, EXIT_TRIAL_CAP, EXIT_NAN = range(6)
 NO_COMPONENT = 0xFFFF
+HINT_ONE_STRUCTURE = 1  # (FX_HINT_ONE_STRUCTURE)
 
 # fx_tag
 (VARIABLE_VARIABLE_EQUALITY, POINT_POINT_DISTANCE, POINT_POINT_POINT_ANGLE, POINT_LINE_INCIDENCE,
@@ -224,6 +225,22 @@ class Context:
         """Systems beyond one wavefront: the multifrontal build where the structure allows it (default), or the column walkers;
         ranks: lambda trials per launch of a large System alone (0: by the room on the chip, at most 4)."""
         check(lib.fx_ctx_set_sparse_fronts(self._h, 1 if enable else 0, ranks), "fx_ctx_set_sparse_fronts")
+
+    def set_batch_hints(self, one_structure: bool = False):
+        """Hints for the host-buffer calls to come (fx_ctx_set_batch_hints). one_structure: every System of a batch has System 0's
+        structure — the library analyses System 0 alone and verifies the claim against every System while the device works; a
+        batch that fails the check is solved again the ordinary way (the hint is never trusted)."""
+        check(lib.fx_ctx_set_batch_hints(self._h, HINT_ONE_STRUCTURE if one_structure else 0), "fx_ctx_set_batch_hints")
+
+    def host_register(self, *arrays):
+        """Page-locks caller-owned numpy arrays (fx_host_register) so that the copies of a host-buffer call run at the link's rate
+        without the staging buffer; unregister before freeing them."""
+        for a in arrays:
+            check(lib.fx_host_register(self._h, a.ctypes.data, a.nbytes), "fx_host_register")
+
+    def host_unregister(self, *arrays):
+        for a in arrays:
+            check(lib.fx_host_unregister(self._h, a.ctypes.data), "fx_host_unregister")
 
     def set_host_threads(self, threads: int = 0):
         """Host threads for the sparse path's loops when a batch holds several large Systems (fx_ctx_set_host_threads)."""

@@ -157,6 +157,47 @@ int analyze(const fx_batch* b, HostPlan* plan) {
     if (nv > 0 && (!b->vars || !b->var_fixed)) return fail(FX_ERR_INVALID, "vars/var_fixed is NULL");
     if (ne > 0 && (!b->expr_tag || !b->expr_idx || !b->expr_param)) return fail(FX_ERR_INVALID, "expr_* is NULL");
 
+    // The caller's word that every System has the first one's structure (fx_ctx_set_batch_hints): the first System alone is analysed,
+    // its outcome stands for the others — regular offsets are checked here, everything else by verify_one_structure, which the caller
+    // of this function runs beside the device's work and before any result reaches the user.
+    if (plan && g_hint_one_structure && n >= 2) {
+        const uint32_t nv0 = b->var_off[1], ne0 = b->expr_off[1];
+        bool regular = nv0 <= FX_MAX_SYSTEM_VARS && (uint64_t)nv0 * n == nv && (uint64_t)ne0 * n == ne;
+        for (uint32_t s = 1; regular && s <= n; ++s) regular = b->var_off[s] == s * nv0 && b->expr_off[s] == s * ne0;
+        if (regular) {
+            fx_batch first = *b;
+            first.n_systems = 1;
+            HostPlan one;
+            g_hint_one_structure = false;
+            const int rc1 = analyze(&first, &one);
+            g_hint_one_structure = true;
+            if (rc1) return rc1;
+            if (one.n_large == 0) {  // (Systems beyond one wavefront keep a host copy and their own analysis: the ordinary way)
+                HostPlan& p = *plan;
+                p = HostPlan();
+                p.n_systems = n;
+                p.n_vars = nv;
+                p.n_exprs = ne;
+                p.nnz = one.nnz * n;
+                p.max_free = one.max_free; p.max_rows = one.max_rows; p.max_vars = one.max_vars; p.max_exprs = one.max_exprs;
+                p.max_vars_all = one.max_vars_all; p.max_exprs_all = one.max_exprs_all; p.max_pairs = one.max_pairs; p.max_ents = one.max_ents;
+                p.max_pairs_tri = one.max_pairs_tri;
+                p.uniform = 1u;
+                p.hinted = true;
+                p.sys_ncomp.assign(n, one.sys_ncomp[0]);
+                p.sys_large.assign(n, 0);
+                p.same_as_prev.assign(n, 1);
+                p.same_as_prev[0] = 0;
+                // the structure arrays: System 0's only (an upload of a batch of one structure sends one period and the device fills
+                // in the rest; upload_planned reads them at offset 0 for such a batch)
+                p.var_info = one.var_info;
+                p.expr_comp = one.expr_comp;
+                p.expr_idx16 = one.expr_idx16;
+                p.expr_tagx = one.expr_tagx;
+                return FX_OK;
+            }
+        }
+    }
     HostPlan local;
     HostPlan& p = plan ? *plan : local;
     p = HostPlan();
@@ -522,6 +563,27 @@ int analyze(const fx_batch* b, HostPlan* plan) {
         }
     }
     return FX_OK;
+}
+
+// Every System's raw structure arrays against the first System's (what analyze's walk compares System by System when it is not
+// told): threads over ranges of Systems, a pass over the batch's structure bytes.
+bool verify_one_structure(const fx_batch* b) {
+    const uint32_t n = b->n_systems;
+    if (n < 2) return true;
+    const uint32_t nv0 = b->var_off[1], ne0 = b->expr_off[1];
+    std::atomic<uint32_t> differs{0};
+    parallel_ranges(n, (uint64_t)n * (nv0 + ne0), [&](uint32_t, uint32_t lo, uint32_t hi) {
+        bool same = true;
+        for (uint32_t s = std::max(lo, 1u); s < hi && same; ++s) {
+            const size_t v0 = (size_t)s * nv0, e0 = (size_t)s * ne0;
+            same = memcmp(b->var_fixed + v0, b->var_fixed, nv0) == 0 && memcmp(b->expr_tag + e0, b->expr_tag, ne0 * sizeof(*b->expr_tag)) == 0 &&
+                   memcmp(b->expr_idx + 4 * e0, b->expr_idx, 4 * (size_t)ne0 * sizeof(uint32_t)) == 0 &&
+                   (!b->var_comp || memcmp(b->var_comp + v0, b->var_comp, nv0 * sizeof(*b->var_comp)) == 0) &&
+                   (!b->expr_comp || memcmp(b->expr_comp + e0, b->expr_comp, ne0 * sizeof(*b->expr_comp)) == 0);
+        }
+        if (!same) differs.store(1u, std::memory_order_relaxed);
+    });
+    return differs.load() == 0u;
 }
 
 }  // namespace fxh

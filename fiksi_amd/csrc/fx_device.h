@@ -160,6 +160,14 @@ struct DeviceBatch {
     // 1: the batch holds pose rows (FX_TAG_POSE_X / _Y, cluster problems of Decomposer::RecursiveAssembly):
     // only the pose instantiations of the solve kernel may run it
     uint32_t has_pose;
+    // A host-buffer call on page-locked arrays (fx_host_register), one-structure build of the grouped kernel only: the kernel reads a
+    // System's start values and parameters from the caller's arrays when the System's turn comes and writes its solved free variables
+    // and its result record there when it is done — the transfers ride inside the solve instead of before and after it. The device
+    // arrays are still filled (vars0 / vars / expr_param / results stay what they are for every other consumer). Null otherwise.
+    const double* vars_in;     // [n_vars] device-visible address of the caller's vars
+    const double* param_in;    // [n_exprs] ... of the caller's expr_param
+    double* vars_out;          // [n_vars] ... of the caller's vars again (written: free variables of a finished System)
+    fx_result* results_out;    // [n_systems] ... of the caller's results
 };
 
 struct LmParams {

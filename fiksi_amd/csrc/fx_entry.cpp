@@ -6,6 +6,7 @@
 
 using namespace fxh;
 
+#include <mutex>
 #include <stdexcept>
 #include <system_error>
 
@@ -13,6 +14,7 @@ namespace fxh {
 thread_local bool g_allow_pose = false;
 thread_local int g_wide_routing = -1;
 thread_local int g_wide_routing_pinned = -2;
+thread_local bool g_hint_one_structure = false;
 }  // namespace fxh
 
 namespace fx {
@@ -178,6 +180,86 @@ int fx_ctx_set_sparse_fronts(fx_ctx* ctx, int enable, uint32_t ranks) try {
     if (ranks > 4u) return fail(FX_ERR_INVALID, "ranks must be 0 (by the room on the chip) ... 4");
     ctx->sparse_fronts = enable ? 1u : 0u;
     ctx->sparse_front_ranks = ranks;
+    return FX_OK;
+}
+FX_CATCH_CODE
+
+int fx_ctx_set_batch_hints(fx_ctx* ctx, uint32_t hints) try {
+    if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
+    if (hints & ~FX_HINT_ONE_STRUCTURE) return fail(FX_ERR_INVALID, "unknown hint bits 0x%x", hints & ~FX_HINT_ONE_STRUCTURE);
+    ctx->batch_hints = hints;
+    return FX_OK;
+}
+FX_CATCH_CODE
+
+// The ranges fx_host_register has page-locked (process-wide, as the registration is), with their device-visible addresses: a
+// host-buffer call whose arrays lie inside them lets the solve kernel read and write them in place (fx_solve.cpp: solve_host).
+namespace {
+struct HostRange {
+    const unsigned char* host;
+    size_t bytes;
+    unsigned char* dev;
+};
+std::mutex g_ranges_lock;
+std::vector<HostRange> g_ranges;
+}  // namespace
+
+extern "C++" {
+namespace fxh {
+void* registered_range(const void* p, size_t bytes) {
+    if (!p || !bytes) return nullptr;
+    const unsigned char* q = static_cast<const unsigned char*>(p);
+    std::lock_guard<std::mutex> hold(g_ranges_lock);
+    for (const HostRange& r : g_ranges)
+        if (q >= r.host && bytes <= r.bytes && (size_t)(q - r.host) <= r.bytes - bytes) return r.dev + (q - r.host);
+    return nullptr;
+}
+}  // namespace fxh
+}  // extern "C++"
+
+int fx_host_register(fx_ctx* ctx, void* ptr, size_t bytes) try {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ptr || !bytes) return fail(FX_ERR_INVALID, "nothing to register");
+    {
+        std::lock_guard<std::mutex> hold(g_ranges_lock);
+        g_ranges.reserve(g_ranges.size() + 1);  // (before the runtime pins anything: the bookkeeping below cannot fail)
+    }
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? FX_ERR_NOMEM : FX_ERR_HIP, "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {  // (page-locked all the same: the copies run at the link's rate)
+        (void)hipGetLastError();
+        dev = nullptr;
+    }
+    if (dev) {
+        std::lock_guard<std::mutex> hold(g_ranges_lock);
+        g_ranges.push_back({static_cast<const unsigned char*>(ptr), bytes, static_cast<unsigned char*>(dev)});
+    }
+    return FX_OK;
+}
+FX_CATCH_CODE
+
+int fx_host_unregister(fx_ctx* ctx, void* ptr) try {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!ptr) return fail(FX_ERR_INVALID, "ptr is NULL");
+    {
+        std::lock_guard<std::mutex> hold(g_ranges_lock);
+        for (size_t i = 0; i < g_ranges.size(); ++i)
+            if (g_ranges[i].host == ptr) {
+                g_ranges.erase(g_ranges.begin() + (long)i);
+                break;
+            }
+    }
+    hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FX_ERR_HIP, "hipHostUnregister: %s", hipGetErrorString(e));
+    }
     return FX_OK;
 }
 FX_CATCH_CODE
@@ -397,6 +479,30 @@ int fx_system_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
     return solve_beyond_one_wavefront(ctx, db, p);
 }
 FX_CATCH_CODE
+
+extern "C++" {
+namespace fxh {
+// Whether the solve the two entry points above / below would launch for these options is ONE launch of the grouped kernel's
+// one-structure build over the whole batch (fx_grouped_c.hip) — the build that can read and write the caller's arrays in place.
+bool takes_one_structure_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* sopts, const fx_lm_opts* lopts, bool system_level) {
+    fx::LmParams p;
+    ctx->route(p);
+    if (system_level) {
+        fx_solving_opts o;
+        if (sopts) o = *sopts; else fx_solving_opts_default(&o);
+        if (o.optimizer != 0 || o.decomposer != 0) return false;
+        p.lm = o.lm;
+        p.mode = 1u | (o.perturb ? 2u : 0u);
+    } else {
+        if (lopts) p.lm = *lopts; else fx_lm_opts_default(&p.lm);
+        p.mode = 0;
+    }
+    const fx::DeviceBatch& d = db->d;
+    if (p.lm.solver != FX_STEP_CHOLESKY || !d.uniform || db->n_large || !db->classes.empty()) return false;
+    return !fx::grouped_s_applies(d, p) && fx::grouped_applies(d, p) && fx::grouped_c_applies(d, p);
+}
+}  // namespace fxh
+}  // extern "C++"
 
 int fx_lm_solve_device(fx_ctx* ctx, fx_dbatch* db, const fx_lm_opts* opts) try {
     int rc = bind(ctx);

@@ -361,14 +361,24 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
 #pragma unroll
                 for (int k = 0; k < NC; ++k) {
                     const uint32_t i = (uint32_t)(RS * k + hl);
-                    c_var[k] = i < nvt ? b.vars0[v0 + i] : 0.0;
+                    c_var[k] = i < nvt ? (b.vars_in ? b.vars_in : b.vars0)[v0 + i] : 0.0;
                     colk[k] = i < nvt ? (int)vcol[i] : -1;
                 }
 #pragma unroll
                 for (int k = 0; k < RC; ++k) {
                     const uint32_t i = (uint32_t)(RS * k + hl);
-                    c_param[k] = i < net ? b.expr_param[e0 + i] : 0.0;
+                    c_param[k] = i < net ? (b.param_in ? b.param_in : b.expr_param)[e0 + i] : 0.0;
                     tagk[k] = i < net ? (int)rtag[i] : 0;
+                }
+                if (b.param_in) {  // (the closing check reads them again: from the device's copy, not over the link)
+#pragma unroll
+                    for (int k = 0; k < RC; ++k)
+                        if ((uint32_t)(RS * k + hl) < net) b.expr_param[e0 + (uint32_t)(RS * k + hl)] = c_param[k];
+                }
+                if (b.vars_in) {  // (start values stay on the device: a refused hint puts them back, fx_solve.cpp)
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+                        if ((uint32_t)(RS * k + hl) < nvt) b.vars0[v0 + (uint32_t)(RS * k + hl)] = c_var[k];
                 }
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 // K0a: system scale, summed strictly in reference order (utils.rs:11-33)
@@ -724,6 +734,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                     const double x = (double)xc[q];
                     const double xo = (prm.mode & 1u) ? scale * x : x;
                     b.vars[v0 + my_vi[q]] = xo;
+                    if (b.vars_out) b.vars_out[v0 + my_vi[q]] = xo;
                     VOUT[my_vi[q]] = xo;
                 }
             }
@@ -756,6 +767,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
                 res.sse = (double)sse;
                 res.sse_unscaled = sse_u;
                 b.results[s] = res;
+                if (b.results_out) b.results_out[s] = res;
             }
             group_sync();
             phase = GP_NEXT;

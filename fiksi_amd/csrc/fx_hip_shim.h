@@ -60,6 +60,20 @@ inline hipError_t hipFree(void* p) {
 }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void* p) { return hipFree(p); }
+constexpr unsigned hipHostRegisterDefault = 0u;
+constexpr unsigned hipHostRegisterMapped = 2u;
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+    *least = 0;
+    *greatest = -1;
+    return hipSuccess;
+}
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipHostUnregister(void*) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {  // (the make-believe device's memory is the host's)
+    *dev = host;
+    return fx_shim_fake() ? hipSuccess : hipErrorNoDevice;
+}
+inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
     if (!fx_shim_fake()) return hipErrorNoDevice;
     if (n) std::memmove(d, s, n);
@@ -73,6 +87,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
 }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return fx_shim_fake() ? hipSuccess : hipErrorNoDevice; }
 constexpr unsigned hipEventDisableTiming = 2u;

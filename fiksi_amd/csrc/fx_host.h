@@ -39,6 +39,9 @@ extern thread_local bool g_allow_pose;
 extern thread_local int g_wide_routing;
 // fx_system_solve_batch_multi: the choice made once on the whole batch, for every shard (-2: none)
 extern thread_local int g_wide_routing_pinned;
+// the running host-buffer call was told that its batch is of one structure (fx_ctx_set_batch_hints): analyze takes the first System's
+// word for the others — the caller of analyze verifies (verify_one_structure) before anything reaches the user's arrays
+extern thread_local bool g_hint_one_structure;
 
 // FIKSI_AMD_TRACE=1: where the wall time of a host-buffer call goes (one line per phase on stderr)
 struct PhaseTrace {
@@ -77,6 +80,7 @@ struct HostPlan {
     uint32_t max_free = 0, max_rows = 0, max_vars = 0, max_exprs = 0, max_vars_all = 0, max_exprs_all = 0;
     uint32_t max_pairs = 0, max_ents = 0, max_pairs_large = 0, max_ents_large = 0, max_pairs_tri = 0;
     uint32_t uniform = 0;  // every System has the same structure (one sketch, many parameter sets)
+    bool hinted = false;   // ... on the caller's word (fx_ctx_set_batch_hints): only System 0 was analysed, verify_one_structure is still owed
     std::vector<uint32_t> sys_class;  // not uniform: the first System with this System's structure (empty: not computed)
     std::vector<uint16_t> sys_ncomp;
     std::vector<uint8_t> sys_large;  // 0 fused kernel, 2 wide kernel (65..128 free variables), 1 sparse path
@@ -131,6 +135,7 @@ void build_csr(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, co
 void build_eval_plan(uint32_t n, const uint32_t* var_off, const uint32_t* expr_off, const uint16_t* var_info, const uint8_t* expr_tagx,
                      const uint16_t* expr_idx16, EvalPlan& out);
 int analyze(const fx_batch* b, HostPlan* plan);
+bool verify_one_structure(const fx_batch* b);  // every System's raw structure arrays equal the first System's
 
 }  // namespace fxh
 
@@ -154,6 +159,7 @@ struct fx_ctx {
     uint32_t ladder = 1u, ladder_k = 8u, ladder_tail = 0xFFFFFFFFu, ladder_spread = 1u;  // fx_ctx_set_ladder
     int wide_routing = -1;                 // fx_ctx_set_wide_routing
     uint32_t sparse_fronts = 1u, sparse_front_ranks = 0u;  // fx_ctx_set_sparse_fronts
+    uint32_t batch_hints = 0u;             // fx_ctx_set_batch_hints
     uint32_t host_threads = 8u;            // fx_ctx_set_host_threads: groups of large Systems (one structure each) solved side by side
     std::vector<hipStream_t> worker_streams;  // ... a stream per extra host thread
     // Page-locked staging for one-shot solves up to 8 MB of batch (System::solve on one sketch ... some ten thousand small
@@ -317,6 +323,7 @@ struct fx_dbatch {
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
     std::vector<uint8_t> h_qr_wide;          // FX_STEP_QR: Systems beyond one wavefront the wide kernel's QR build solves (ensure_qr_plans)
     bool qr_wide_active = false;             // ... and they have just been solved that way: the sparse path leaves them alone
+    bool in_place = false;                   // d.vars_in / param_in are set: vars0 / expr_param are filled by the solve kernel itself (no scout pass may read them first)
     // sparse-path plans of the batch's large Systems, one per structure and decomposer mode (hash -> candidates)
     struct ResidentPlan {
         std::vector<unsigned char> key;
@@ -402,7 +409,13 @@ int ensure_csr(fx_ctx* ctx, fx_dbatch* db);
 int ensure_units(fx_ctx* ctx, fx_dbatch* db);
 int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units);
 int ensure_component_walk(fx_ctx* ctx, fx_dbatch* db);
-int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out, bool one_shot = false);
+constexpr uint32_t FX_DEFER_VARS = 1u, FX_DEFER_PARAMS = 2u;  // upload_planned: room for vars0 / vars (expr_param), no values yet
+int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out, bool one_shot = false,
+                   uint32_t defer = 0);
+int fill_deferred(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch, uint32_t defer);
+bool takes_one_structure_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* sopts, const fx_lm_opts* lopts, bool system_level);
+// fx_host_register's ranges: the device-visible address of [p, p + bytes) when the whole range lies inside one of them, else null
+void* registered_range(const void* p, size_t bytes);
 int read_back_and_free(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch, fx_result* results, int rc);
 
 // ---- fx_programs.cpp: the table programs of the kernels for batches of one structure, and the QR plans
@@ -441,6 +454,7 @@ bool wide_kernel_applies(const fx::LmParams& p);
 int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p);
 int solve_beyond_one_wavefront(fx_ctx* ctx, fx_dbatch* db, fx::LmParams p);
 
-int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts, bool system_level, fx_result* results);
+int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts, bool system_level, fx_result* results,
+               bool no_hint = false);
 
 }  // namespace fxh

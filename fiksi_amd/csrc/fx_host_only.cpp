@@ -95,4 +95,39 @@ void fx_test_fail_alloc_at(long n) { __atomic_store_n(&g_fail_countdown, n, __AT
 long fx_test_alloc_count(void) { return __atomic_load_n(&g_alloc_count, __ATOMIC_RELAXED); }
 long fx_test_live_allocations(void) { return __atomic_load_n(&g_live, __ATOMIC_RELAXED); }
 long fx_test_live_device_blocks(void) { return __atomic_load_n(&fx_shim_live_blocks(), __ATOMIC_RELAXED); }
+// The one-structure hint (fx_ctx_set_batch_hints) without a device: 1 when the verification accepts the batch ...
+int fx_test_verify_one_structure(const fx_batch* b) { return fxh::verify_one_structure(b) ? 1 : 0; }
+// ... and, for a batch that is of one structure, whether the plan made from System 0 alone says what the full analysis says:
+// 0 the same, > 0 the first thing that differs, < 0 an error code of the analysis, -100 the hint was not taken
+int fx_test_hinted_plan_differs(const fx_batch* b) try {
+    fxh::HostPlan full, hint;
+    int rc = fxh::analyze(b, &full);
+    if (rc) return rc;
+    fxh::g_hint_one_structure = true;
+    rc = fxh::analyze(b, &hint);
+    fxh::g_hint_one_structure = false;
+    if (rc) return rc;
+    if (!hint.hinted) return -100;
+    if (!full.uniform || !hint.uniform) return 1;
+    if (full.nnz != hint.nnz || full.max_free != hint.max_free || full.max_rows != hint.max_rows || full.max_vars != hint.max_vars ||
+        full.max_exprs != hint.max_exprs || full.max_vars_all != hint.max_vars_all || full.max_exprs_all != hint.max_exprs_all ||
+        full.max_pairs != hint.max_pairs || full.max_ents != hint.max_ents || full.max_pairs_tri != hint.max_pairs_tri ||
+        full.n_large != hint.n_large || full.max_pairs_large != hint.max_pairs_large || full.max_ents_large != hint.max_ents_large)
+        return 2;
+    if (full.sys_ncomp != hint.sys_ncomp || full.sys_large != hint.sys_large || full.wide_list != hint.wide_list ||
+        full.wide_decision != hint.wide_decision || !hint.sys_class.empty())
+        return 3;
+    const uint32_t nv0 = b->var_off[1], ne0 = b->expr_off[1];
+    if (hint.var_info.size() != nv0 || hint.expr_comp.size() != ne0 || hint.expr_idx16.size() != 4 * (size_t)ne0 || hint.expr_tagx.size() != ne0) return 4;
+    for (uint32_t s = 0; s < b->n_systems; ++s) {  // (the device fills the periods in: every System's analysed arrays are the first one's)
+        if (memcmp(full.var_info.data() + (size_t)s * nv0, hint.var_info.data(), nv0 * sizeof(uint16_t))) return 5;
+        if (memcmp(full.expr_comp.data() + (size_t)s * ne0, hint.expr_comp.data(), ne0 * sizeof(uint16_t))) return 6;
+        if (memcmp(full.expr_idx16.data() + 4 * (size_t)s * ne0, hint.expr_idx16.data(), 4 * (size_t)ne0 * sizeof(uint16_t))) return 7;
+        if (memcmp(full.expr_tagx.data() + (size_t)s * ne0, hint.expr_tagx.data(), ne0)) return 8;
+    }
+    return 0;
+} catch (...) {
+    fxh::g_hint_one_structure = false;
+    return fx::translate_exception();
+}
 }

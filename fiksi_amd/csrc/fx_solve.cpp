@@ -76,7 +76,8 @@ int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         int rc = FX_OK;
         if (launch_class_solves(ctx, db, p, &rc)) return rc;
     }
-    if (ctx->presort && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
+    // (a batch solved in place on the caller's arrays has no start values on the device yet for the scout pass to rank by)
+    if (ctx->presort && !db->in_place && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
         const uint32_t n = d.n_systems;
         if (!db->ps_keys) {
             db->ps_temp_bytes = fx::presort_temp_bytes(n);
@@ -304,6 +305,7 @@ int solve_beyond_one_wavefront(fx_ctx* ctx, fx_dbatch* db, fx::LmParams p) {
 // is copied up (second stream) while chunk k is being solved; the read-backs follow in order. Every System is solved on its
 // own and every chunk runs the kernels the whole batch would, so the cut changes nothing in the results (the tests compare
 // the bits). FIKSI_AMD_HOST_CHUNKS=0 switches it off, =k sets the number of chunks.
+constexpr int FX_HINT_REFUSED = 1;  // (internal to this file: the hinted batch failed its verification — never returned to a caller)
 static int solve_host_chunked(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t n_chunks, const fx_solving_opts* sopts,
                               const fx_lm_opts* lopts, bool system_level, fx_result* results) {
     const uint32_t n = p.n_systems;
@@ -341,6 +343,8 @@ static int solve_host_chunked(fx_ctx* ctx, const fx_batch* batch, const HostPlan
         rc = system_level ? fx_system_solve_device(ctx, c.db, sopts) : fx_lm_solve_device(ctx, c.db, lopts);
     }
     tr.stamp("chunks: up + launched", n);
+    if (rc == FX_OK && p.hinted && !verify_one_structure(batch)) rc = FX_HINT_REFUSED;  // (beside the device's work; nothing is back yet)
+    if (p.hinted) tr.stamp("one structure: verified", n);
     if (rc != FX_OK) {  // nothing has been written to the caller's arrays yet
         (void)hipStreamSynchronize(ctx->stream2);
         for (Chunk& c : chunks)
@@ -361,28 +365,105 @@ static int solve_host_chunked(fx_ctx* ctx, const fx_batch* batch, const HostPlan
     return rc;
 }
 
+// A batch of one structure whose value arrays the caller has page-locked (fx_host_register): the structure goes up as ever (one
+// period per array, a few hundred KB of offsets), the values do not — the one-structure build of the grouped kernel reads a System's
+// start values and parameters from the caller's arrays when the System's turn comes, and writes the solved variables and the result
+// record back there when it is done, so the transfers are spread over the solve instead of standing before and after it (100 000
+// ring16 sketches: 51 MB up, 35 MB down). The device keeps its own copy of everything (vars0 included: a refused hint
+// puts the caller's start values back from there). A solve that would not take that build fills the values in by ordinary copies.
+static int solve_host_in_place(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, void* dev_vars, void* dev_params, void* dev_results,
+                               const fx_solving_opts* sopts, const fx_lm_opts* lopts, bool system_level, fx_result* results, PhaseTrace& tr) {
+    fx_dbatch* db = nullptr;
+    const uint32_t defer = FX_DEFER_VARS | FX_DEFER_PARAMS;
+    int rc = upload_planned(ctx, batch, p, 0, p.n_systems, &db, /*one_shot=*/true, defer);
+    if (rc) return rc;
+    BatchHolder hold(ctx, db);
+    db->resident = false;
+    tr.stamp("upload (structure only)", p.n_systems);
+    if (!takes_one_structure_build(ctx, db, sopts, lopts, system_level)) {
+        rc = fill_deferred(ctx, db, batch, defer);
+        tr.stamp("values, by copies", p.n_systems);
+        if (rc) return rc;
+        rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
+        if (p.hinted && !rc && !verify_one_structure(batch)) return FX_HINT_REFUSED;  // (nothing is back yet; the holder frees the batch)
+        return read_back_and_free(ctx, hold.release(), batch, results, rc);
+    }
+    fx::DeviceBatch& d = db->d;
+    db->in_place = true;
+    d.vars_in = static_cast<const double*>(dev_vars);
+    d.param_in = static_cast<const double*>(dev_params);
+    d.vars_out = static_cast<double*>(dev_vars);
+    d.results_out = static_cast<fx_result*>(dev_results);
+    rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
+    tr.stamp("solve (launched)", p.n_systems);
+    if (rc) return rc;  // (refused before any launch: the caller's arrays are as they were)
+    const bool kept = !p.hinted || verify_one_structure(batch);  // beside the device's work
+    if (p.hinted) tr.stamp("one structure: verified", p.n_systems);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->stream_synced();
+    tr.stamp("wait", p.n_systems);
+    if (e != hipSuccess) return fail(FX_ERR_HIP, "solve failed: %s", hipGetErrorString(e));
+    if (!kept) {  // the promise was not kept: the caller's start values back from the device's copy, then the ordinary way
+        FX_HIP(hipMemcpy(batch->vars, d.vars0, (size_t)d.n_vars * sizeof(double), hipMemcpyDeviceToHost));
+        return FX_HINT_REFUSED;
+    }
+    if (results && !dev_results) rc = fx_batch_get_results(ctx, db, results);
+    return rc;
+}
+
 int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts, const fx_lm_opts* lopts,
-                      bool system_level, fx_result* results) {
+               bool system_level, fx_result* results, bool no_hint) {
     int rc = bind(ctx);
     if (rc) return rc;
     fx_dbatch* db = nullptr;
     PhaseTrace tr;
+    bool hinted = false;
     {
         HostPlan p;
         g_wide_routing = ctx->wide_routing;
-        rc = analyze(batch, &p);
+        g_hint_one_structure = (ctx->batch_hints & FX_HINT_ONE_STRUCTURE) != 0 && !no_hint;
+        try {
+            rc = analyze(batch, &p);
+        } catch (...) {
+            g_hint_one_structure = false;
+            throw;
+        }
+        g_hint_one_structure = false;
         if (rc) return rc;
+        hinted = p.hinted;
         tr.stamp("analysis", p.n_systems);
         // Two chunks from 65 536 Systems on: measured on 100 000 ring16 sketches (tools/host_path.py), 2 chunks
         // 6.3 ms, 3 and 4 chunks 6.8 ms, 8 chunks 8.7 ms, uncut 7.6 ms — every chunk pays its own dozen copies and the slow
         // end of its own solve, so more chunks lose what the earlier start of the first solve wins
+        static const bool in_place_on = [] { const char* e = std::getenv("FIKSI_AMD_IN_PLACE"); return !e || atoi(e) != 0; }();
+        if (in_place_on && p.uniform && p.n_large == 0 && p.wide_list.empty() && p.n_systems >= 16384u) {
+            void* dv = registered_range(batch->vars, (size_t)p.n_vars * sizeof(double));
+            void* dp = registered_range(batch->expr_param, (size_t)p.n_exprs * sizeof(double));
+            void* dr = results ? registered_range(results, (size_t)p.n_systems * sizeof(fx_result)) : nullptr;
+            if (dv && dp) {
+                rc = solve_host_in_place(ctx, batch, p, dv, dp, dr, sopts, lopts, system_level, results, tr);
+                return rc == FX_HINT_REFUSED ? solve_host(ctx, batch, sopts, lopts, system_level, results, /*no_hint=*/true) : rc;
+            }
+        }
         static const int forced = [] { const char* e = std::getenv("FIKSI_AMD_HOST_CHUNKS"); return e ? atoi(e) : -1; }();
         uint32_t n_chunks = p.n_systems >= 65536u ? 2u : 0u;
         if (forced >= 0) n_chunks = std::min<uint32_t>((uint32_t)forced, p.n_systems / 2u);
-        if (n_chunks >= 2 && p.n_large == 0 && (ctx->stream2 || hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) == hipSuccess) &&
+        // (the copy stream at the highest priority: a chunk's small copies and period fills are kernels, and behind the workgroups of
+        // the chunk before's solve one of them took 0.5 ms instead of 5 us — profiles/round5_host_path.md)
+        auto copy_stream = [&]() {
+            if (ctx->stream2) return true;
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) greatest = 0;
+            return hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, greatest) == hipSuccess;
+        };
+        if (n_chunks >= 2 && p.n_large == 0 && copy_stream() &&
             (ctx->stream3 || hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) == hipSuccess) &&
             (ctx->ev_chunk || hipEventCreateWithFlags(&ctx->ev_chunk, hipEventDisableTiming) == hipSuccess))
-            return solve_host_chunked(ctx, batch, p, n_chunks, sopts, lopts, system_level, results);
+        {
+            rc = solve_host_chunked(ctx, batch, p, n_chunks, sopts, lopts, system_level, results);
+            // the batch was not of one structure after all: again, the ordinary way (the caller's arrays are untouched)
+            return rc == FX_HINT_REFUSED ? solve_host(ctx, batch, sopts, lopts, system_level, results, /*no_hint=*/true) : rc;
+        }
         rc = upload_planned(ctx, batch, p, 0, p.n_systems, &db, /*one_shot=*/true);
     }
     if (rc) return rc;
@@ -391,6 +472,8 @@ int solve_host(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* sopts,
     db->resident = false;  // solved once and freed: no point in keeping plans
     rc = system_level ? fx_system_solve_device(ctx, db, sopts) : fx_lm_solve_device(ctx, db, lopts);
     tr.stamp("solve (launches)", batch->n_systems);
+    if (hinted && !rc && !verify_one_structure(batch))  // (beside the device's work; the holder frees the batch, nothing is back yet)
+        return solve_host(ctx, batch, sopts, lopts, system_level, results, /*no_hint=*/true);
     rc = read_back_and_free(ctx, hold.release(), batch, results, rc);
     tr.stamp("wait + read back", batch->n_systems);
     return rc;

@@ -677,7 +677,8 @@ int ensure_component_walk(fx_ctx* ctx, fx_dbatch* db) {
 
 // Systems [s0, s1) of an analysed batch onto the device (the whole batch, or one chunk of solve_host_chunked: the limits
 // that size kernels and LDS are the whole batch's either way, so a chunk runs the very kernels the whole batch would).
-int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out, bool one_shot) {
+int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32_t s0, uint32_t s1, fx_dbatch** out, bool one_shot,
+                   uint32_t defer) {
     *out = nullptr;
     int rc = FX_OK;
     const bool whole = s0 == 0 && s1 == p.n_systems;
@@ -742,7 +743,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     //  - a big batch: one copy per array straight from the caller's memory (no extra pass over 100 MB on the host).
     // (`period`: the array repeats with this period — the structure arrays of a batch of one structure —, so a big batch sends
     // its first `period` bytes over the bus and the device fills in the rest: 45 % of a ring16 batch's bytes)
-    struct Req { void** dst; const void* src; size_t bytes; size_t period; };
+    struct Req { void** dst; const void* src; size_t bytes; size_t period; bool later = false; };
     std::vector<Req> reqs;
 #define FX_UP(field, host, count) \
     reqs.push_back({reinterpret_cast<void**>(&d.field), static_cast<const void*>(host), (size_t)(count) * sizeof(*d.field), 0});
@@ -754,11 +755,16 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     FX_UP(sys_ncomp, p.sys_ncomp.data() + s0, n_sys)
     FX_UP(sys_large, p.sys_large.data() + s0, n_sys)
     FX_UP(vars0, (const double*)batch->vars + v0, n_vars)
-    FX_UP_PERIODIC(var_info, p.var_info.data() + v0, n_vars, d.u_nvars)
-    FX_UP_PERIODIC(expr_tag, p.expr_tagx.data() + e0, n_exprs, d.u_nexprs)
-    FX_UP_PERIODIC(expr_comp, p.expr_comp.data() + e0, n_exprs, d.u_nexprs)
-    FX_UP_PERIODIC(expr_idx, p.expr_idx16.data() + 4 * (size_t)e0, 4 * (size_t)n_exprs, 4 * (size_t)d.u_nexprs)
+    reqs.back().later = (defer & FX_DEFER_VARS) != 0;  // (room only: the solve kernel or fill_deferred brings the values)
+    // (a hinted batch — HostPlan::hinted — holds the first System's structure only: such a batch is big, goes up by periods, and
+    // the programs below read one System)
+    const uint32_t pv0 = p.hinted ? 0u : v0, pe0 = p.hinted ? 0u : e0;
+    FX_UP_PERIODIC(var_info, p.var_info.data() + pv0, n_vars, d.u_nvars)
+    FX_UP_PERIODIC(expr_tag, p.expr_tagx.data() + pe0, n_exprs, d.u_nexprs)
+    FX_UP_PERIODIC(expr_comp, p.expr_comp.data() + pe0, n_exprs, d.u_nexprs)
+    FX_UP_PERIODIC(expr_idx, p.expr_idx16.data() + 4 * (size_t)pe0, 4 * (size_t)n_exprs, 4 * (size_t)d.u_nexprs)
     FX_UP(expr_param, batch->expr_param + e0, n_exprs)
+    reqs.back().later = (defer & FX_DEFER_PARAMS) != 0;
     FX_UP(work_counter, (const uint32_t*)nullptr, 16)  // (the batch's queue head, then those of up to eight structure classes and of the rest: launch_class_solves)
     if (sys_class) FX_UP(sys_class, sys_class, n_sys)
     // A batch of one structure gets the program of one of the grouped kernel's builds for such batches, when the structure
@@ -770,7 +776,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     GcHostProgram gc;
     bool sparse_build = false;
     if (d.uniform && d.u_ncomp == 1u && d.u_nvars <= 255u && d.u_nexprs <= 255u &&
-        build_gs_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0, d.u_nvars,
+        build_gs_program(p.var_info.data() + pv0, p.expr_tagx.data() + pe0, p.expr_comp.data() + pe0, p.expr_idx16.data() + 4 * (size_t)pe0, d.u_nvars,
                          d.u_nexprs, gs))
         sparse_build = gs.nfree > 48u || 4u * gs.nl <= gs.nfree * (gs.nfree + 1u) / 2u;
     if (sparse_build) {
@@ -780,7 +786,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
         d.gs_ng = gs.ng;
         d.gs_nfree = gs.nfree;
     } else if (d.uniform && d.u_ncomp == 1u && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u &&
-               build_gc_program(p.var_info.data() + v0, p.expr_tagx.data() + e0, p.expr_comp.data() + e0, p.expr_idx16.data() + 4 * (size_t)e0,
+               build_gc_program(p.var_info.data() + pv0, p.expr_tagx.data() + pe0, p.expr_comp.data() + pe0, p.expr_idx16.data() + 4 * (size_t)pe0,
                                 d.u_nvars, d.u_nexprs, p.max_free, gc)) {
         FX_UP(gc_tab, gc.words.data(), gc.words.size())
         d.gc_words = gc.words_f64;
@@ -859,6 +865,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     FX_UP(w_list, p.wide_list.data(), whole ? p.wide_list.size() : 0)
     const size_t n_front = reqs.size();  // the two below end the block, side by side: a one-shot solve reads them back in one copy
     FX_UP(vars, (const double*)batch->vars + v0, n_vars)
+    reqs.back().later = (defer & FX_DEFER_VARS) != 0;
     FX_UP(results, (const fx_result*)nullptr, n_sys)
 #undef FX_UP
 #undef FX_UP_PERIODIC
@@ -873,7 +880,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     // image into the context's host-coherent region, one small kernel pulls it over in a burst and another pushes `vars` and
     // `results` back when the solve is done (2 us each; a solve kernel working on the region in place pays a PCIe round trip
     // per dependent load, and waits for its stores: 40 / 30 us instead of 10 — both measured).
-    const bool zero_copy = one_shot && whole && packed <= fx_ctx::ZC_BYTES && p.n_large == 0 && p.wide_list.empty() && ctx->ensure_zc();
+    const bool zero_copy = one_shot && whole && !defer && packed <= fx_ctx::ZC_BYTES && p.n_large == 0 && p.wide_list.empty() && ctx->ensure_zc();
     db->allocations.reserve(db->allocations.size() + 1);
     unsigned char* base = static_cast<unsigned char*>(ctx->take(packed, e1));
     if (!base) {
@@ -899,7 +906,11 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
             for (const Req& r : reqs) {
                 const size_t room = room_of(r);
                 if (r.src && r.bytes) {
-                    memcpy(img + at, r.src, r.bytes);
+                    if (p.hinted && r.period && r.period < r.bytes) {
+                        for (size_t o2 = 0; o2 < r.bytes; o2 += r.period) memcpy(img + at + o2, r.src, std::min(r.period, r.bytes - o2));
+                    } else {
+                        memcpy(img + at, r.src, r.bytes);
+                    }
                     memset(img + at + r.bytes, 0, room - r.bytes);
                 } else {
                     memset(img + at, 0, room);
@@ -929,8 +940,12 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
             for (size_t i = 0; i < reqs.size() && at < staged; ++i) {
                 const Req& r = reqs[i];
                 const size_t room = room_of(r);
-                if (r.src && r.bytes) {
-                    memcpy(st + at, r.src, r.bytes);
+                if (r.src && r.bytes && !r.later) {
+                    if (p.hinted && r.period && r.period < r.bytes) {
+                        for (size_t o2 = 0; o2 < r.bytes; o2 += r.period) memcpy(st + at + o2, r.src, std::min(r.period, r.bytes - o2));
+                    } else {
+                        memcpy(st + at, r.src, r.bytes);
+                    }
                     memset(st + at + r.bytes, 0, room - r.bytes);
                 } else {
                     memset(st + at, 0, room);
@@ -948,6 +963,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
         } else {
             for (size_t i = 0; i < n_front; ++i) {
                 const Req& r = reqs[i];
+                if (r.later) continue;
                 if (r.src && r.bytes && r.period && r.period < r.bytes) {
                     FX_HIP(hipMemcpyAsync(*r.dst, r.src, r.period, hipMemcpyHostToDevice, ctx->stream));
                     FX_HIP(fx::launch_replicate(*r.dst, r.period, r.bytes, ctx->stream));
@@ -959,7 +975,8 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
             }
         }
         if (on_device_tail) {
-            if (n_vars) FX_HIP(hipMemcpyAsync(d.vars, d.vars0, (size_t)n_vars * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            if (n_vars && !(defer & FX_DEFER_VARS))
+                FX_HIP(hipMemcpyAsync(d.vars, d.vars0, (size_t)n_vars * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             FX_HIP(hipMemsetAsync(d.results, 0, room_of(reqs.back()), ctx->stream));
         }
         return FX_OK;
@@ -1016,6 +1033,21 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
         return fail(FX_ERR_TOO_LARGE, "batch needs %zu bytes of LDS per wavefront (limit 163840)", fx::solve_lds_bytes(d));
     }
     *out = hold.release();
+    return FX_OK;
+}
+
+// What upload_planned left out on request (`defer`): the values, by ordinary copies — the solve did not take the route that reads
+// them in place after all.
+int fill_deferred(fx_ctx* ctx, fx_dbatch* db, const fx_batch* batch, uint32_t defer) {
+    fx::DeviceBatch& d = db->d;
+    if ((defer & FX_DEFER_VARS) && d.n_vars) {
+        FX_HIP(hipMemcpyAsync(d.vars0, batch->vars, (size_t)d.n_vars * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        FX_HIP(hipMemcpyAsync(d.vars, d.vars0, (size_t)d.n_vars * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if ((defer & FX_DEFER_PARAMS) && d.n_exprs)
+        FX_HIP(hipMemcpyAsync(d.expr_param, batch->expr_param, (size_t)d.n_exprs * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    FX_HIP(hipStreamSynchronize(ctx->stream));  // (pageable sources: the caller may not outlive an asynchronous copy's staging)
+    ctx->stream_synced();
     return FX_OK;
 }
 

@@ -369,6 +369,20 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
  * same large sketch with new values pays for it once (a plan's index arrays stay in device memory until it is dropped;
  * fx_ctx_destroy frees them all). */
 int fx_system_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_solving_opts* opts, fx_result* results);
+/* What a host that calls the entry points above again and again on the same buffers can do for them. Both are optional and
+ * change no result.
+ *  - fx_host_register / fx_host_unregister: page-locks caller-owned memory (the arrays a batch points to, the result array) for
+ *    the device's copy engines: copies to and from registered memory run at the bus's rate instead of through a staging
+ *    buffer (100 000 ring16 sketches: 82 MB per call). The memory stays the caller's; unregister before freeing it.
+ *  - fx_ctx_set_batch_hints(ctx, FX_HINT_ONE_STRUCTURE): the caller says that every System of the batches to come has the
+ *    structure of the first (one sketch, many parameter sets). The library does not believe it: the comparison of every
+ *    System with the first — a pass of the host over 100 MB that otherwise comes before anything is uploaded — runs while
+ *    the device already works, and a batch that turns out not to be of one structure is solved again the ordinary way before
+ *    anything is written to the caller's arrays. 0 clears the hints. */
+#define FX_HINT_ONE_STRUCTURE 1u
+int fx_host_register(fx_ctx* ctx, void* ptr, size_t bytes);
+int fx_host_unregister(fx_ctx* ctx, void* ptr);
+int fx_ctx_set_batch_hints(fx_ctx* ctx, uint32_t hints);
 /* == levenberg_marquardt(Subsystem): values used as given (already scaled/perturbed). */
 int fx_lm_solve_batch(fx_ctx* ctx, const fx_batch* batch, const fx_lm_opts* opts, fx_result* results);
 

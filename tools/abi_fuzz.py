@@ -179,6 +179,36 @@ if ctxs:
                 note("fx_system_solve_device (classes / programs)", lib.fx_system_solve_device(ctxs[0], db, C.byref(o)))
                 lib.fx_batch_free(ctxs[0], db)
 
+# ---------------- host-buffer calls under the one-structure hint, on registered buffers (round 5) ----------------
+if ctxs:
+    lib.fx_ctx_set_batch_hints(ctxs[0], abi.HINT_ONE_STRUCTURE)
+    for it in range(4):
+        b = [workloads.ring16(700), workloads.hinged_triangles(300, 11), workloads.ring16(70000 if n_iter >= 100 else 5000),
+             workloads.concat([workloads.ring16(40), workloads.hinged_triangles(40, 5)])][it]
+        for wrong in (False, True):  # the claim holds / one System differs: the library must find out by itself
+            a = abi.normalize_batch({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()})
+            if wrong:
+                s = len(a["var_off"]) // 2
+                a["expr_idx"][4 * int(a["expr_off"][s]) + 1] ^= 1
+                a["var_fixed"][int(a["var_off"][s])] ^= 1
+            if hasattr(lib, "fx_test_verify_one_structure"):  # (the sanitizer build's hooks, fx_host_only.cpp)
+                ok = lib.fx_test_verify_one_structure(C.byref(abi.as_struct(a)))
+                assert ok == (0 if wrong or it == 3 else 1), ("verify_one_structure", it, wrong, ok)
+                if not wrong and it != 3:
+                    d = lib.fx_test_hinted_plan_differs(C.byref(abi.as_struct(a)))
+                    assert d == 0, ("the plan from System 0 alone differs from the full analysis", it, d)
+                    note("hinted plan == full plan", d)
+            res = np.zeros(len(a["var_off"]) - 1, dtype=abi.RESULT_DTYPE)
+            for arr in (a["vars"], a["expr_param"], res):
+                note("fx_host_register", lib.fx_host_register(ctxs[0], ptr(arr), arr.nbytes))
+            o = abi.solving_opts()
+            note("fx_system_solve_batch (hinted)", lib.fx_system_solve_batch(ctxs[0], C.byref(abi.as_struct(a)), C.byref(o), ptr(res)))
+            for arr in (a["vars"], a["expr_param"], res):
+                note("fx_host_unregister", lib.fx_host_unregister(ctxs[0], ptr(arr)))
+    note("fx_host_unregister (never registered)", lib.fx_host_unregister(ctxs[0], ptr(np.zeros(4))))
+    note("fx_host_register (null)", lib.fx_host_register(ctxs[0], None, 64))
+    lib.fx_ctx_set_batch_hints(ctxs[0], 0)
+
 for h in ctxs:
     lib.fx_ctx_destroy(h)
 print("return codes:", codes)
