@@ -65,12 +65,9 @@ struct SpLm {
 // split, but everything around it can: 256 threads square 4096 values at a time into LDS (+0.0 for expressions without
 // a distance: exact), then ONE thread adds them up in order, sixteen LDS values in flight per step. (The first
 // version added 64 values per step through v_readlane pairs: 0.83 ms for cfg2's 20 000 values; this one ~0.1 ms.)
-__global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows,
-                                                      double* __restrict__ scal, int do_scale, size_t stride) {
-    // (stride: value arrays of the group's System blockIdx.y lie blockIdx.y * stride doubles further; 0 for one System)
-    vars0 += blockIdx.y * stride;
-    rows.param += blockIdx.y * stride;
-    scal += blockIdx.y * stride;
+// (the body: a workgroup of 256 threads, pointers of ITS System — shared by the kernel below and by spg_prologue_kernel)
+__device__ __forceinline__ void sp_scale_body(const double* __restrict__ vars0, uint32_t nvt, const SpRows& rows, double* __restrict__ scal,
+                                              int do_scale) {
     constexpr uint32_t CH = 4096;
     __shared__ double sq[CH + 64];
     __shared__ uint32_t cnt_s[256];
@@ -125,6 +122,12 @@ __global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict_
         scal[0] = scale;
         scal[1] = 1.0 / scale;
     }
+}
+__global__ __launch_bounds__(256) void sp_scale_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows,
+                                                      double* __restrict__ scal, int do_scale, size_t stride) {
+    // (stride: value arrays of the group's System blockIdx.y lie blockIdx.y * stride doubles further; 0 for one System)
+    rows.param += blockIdx.y * stride;
+    sp_scale_body(vars0 + blockIdx.y * stride, nvt, rows, scal + blockIdx.y * stride, do_scale);
 }
 
 __global__ void sp_init_kernel(const double* __restrict__ vars0, uint32_t nvt, SpRows rows, const double* __restrict__ scal,
@@ -237,6 +240,78 @@ struct SpRowsOfL {               // L by rows (strictly lower part), for the for
 
 #include "fx_sparse_team.h"
 #include "fx_front.h"
+
+// Everything before the first block of a System of ONE component, in one launch (a workgroup per System of the group): what
+// spg_begin_kernel, sp_scale_kernel, sp_init_kernel, sp_perturb_kernel and spg_component_kernel do one after the other — each of
+// those launches costs the host ~7 us to issue, which a lone 258-variable sketch (0.18 ms a solve) sees as a fifth of its time.
+// Same statements per value in the same order: same bits.
+__global__ __launch_bounds__(256) void spg_prologue_kernel(const double* __restrict__ vars0_base, const double* __restrict__ param_base,
+                                                           const uint64_t* __restrict__ off, uint32_t n, uint32_t nvt, double* __restrict__ vars0,
+                                                           SpRows rows, size_t stride, double* __restrict__ vars_base, SpAccum* __restrict__ accum,
+                                                           uint32_t* __restrict__ tickets, double* __restrict__ scal, double* __restrict__ xs_a,
+                                                           double* __restrict__ xs_b, double* __restrict__ snap, int do_scale,
+                                                           const uint32_t* __restrict__ fvar, uint32_t nfv, uint32_t rng_state, int perturb) {
+    const uint32_t sys = blockIdx.y, net = rows.net;
+    const size_t so = (size_t)sys * stride;
+    vars0 += so;
+    scal += so;
+    xs_a += so;
+    xs_b += so;
+    snap += so;
+    double* param = const_cast<double*>(rows.param) + so;
+    double* sparam = const_cast<double*>(rows.sparam) + so;
+    rows.param = param;
+    rows.sparam = sparam;
+    // spg_begin_kernel
+    const uint64_t v_at = off[sys], e_at = off[n + sys];
+    for (uint32_t i = threadIdx.x; i < nvt; i += 256u) {
+        const double v = vars0_base[v_at + i];
+        vars0[i] = v;
+        vars_base[v_at + i] = v;
+    }
+    for (uint32_t i = threadIdx.x; i < net; i += 256u) param[i] = param_base[e_at + i];
+    if (threadIdx.x == 0) {
+        accum[sys] = SpAccum{0, 0, FX_EXIT_SSE, 1, 0.0, 0.0};  // (spg_component_kernel: the one component counts)
+        tickets[sys] = 0;
+    }
+    __syncthreads();
+    // sp_scale_kernel
+    sp_scale_body(vars0, nvt, rows, scal, do_scale);
+    __syncthreads();
+    // sp_init_kernel
+    const double recip = scal[1];
+    for (uint32_t i = threadIdx.x; i < nvt; i += 256u) {
+        const double v = vars0[i];
+        const double x = do_scale ? v * recip : v;
+        xs_a[i] = x;
+        xs_b[i] = x;
+    }
+    for (uint32_t i = threadIdx.x; i < net; i += 256u) {
+        const int tag = rows.tag[i] & 0x7F;
+        double p = param[i];
+        if (do_scale && (tag == FX_TAG_PPD || tag == FX_TAG_PLD)) p = recip * p;
+        sparam[i] = p;
+    }
+    __syncthreads();
+    // sp_perturb_kernel
+    if (perturb) {
+        for (uint32_t k = threadIdx.x; k < nfv; k += 256u) {
+            uint32_t st = lcg_skip(rng_state, 2u * k);
+            st = st * 1664525u + 1013904223u;
+            const double f1 = (1.0 / 4294967295.0) * (double)st;
+            st = st * 1664525u + 1013904223u;
+            const double f2 = (1.0 / 4294967295.0) * (double)st;
+            const uint32_t vi = fvar[k];
+            double x = xs_a[vi];
+            x += x * (1.0 / 8196.0) * f1 + (1.0 / 65568.0) * f2;
+            xs_a[vi] = x;
+            xs_b[vi] = x;
+        }
+        __syncthreads();
+    }
+    // spg_component_kernel
+    for (uint32_t i = threadIdx.x; i < nvt; i += 256u) snap[i] = xs_a[i];
+}
 
 // ------------------------------------------------------------------------------------------------
 // host: structure
@@ -880,20 +955,30 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         V.stride = stride;
         double* d_vars0 = slab + o_vars0;
 
-        hipLaunchKernelGGL(spg_begin_kernel, grid_for2(std::max(nvt, net), n), dim3(256), 0, stream, d.vars0, d.expr_param, d_off, n, nvt, net,
-                           d_vars0, slab + o_param, stride, d.vars, d_accum, d_tickets);
-        hipLaunchKernelGGL(sp_scale_kernel, dim3(1, n), dim3(256), 0, stream, d_vars0, nvt, rows, V.scal, do_scale, stride);
-        hipLaunchKernelGGL(sp_init_kernel, grid_for2(std::max(nvt, net), n), dim3(256), 0, stream, d_vars0, nvt, rows, V.scal, V.xs0, V.xs1,
-                           do_scale, stride);
+        // a System of one component: everything before its first block in one launch (spg_prologue_kernel)
+        static const bool fuse_env = [] { const char* e = getenv("FIKSI_AMD_FUSED_PROLOGUE"); return !e || atoi(e) != 0; }();
+        const bool fused_prologue = fuse_env && cache->comps.size() == 1;
+        if (fused_prologue) {
+            const CompOnDevice& c0 = cache->comps[0];
+            hipLaunchKernelGGL(spg_prologue_kernel, dim3(1, n), dim3(256), 0, stream, d.vars0, d.expr_param, d_off, n, nvt, d_vars0, rows, stride,
+                               d.vars, d_accum, d_tickets, V.scal, V.xs0, V.xs1, V.snap, do_scale ? 1 : 0, c0.d_fvar, c0.nfv, 42u,
+                               ((prm.mode & 2u) && c0.nfv) ? 1 : 0);
+        } else {
+            hipLaunchKernelGGL(spg_begin_kernel, grid_for2(std::max(nvt, net), n), dim3(256), 0, stream, d.vars0, d.expr_param, d_off, n, nvt, net,
+                               d_vars0, slab + o_param, stride, d.vars, d_accum, d_tickets);
+            hipLaunchKernelGGL(sp_scale_kernel, dim3(1, n), dim3(256), 0, stream, d_vars0, nvt, rows, V.scal, do_scale, stride);
+            hipLaunchKernelGGL(sp_init_kernel, grid_for2(std::max(nvt, net), n), dim3(256), 0, stream, d_vars0, nvt, rows, V.scal, V.xs0, V.xs1,
+                               do_scale, stride);
+        }
         uint32_t rng = 42u;  // Rng::from_seed(42), shared by the components (:47)
         for (const CompOnDevice& comp : cache->comps) {
             // ---- the component's perturbation (:91-124), before any of its blocks
-            if ((prm.mode & 2u) && comp.nfv) {
+            if (!fused_prologue && (prm.mode & 2u) && comp.nfv) {
                 hipLaunchKernelGGL(sp_perturb_kernel, grid_for2(comp.nfv, n), dim3(256), 0, stream, comp.d_fvar, comp.nfv, rng, V.xs0, V.xs1, stride);
                 for (uint32_t k = 0; k < 2 * comp.nfv; ++k) rng = rng * 1664525u + 1013904223u;  // integer bookkeeping only
             }
             // the pre-solve snapshot (quirk Q2); the component counts, its exit code starts as "nothing to do"
-            hipLaunchKernelGGL(spg_component_kernel, grid_for2(nvt, n), dim3(256), 0, stream, V.xs0, V.snap, nvt, stride, d_accum);
+            if (!fused_prologue) hipLaunchKernelGGL(spg_component_kernel, grid_for2(nvt, n), dim3(256), 0, stream, V.xs0, V.snap, nvt, stride, d_accum);
             for (uint32_t u = 0; u < comp.n_blocks; ++u) {
                 const BlockOnDevice& blk = *cache->blocks[comp.first_block + u];
                 const uint32_t flags = (refined ? TEAM_REFINED : 0u) | (single_pass ? TEAM_SINGLE_PASS : 0u) | (do_scale ? TEAM_SCALE : 0u);
