@@ -406,6 +406,8 @@ def _build_name(db):
     b = db.grouped_build()
     if b == 2:
         return "lm_solve_grouped_s_kernel (one structure, sparse factor: level-scheduled Cholesky over tables in LDS, fx_grouped_s.hip)"
+    if b == 4:
+        return "lm_solve_tiny_kernel (one structure of at most 8 variables: eight lanes per System, eight Systems per wavefront, fx_grouped_tiny.hip)"
     if b == 1:
         return "lm_solve_grouped_c*_kernel (one structure: lists shared per wavefront, Jt J by its pattern, fx_grouped_c.hip)"
     if b == 0:

@@ -209,9 +209,10 @@ class Context:
         (fx_ctx_set_ladder); results unchanged."""
         check(lib.fx_ctx_set_ladder(self._h, 1 if enable else 0, tail_systems, min_trials, int(spread)), "fx_ctx_set_ladder")
 
-    def set_one_structure_builds(self, enable: bool = True):
-        """Batches of one structure take the grouped kernel's builds made for them (fx_ctx_set_one_structure_builds)."""
-        check(lib.fx_ctx_set_one_structure_builds(self._h, 1 if enable else 0), "fx_ctx_set_one_structure_builds")
+    def set_one_structure_builds(self, enable: bool = True, tiny: bool = True):
+        """Batches of one structure take the grouped kernel's builds made for them (fx_ctx_set_one_structure_builds); tiny = False
+        keeps structures of at most eight variables / expressions on the 16-column build instead of fx_grouped_tiny.hip (same bits)."""
+        check(lib.fx_ctx_set_one_structure_builds(self._h, (1 if tiny else 2) if enable else 0), "fx_ctx_set_one_structure_builds")
 
     def set_hold_passes(self, passes: int = 2):
         """Grouped kernel: passes a finished row waits for a second one (fx_ctx_set_hold_passes); results unchanged."""

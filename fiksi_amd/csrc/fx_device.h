@@ -164,6 +164,10 @@ struct DeviceBatch {
     // System's start values and parameters from the caller's arrays when the System's turn comes and writes its solved free variables
     // and its result record there when it is done — the transfers ride inside the solve instead of before and after it. The device
     // arrays are still filled (vars0 / vars / expr_param / results stay what they are for every other consumer). Null otherwise.
+    // The tiny build's hand-over (fx_grouped_tiny.hip): with `order` and `queue_len` both set, a System still running after the
+    // build's trial budget is appended to `order` (count in *queue_len) and the 16-column build, whose ladder is made for stragglers,
+    // solves those Systems from their start values — same arithmetic, same bits; its queue is then *queue_len long.
+    uint32_t* queue_len;
     const double* vars_in;     // [n_vars] device-visible address of the caller's vars
     const double* param_in;    // [n_exprs] ... of the caller's expr_param
     double* vars_out;          // [n_vars] ... of the caller's vars again (written: free variables of a finished System)
@@ -230,6 +234,9 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
 size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t element_size);
 // ... and its sparse build for batches of one structure of 33 ... 255 free variables with a small factor (fx_grouped_s.hip)
 bool grouped_s_applies(const DeviceBatch& b, const LmParams& p);
+// fx_grouped_tiny.hip: the one-structure build for Systems of at most eight variables and expressions (eight lanes per System)
+bool grouped_tiny_applies(const DeviceBatch& b, const LmParams& p);
+hipError_t launch_solve_tiny(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 hipError_t launch_solve_grouped_s(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // the GLOBAL block walker on the lists of `b` (g_list / unit arrays): SinglePass blocks or None-mode components
 hipError_t launch_solve_walk(const DeviceBatch& b, const LmParams& p, hipStream_t stream);

@@ -145,7 +145,7 @@ FX_CATCH_CODE
 
 int fx_ctx_set_one_structure_builds(fx_ctx* ctx, int enable) try {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
-    ctx->grouped_one_structure = enable ? 1 : 0;
+    ctx->grouped_one_structure = enable == 2 ? 2 : enable ? 1 : 0;  // (2: on, without the tiny build of fx_grouped_tiny.hip)
     return FX_OK;
 }
 FX_CATCH_CODE
@@ -566,6 +566,7 @@ int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* op
         dc.gc_nclasses = (uint32_t)db->classes.size();
         if (fx::grouped_c_applies(dc, p)) *build = 3;
     }
+    if (*build == 1 && fx::grouped_tiny_applies(db->d, p)) *build = 4;
     return FX_OK;
 }
 FX_CATCH_CODE

@@ -1532,7 +1532,10 @@ bool grouped_applies(const DeviceBatch& b, const LmParams& p) {
     // (tests, A/B measurements). By default a batch must be big enough to fill the chip four Systems per wavefront:
     // below that one wavefront per System finishes sooner.
     if (p.route_grouped == 0 || b.has_pose) return false;  // (cluster problems: the pose builds of the one-wavefront kernel)
-    if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) return false;
+    if (p.route_grouped < 0 && b.n_systems < p.grouped_min_systems) {
+        // (the tiny one-structure build runs eight Systems per wavefront without a queue: it pays from the first System on)
+        return b.uniform && p.lm.solver == FX_STEP_CHOLESKY && !(p.mode & MODE_LBFGS) && grouped_c_applies(b, p) && grouped_tiny_applies(b, p);
+    }
     if (p.lm.solver == FX_STEP_QR) return grouped_qr_applies(b, p, nullptr);
     if ((p.mode & MODE_LBFGS) || p.lm.solver != FX_STEP_CHOLESKY) return false;
     if (b.uniform && grouped_c_applies(b, p)) return true;  // (the one-structure build needs a fraction of the general build's LDS)

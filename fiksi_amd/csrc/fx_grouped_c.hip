@@ -267,6 +267,9 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         }
     };
 
+    // a launch over what the tiny build handed over (DeviceBatch::queue_len): mostly nothing, or a few dozen stragglers — a wavefront
+    // whose first four tickets would lie past the end of that queue leaves before it has copied the program
+    if (b.queue_len && !b.gc_nclasses && blockIdx.x * 4u >= rfl(*b.queue_len)) return;
     const uint32_t ncls = b.gc_nclasses ? b.gc_nclasses : 1u;
     uint32_t home = 0;
     if (b.gc_nclasses > 1u) {  // the class this wavefront's place in the grid falls into
@@ -286,6 +289,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
         qn = b.n_systems;
         qlist = b.order;
         qhead = next_system;
+        if (b.queue_len && !b.gc_nclasses) qn = rfl(*b.queue_len);  // (what the tiny build handed over)
         if (b.gc_nclasses) {
             const GcClass k = b.gc_classes[c];
             prog = b.gc_tab + k.prog_off;
@@ -870,6 +874,7 @@ bool grouped_c_applies(const DeviceBatch& b, const LmParams& p) {
 }
 
 hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+    if (grouped_tiny_applies(b, p)) return launch_solve_tiny(b, p, stream);  // (at most eight variables and expressions: eight Systems per wavefront)
     const bool f32 = p.lm.precision == 32;
     const GcBuild k = gc_build_for(b.gc_nc, b.gc_rc, f32);
     if (!k.fn) return hipErrorInvalidValue;

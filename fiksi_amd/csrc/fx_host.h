@@ -323,6 +323,7 @@ struct fx_dbatch {
     std::vector<uint8_t> h_units_on_device;  // SinglePass: large Systems the GLOBAL kernel instantiation walks
     std::vector<uint8_t> h_qr_wide;          // FX_STEP_QR: Systems beyond one wavefront the wide kernel's QR build solves (ensure_qr_plans)
     bool qr_wide_active = false;             // ... and they have just been solved that way: the sparse path leaves them alone
+    uint32_t* tiny_left = nullptr;           // [n_systems] the Systems the tiny build hands over to the 16-column build (launch_solve_scheduled)
     bool in_place = false;                   // d.vars_in / param_in are set: vars0 / expr_param are filled by the solve kernel itself (no scout pass may read them first)
     // sparse-path plans of the batch's large Systems, one per structure and decomposer mode (hash -> candidates)
     struct ResidentPlan {

@@ -77,7 +77,9 @@ int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         if (launch_class_solves(ctx, db, p, &rc)) return rc;
     }
     // (a batch solved in place on the caller's arrays has no start values on the device yet for the scout pass to rank by)
-    if (ctx->presort && !db->in_place && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
+    // (... and the tiny build has no queue to hand Systems out from: eight consecutive Systems per wavefront)
+    const bool tiny = d.uniform && fx::grouped_applies(d, p) && fx::grouped_c_applies(d, p) && fx::grouped_tiny_applies(d, p);
+    if (ctx->presort && !db->in_place && !tiny && !d.order && !p.prof && d.n_systems >= ctx->presort_min_systems && fx::grouped_applies(d, p)) {
         const uint32_t n = d.n_systems;
         if (!db->ps_keys) {
             db->ps_temp_bytes = fx::presort_temp_bytes(n);
@@ -89,6 +91,17 @@ int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
         FX_HIP(fx::launch_presort(d, db->ps_keys, db->ps_ids, db->ps_temp, db->ps_temp_bytes, ctx->stream));
         fx::DeviceBatch dd = d;
         dd.order = db->ps_ids + n;
+        FX_HIP(fx::launch_solve(dd, p, ctx->stream));
+        return FX_OK;
+    }
+    if (tiny && !d.order && d.n_systems >= 64u) {  // the tiny build with a place for the stragglers it hands over (fx_grouped_tiny.hip)
+        if (!db->tiny_left) {
+            int rc = dev_alloc_copy(ctx, db, &db->tiny_left, (const uint32_t*)nullptr, (size_t)d.n_systems);
+            if (rc) return rc;
+        }
+        fx::DeviceBatch dd = d;
+        dd.order = db->tiny_left;
+        dd.queue_len = d.work_counter + 15;  // (the last of the sixteen counters: the queue heads sit at the front)
         FX_HIP(fx::launch_solve(dd, p, ctx->stream));
         return FX_OK;
     }

@@ -704,6 +704,9 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     d.max_ents = p.max_ents;
     d.max_pairs_tri = p.max_pairs_tri;
     d.uniform = p.uniform && n_sys >= 2 ? 1u : 0u;
+    // (one System::solve on a sketch of at most eight variables and expressions — the reference's own bench at one triangle — is a
+    // batch of one structure too: it gets the program of fx_grouped_tiny.hip's build instead of the general kernel's list building)
+    if (whole && n_sys == 1u && p.n_large == 0 && p.sys_ncomp[0] == 1u && n_vars <= 8u && n_exprs <= 8u && n_exprs >= 1u && p.max_free >= 1u) d.uniform = 1u;
     d.u_nvars = d.uniform ? batch->var_off[1] : 0;
     d.u_nexprs = d.uniform ? batch->expr_off[1] : 0;
     d.u_ncomp = d.uniform ? p.sys_ncomp[0] : 0;

@@ -245,7 +245,9 @@ int fx_ctx_set_hold_passes(fx_ctx* ctx, uint32_t passes);
  * 1023 compact Jacobian entries — fx_grouped_s.hip
  * (the factorisation as a level schedule over tables in LDS: the normal-equation step in a minimum-degree order — the same
  * counters as the team / wide kernels such batches took before, variables to round-off). enable = 0 keeps such batches on the
- * general paths (default 1; a context created under FIKSI_AMD_GROUPED_C=0 starts with 0). fx_debug_grouped_build tells. */
+ * general paths (default 1; a context created under FIKSI_AMD_GROUPED_C=0 starts with 0); enable = 2: as 1, but structures of at
+ * most eight variables and eight expressions stay on fx_grouped_c.hip's 16-column build instead of fx_grouped_tiny.hip (same bits
+ * either way: A / B measurements). fx_debug_grouped_build tells. */
 int fx_ctx_set_one_structure_builds(fx_ctx* ctx, int enable);
 /* (These builds need a batch — or, under fx_system_solve_batch_multi, a SHARD — of at least 8 Systems (2 for fx_grouped_c.hip's
  * one-structure detection). fx_grouped_c.hip gives the general build's bits, so its routing never shows; fx_grouped_s.hip sums in a
@@ -359,7 +361,10 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
  * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS; the limits:
  * fx_ctx_set_one_structure_builds).
  * 3 = a batch of SEVERAL structures whose big structure classes (2 048 Systems and more, up to eight) run build 1 in one launch,
- * everyone else the general build. A context created under FIKSI_AMD_GROUPED_C=0 takes none of 1, 2, 3. Launches nothing. */
+ * everyone else the general build. 4 = build 1's arithmetic for structures of at most eight variables and eight expressions
+ * (fx_grouped_tiny.hip: eight lanes per System, eight Systems per wavefront; same bits as build 1;
+ * fx_ctx_set_one_structure_builds(ctx, 2) keeps such batches on build 1). A context created under FIKSI_AMD_GROUPED_C=0 takes
+ * none of 1, 2, 3, 4. Launches nothing. */
 int fx_debug_grouped_build(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts, int* build);
 
 /* ---- host-buffer entry points (upload -> run -> download; PCIe inclusive) ------------------- */

@@ -210,3 +210,46 @@ def compare_outcomes(b, v, res, v_o, res_o, oracle, tight: bool):
         assert np.array_equal(v[v0:v1], v_o[v0:v1]), s
     verdict = ((solved == solved_o) | (nan_gpu & nan_ref)).mean()
     return float((same | both_nan).mean()), float(verdict)
+
+
+def tile_with_noise(one, n: int, seed: int = 1, var_noise: float = 0.05, param_noise: float = 0.02):
+    """n Systems of the structure of the one-System batch `one`, start values and parameters jittered per System."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    nv, ne = int(one["var_off"][1]), int(one["expr_off"][1])
+    out = {
+        "var_off": (np.arange(n + 1, dtype=np.uint64) * nv).astype(np.uint32),
+        "expr_off": (np.arange(n + 1, dtype=np.uint64) * ne).astype(np.uint32),
+        "vars": np.tile(np.asarray(one["vars"], dtype=np.float64), n) + var_noise * rng.standard_normal(n * nv),
+        "var_fixed": np.tile(np.asarray(one["var_fixed"], dtype=np.uint8), n),
+        "expr_tag": np.tile(np.asarray(one["expr_tag"], dtype=np.uint8), n),
+        "expr_idx": np.tile(np.asarray(one["expr_idx"], dtype=np.uint32).reshape(-1), n),
+        "expr_param": np.tile(np.asarray(one["expr_param"], dtype=np.float64), n) * (1.0 + param_noise * rng.standard_normal(n * ne)),
+    }
+    for k, dt in (("var_comp", np.uint16), ("expr_comp", np.uint16)):
+        if one.get(k) is not None:
+            out[k] = np.tile(np.asarray(one[k], dtype=dt), n)
+    return out
+
+
+def tiny_sketch_batches(n: int):
+    """Batches of one structure of at most eight variables and eight expressions — what fx_grouped_tiny.hip takes: the reference's
+    quadrilateral (consistent / impossible targets: rejected trials, singular steps), one with a fixed point, and a sketch of four
+    points under five constraint kinds."""
+    from fiksi_amd import workloads
+    out = [("quadrilateral", tile_with_noise(workloads.quadrilateral(True), n, seed=11)),
+           ("quadrilateral_impossible", tile_with_noise(workloads.quadrilateral(False), n, seed=12))]
+    q = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in workloads.quadrilateral(True).items()}
+    q["var_fixed"][:2] = 1
+    q["var_fixed"][3] = 1
+    out.append(("quadrilateral_fixed_point", tile_with_noise(q, n, seed=13)))
+    s = System()
+    P = [elements.Point.create(s, x, y) for x, y in ((0.1, 0.0), (2.0, 0.2), (1.9, 1.8), (-0.2, 2.1))]
+    ln = elements.Line.create(s, P[0], P[1])
+    constraints.PointPointDistance.create(s, P[0], P[1], 2.0)
+    constraints.PointPointPointAngle.create(s, P[0], P[1], P[2], 1.5)
+    constraints.PointLineDistance.create(s, P[3], ln, 2.0)
+    constraints.PointPointDistance.create(s, P[2], P[3], 2.1)
+    constraints.SegmentSegmentLengthEquality.create(s, P[0], P[1], P[1], P[2])
+    out.append(("four_points_five_kinds", tile_with_noise(s.flatten(), n, seed=14, var_noise=0.03)))
+    return out

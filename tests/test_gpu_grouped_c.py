@@ -69,8 +69,9 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
         assert dg.grouped_build(abi.solving_opts(**kw)) == 0
         dg.free()
     for name in ("ring16", "ring16_fixed_gauge", "ring16_inconsistent", "ring16_trial_cap", "ring16_no_perturbation", "ring16_f32",
-                 "ring16_inconsistent_f32", "hinged_5_f32", "hinged_1", "hinged_3", "hinged_4", "hinged_5", "hinged_7", "ring20_chords", "ring23_chords"):
+                 "ring16_inconsistent_f32", "hinged_5_f32", "hinged_3", "hinged_4", "hinged_5", "hinged_7", "ring20_chords", "ring23_chords"):
         assert taken[name] == 1, taken
+    assert taken["hinged_1"] == 4, taken  # (six variables, three expressions: eight lanes per System, fx_grouped_tiny.hip)
     # not of one structure, and no class of 2 048 Systems: the general build; f32 has the 32-column instantiation only
     db = ctx.upload(workloads.ring16_two_structures(2000))
     assert db.grouped_build() == 0
@@ -176,7 +177,7 @@ def test_random_structures_against_the_general_build(fiksi, ctx, ctx_general, se
     build = db.grouped_build()
     db.free()
     nv, ne = int(b["var_off"][1]), int(b["expr_off"][1])
-    assert build in (1, 2) or ne > 48 or nv > 48, (build, nv, ne)  # (the tables of the register builds hold 48 expressions)
+    assert build in (1, 2, 4) or ne > 48 or nv > 48, (build, nv, ne)  # (the tables of the register builds hold 48 expressions; 4: the tiny build)
     v1, r1 = ctx.system_solve_batch(b)
     v0, r0 = ctx_general.system_solve_batch(b)
     if build != 2:
@@ -236,7 +237,11 @@ def test_each_instantiation_against_the_oracle_directly(fiksi, oracle, ctx, case
          "cr_16_points_45_rows": lambda: _random_graph_batch(400, 16, 30, 351, fix_first=False, angles=2),
          "c1r_8_points_23_rows": lambda: _random_graph_batch(400, 8, 16, 337, fix_first=False, angles=2)}[case]()
     o = abi.solving_opts()
-    v, res = _solve_on_build(ctx, b, o, 1)
+    ctx.set_one_structure_builds(True, tiny=False)  # (c1_hinged_1 would take fx_grouped_tiny.hip: its own test below)
+    try:
+        v, res = _solve_on_build(ctx, b, o, 1)
+    finally:
+        ctx.set_one_structure_builds(True)
     v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
     # (under-determined, partly infeasible sketches — every kind, the random over-constrained graphs — stall in flat valleys, where the
     # normal-equation step's cond^2 shows: the looser bars tests/test_gpu_fuzz.py holds such sketches to; FX_STEP_QR is the bit-exact mode)
@@ -255,6 +260,78 @@ def test_each_instantiation_against_the_oracle_directly(fiksi, oracle, ctx, case
         return
     same, verdict = compare_outcomes(b, v, res, v_o, res_o, oracle, tight=not loose)
     assert same >= (0.9 if loose else 0.97) and verdict >= 0.995, (case, same, verdict)
+
+
+def _tiny_cases(n):
+    from fiksi_amd import workloads
+
+    from helpers import tiny_sketch_batches
+    return [("hinged_1", workloads.hinged_triangles(n, 1))] + tiny_sketch_batches(n)
+
+
+@pytest.mark.parametrize("case", ["hinged_1", "quadrilateral", "quadrilateral_impossible", "quadrilateral_fixed_point", "four_points_five_kinds"])
+def test_the_tiny_build_against_the_oracle_directly_and_bit_for_bit_against_the_16_column_build(fiksi, oracle, ctx, case):
+    """fx_grouped_tiny.hip (eight lanes per System; asserted by name: fx_debug_grouped_build == 4) against the oracle with the bars of
+    the test above, and against lm_solve_grouped_c1_kernel on the same batch: every bit of the variables and of the result records —
+    with and without the perturbation, under a trial cap, and through the host-buffer call. 1 003 Systems: the last wavefront is ragged."""
+    from fiksi_amd import abi
+
+    from helpers import compare_outcomes
+
+    b = dict(_tiny_cases(1003))[case]
+    for o in (abi.solving_opts(), abi.solving_opts(perturb=False), abi.solving_opts(max_trials=7)):
+        v, res = _solve_on_build(ctx, b, o, 4)
+        ctx.set_one_structure_builds(True, tiny=False)
+        try:
+            v1, res1 = _solve_on_build(ctx, b, o, 1)
+        finally:
+            ctx.set_one_structure_builds(True)
+        assert np.array_equal(_bits(v), _bits(v1)) and res.tobytes() == res1.tobytes()
+    o = abi.solving_opts()
+    v, res = _solve_on_build(ctx, b, o, 4)
+    vh, resh = ctx.system_solve_batch(b, o)
+    assert np.array_equal(_bits(v), _bits(vh)) and res.tobytes() == resh.tobytes()
+    v_o, res_o = oracle.solve_batch(b, mode=3, nthreads=8)
+    loose = case in ("quadrilateral_impossible", "four_points_five_kinds")  # (flat valleys: the bars of tests/test_gpu_fuzz.py)
+    same, verdict = compare_outcomes(b, v, res, v_o, res_o, oracle, tight=not loose)
+    assert same >= (0.9 if loose else 0.97) and verdict >= 0.995, (case, same, verdict)
+
+
+def test_a_lone_tiny_system_and_a_handful_take_the_tiny_build_too(fiksi, oracle, ctx, ctx_general):
+    """System::solve on one sketch of at most eight variables (the reference's own bench at one triangle) and batches below the
+    grouped kernel's eight-System threshold take the tiny build too: a System's bits do not depend on how many others share its
+    batch. (Against the one-System-per-wavefront kernel such a batch took before: every bit on the distance-only sketches, the
+    oracle's bars on the sketch with angles and a repeated variable, whose Jt J that kernel sums in another order.)"""
+    from fiksi_amd import abi
+
+    from helpers import compare_outcomes
+
+    def take(b, lo, hi):  # Systems lo ... hi - 1 of a batch of one structure
+        nv, ne = int(b["var_off"][1]), int(b["expr_off"][1])
+        out = {"var_off": (np.arange(hi - lo + 1) * nv).astype(np.uint32), "expr_off": (np.arange(hi - lo + 1) * ne).astype(np.uint32),
+               "expr_idx": b["expr_idx"][4 * ne * lo:4 * ne * hi].copy()}
+        for k in ("vars", "var_fixed", "var_comp"):
+            out[k] = b[k][nv * lo:nv * hi].copy()
+        for k in ("expr_tag", "expr_param", "expr_comp"):
+            out[k] = b[k][ne * lo:ne * hi].copy()
+        return out
+
+    for name, b in _tiny_cases(8):
+        v_all, res_all = ctx.system_solve_batch(b)
+        nv = int(b["var_off"][1])
+        for lo, hi in ((3, 4), (0, 2), (1, 8)):
+            sub_b = take(b, lo, hi)
+            db = ctx.upload(sub_b)
+            assert db.grouped_build() == 4, (name, lo, hi, db.grouped_build())
+            db.free()
+            v, res = ctx.system_solve_batch(sub_b)
+            assert np.array_equal(_bits(v), _bits(v_all[nv * lo:nv * hi])) and res.tobytes() == res_all[lo:hi].tobytes(), (name, lo, hi)
+            vg, resg = ctx_general.system_solve_batch(sub_b)
+            if name != "four_points_five_kinds":
+                assert np.array_equal(_bits(v), _bits(vg)) and res.tobytes() == resg.tobytes(), (name, lo, hi)
+            else:
+                same, verdict = compare_outcomes(sub_b, v, res, vg, resg, oracle, tight=False)
+                assert verdict == 1.0, (name, lo, hi, same, verdict)
 
 
 @pytest.mark.parametrize("case", ["ring16", "ring16_inconsistent", "16_points_45_rows"])
