@@ -255,7 +255,7 @@ def main() -> int:
             "kernel": "eval_rows_kernel<true> (K1 Jacobian assembly: residuals + CSR J values; "
                       "fx_eval_residual_jacobian_device on a resident batch)",
             "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "traffic_source": "profiles/round4_pmc_traffic*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+            "traffic_source": "profiles/round5_pmc_traffic*.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                               "passes; read bytes = 2 x FETCH_SIZE KiB per the gfx950 correction, checked on a "
                               "known-byte kernel with K1's access widths: tools/probes/fetch_calib.hip)",
         }
@@ -605,14 +605,24 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
     out["ring16_two_structures"] = {"systems": n_sys, "ms_per_step": ms2, "converged_systems_per_sec": conv / (ms2 * 1e-3),
                                     "converged_fraction": conv / n_sys, "grouped_build": db.grouped_build()}
     db.free()
+    # ... and with every System's structure its own (random chords and angle sites): no one-structure program, no structure class —
+    # the general build of the grouped kernel, the rate a batch of unrelated sketches gets
+    b3 = workloads.ring16_all_different(n_sys)
+    db = ctx.upload(b3)
+    ms3 = _time_solves(ctx, db, abi.solving_opts())
+    res = db.get_results()
+    conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
+    out["ring16_all_different"] = {"systems": n_sys, "ms_per_step": ms3, "converged_systems_per_sec": conv / (ms3 * 1e-3),
+                                   "converged_fraction": conv / n_sys, "kernel": _build_name(db), "lm_trials": int(res["trials"].sum())}
+    db.free()
     return out
 
 
 def pmc_traffic(kernel_substr: str, n_sys: int, mixed: bool = False):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC summaries (collected in separate
     --pmc passes on the same workload; one file per batch size); None when no summary covers this size."""
-    names = ("round4_pmc_traffic_500k_mixed.json",) if mixed else (
-        "round4_pmc_traffic.json", "round4_pmc_traffic_500k.json", "round3_pmc_traffic.json", "round3_pmc_traffic_500k.json",
+    names = ("round5_pmc_traffic_500k_mixed.json", "round4_pmc_traffic_500k_mixed.json") if mixed else (
+        "round5_pmc_traffic.json", "round5_pmc_traffic_500k.json", "round4_pmc_traffic.json", "round4_pmc_traffic_500k.json", "round3_pmc_traffic.json", "round3_pmc_traffic_500k.json",
         "round2_pmc_traffic.json", "round2_pmc_traffic_500k.json", "round1_pmc_traffic.json")
     for name in names:
         try:
@@ -631,7 +641,7 @@ def pmc_traffic(kernel_substr: str, n_sys: int, mixed: bool = False):
 def sq_counters(kernel_substr: str, useful_flops: float):
     """VALU instructions the solve kernel issues per useful full-width FMA, from the committed SQ counter summary
     (rocprofv3 --pmc SQ_INSTS_VALU ..., its own pass on the same 100k batch): a wave64 f64 FMA is 64 lanes x 2 flop."""
-    for name in ("round4_pmc_sq.json", "round3_pmc_sq.json", "round2_pmc_sq.json"):
+    for name in ("round5_pmc_sq.json", "round4_pmc_sq.json", "round3_pmc_sq.json", "round2_pmc_sq.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

@@ -957,7 +957,8 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
 
         // a System of one component: everything before its first block in one launch (spg_prologue_kernel)
         static const bool fuse_env = [] { const char* e = getenv("FIKSI_AMD_FUSED_PROLOGUE"); return !e || atoi(e) != 0; }();
-        const bool fused_prologue = fuse_env && cache->comps.size() == 1;
+        // (one workgroup per System: up to a few thousand values; cfg2's 20 000 take the five launches' many workgroups — 0.21 ms fused, 0.13 apart)
+        const bool fused_prologue = fuse_env && cache->comps.size() == 1 && std::max(nvt, net) <= 4096u;
         if (fused_prologue) {
             const CompOnDevice& c0 = cache->comps[0];
             hipLaunchKernelGGL(spg_prologue_kernel, dim3(1, n), dim3(256), 0, stream, d.vars0, d.expr_param, d_off, n, nvt, d_vars0, rows, stride,

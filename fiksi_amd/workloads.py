@@ -219,6 +219,45 @@ def ring16_two_structures(n_systems: int, seed0: int = 1000) -> Dict[str, np.nda
     return b
 
 
+def ring16_all_different(n_systems: int, seed0: int = 1000) -> Dict[str, np.ndarray]:
+    """The headline's sketches with every System's STRUCTURE its own: the 16 ring distances stay, the eight chords join point 2k to a
+    point drawn per System (never itself or a ring neighbour), and the eight angles sit at points drawn per System. 32 constraints on
+    32 variables as in ``ring16``, consistent targets — but no two Systems share their index arrays, so no one-structure program, no
+    structure class: what the general build of the grouped kernel makes of a batch of unrelated sketches."""
+    b = ring16(n_systems, seed0)
+    n, P, m = int(n_systems), 16, 32
+    rng = LcgVec(seed0 + 77777 + np.arange(n, dtype=np.uint64))
+    truth_rng = LcgVec(seed0 + np.arange(n, dtype=np.uint64))  # the same draws as ring16: the ground truth the targets come from
+    R = 5.0 + 10.0 * truth_rng.next_f64()
+    cx = 20.0 * (truth_rng.next_f64() - 0.5)
+    cy = 20.0 * (truth_rng.next_f64() - 0.5)
+    truth = np.zeros((n, P, 2))
+    for i in range(P):
+        th = 2.0 * np.pi * (i + 0.3 * (truth_rng.next_f64() - 0.5)) / P
+        ri = R * (1.0 + 0.1 * (truth_rng.next_f64() - 0.5))
+        truth[:, i, 0] = cx + ri * np.cos(th)
+        truth[:, i, 1] = cy + ri * np.sin(th)
+    idx = b["expr_idx"].reshape(n, m, 4).copy()
+    par = b["expr_param"].reshape(n, m).copy()
+    rows = np.arange(n)
+    for k in range(8):  # chord k: point 2k to 2k + 2 + (0 ... 11): anything but itself and its two neighbours
+        i = 2 * k
+        j = (i + 2 + np.minimum((rng.next_f64() * 12.0).astype(np.int64), 11)) % P
+        d = truth[rows, i, :] - truth[rows, j, :]
+        idx[:, 16 + k, 0], idx[:, 16 + k, 1] = 2 * i, (2 * j).astype(np.uint32)
+        par[:, 16 + k] = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+    for k in range(8):  # angle k: at a drawn point between its ring neighbours
+        bb = np.minimum((rng.next_f64() * 16.0).astype(np.int64), 15)
+        a, c = (bb + P - 1) % P, (bb + 1) % P
+        idx[:, 24 + k, 0], idx[:, 24 + k, 1], idx[:, 24 + k, 2] = (2 * a).astype(np.uint32), (2 * bb).astype(np.uint32), (2 * c).astype(np.uint32)
+        u = truth[rows, a, :] - truth[rows, bb, :]
+        v = truth[rows, c, :] - truth[rows, bb, :]
+        par[:, 24 + k] = _wrap(np.arctan2(v[:, 1], v[:, 0]) - np.arctan2(u[:, 1], u[:, 0]))
+    b["expr_idx"] = idx.reshape(-1)
+    b["expr_param"] = par.reshape(-1)
+    return b
+
+
 def hinged_triangles(n_systems: int, n_triangles: int = 11) -> Dict[str, np.ndarray]:
     """fiksi/benches/fiksi_bench.rs:15-40: hinge (0,0); triangle t adds p1=(-1,t), p2=(1,t) and
     distances hinge-p1 = 2, hinge-p2 = 2, p1-p2 = 3. Every system of the batch is identical (the

@@ -1,4 +1,5 @@
-"""The hand-written DPP instructions of fx_grouped.hip / fx_grouped_c.hip (fx_grouped_rows.h) are inline asm, which the compiler's hazard recogniser
+"""The hand-written DPP instructions of fx_grouped.hip / fx_grouped_c.hip (fx_grouped_rows.h), of fx_grouped_tiny.hip (half-row
+broadcasts) and of the multifrontal build in fx_sparse.hip (fx_front.h) are inline asm, which the compiler's hazard recogniser
 does not look into: a DPP read needs two wait states after a VALU write of its source register. The ISA the
 Makefile's flags produce is scanned for that pattern (tools/check_dpp_hazards.py) — CPU only, hipcc
 cross-compiles."""
@@ -13,15 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
-@pytest.mark.parametrize("name", ["fx_grouped", "fx_grouped_c"])  # (the one-structure build shares the row-wide Cholesky: fx_grouped_rows.h)
-def test_no_valu_write_to_dpp_read_hazard_in_the_grouped_kernels(tmp_path, name):
+@pytest.mark.parametrize("name, counts", [("fx_grouped", {"v_fmac_f64_dpp": 1000, "v_fmac_f32_dpp": 800}),
+                                          ("fx_grouped_c", {"v_fmac_f64_dpp": 1000, "v_fmac_f32_dpp": 800}),  # (shares fx_grouped_rows.h)
+                                          ("fx_grouped_tiny", {"v_mov_b64_dpp": 100}), ("fx_sparse", {"v_fmac_f64_dpp": 200})])
+def test_no_valu_write_to_dpp_read_hazard_in_the_grouped_kernels(tmp_path, name, counts):
     src = os.path.join(ROOT, "fiksi_amd", "csrc", name + ".hip")
     out = tmp_path / (name + ".s")
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only", "-S",
            "-I", os.path.join(ROOT, "include"), src, "-o", str(out)]
-    subprocess.run(cmd, check=True, cwd=str(tmp_path), timeout=600)
+    subprocess.run(cmd, check=True, cwd=str(tmp_path), timeout=900)
     text = out.read_text()
-    assert text.count("v_fmac_f64_dpp") > 1000 and text.count("v_fmac_f32_dpp") > 800  # the scan sees the instructions
+    for op, at_least in counts.items():  # the scan sees the instructions
+        assert text.count(op) > at_least, (op, text.count(op))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
 

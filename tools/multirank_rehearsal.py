@@ -3,8 +3,10 @@ A code-path rehearsal of the N > 1 bench (rank seeds / shards, process-group ini
 counters), NOT a scaling number: the ranks share one GPU. Backend nccl (= RCCL) first; RCCL refuses communicators with two
 ranks on one device on most builds — the refusal is recorded and the run repeated with gloo reductions
 (FIKSI_BENCH_BACKEND=gloo), which exercises everything but the RCCL all-reduce itself; N = 1 with FIKSI_BENCH_FORCE_DIST=1
-runs init / barrier / all-reduce on device tensors over RCCL for real.
-    python3 tools/multirank_rehearsal.py > profiles/round4_multirank_rehearsal.json"""
+runs init / barrier / all-reduce on device tensors over RCCL for real. The last runs repeat two of them the way a launcher that
+masks devices per rank would start them: HIP_VISIBLE_DEVICES=0 for every rank and NO FIKSI_BENCH_DEVICE, so that LOCAL_RANK 1 ... 3
+meet one visible device and bench.py's masked-device branch (local_rank % devices visible) picks it.
+    python3 tools/multirank_rehearsal.py > profiles/round5_multirank_rehearsal.json"""
 import json
 import os
 import subprocess
@@ -13,8 +15,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(n, scaling, backend, port):
-    env = dict(os.environ, FIKSI_BENCH_FORCE_DIST="1", FIKSI_BENCH_DEVICE="0", FIKSI_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def run(n, scaling, backend, port, masked=False):
+    env = dict(os.environ, FIKSI_BENCH_FORCE_DIST="1", FIKSI_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if masked:
+        env["HIP_VISIBLE_DEVICES"] = "0"
+        env.pop("FIKSI_BENCH_DEVICE", None)
+    else:
+        env["FIKSI_BENCH_DEVICE"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "10", "--warmup", "2", "--quick",
            "--no-cpu-baseline", "--scaling", scaling]
@@ -30,7 +37,9 @@ def run(n, scaling, backend, port):
     d = json.loads(lines[0])
     return {"n_gpus": d["n_gpus"], "scaling": d["scaling"], "backend": backend, "value": d["value"], "unit": d["unit"],
             "ms_per_step": d["ms_per_step"], "steps": d["steps"], "converged_fraction": d["converged_fraction"],
-            "global_systems": d["config"]["global_systems"], "systems_per_rank": d["config"]["systems_per_gpu"]}, None
+            "global_systems": d["config"]["global_systems"], "systems_per_rank": d["config"]["systems_per_gpu"],
+            "per_rank_ms": d.get("per_rank_ms"), "slowest_rank": d.get("slowest_rank"), "per_rank_systems": d.get("per_rank_systems"),
+            "devices_masked_per_rank": bool(masked)}, None
 
 
 def main():
@@ -44,6 +53,13 @@ def main():
                 out["runs"].append(r)
                 break
             out["refusals"].append({"n_gpus": n, "scaling": scaling, "backend": backend, "error_tail": err})
+    for n, scaling in ((2, "weak"), (4, "strong")):  # HIP_VISIBLE_DEVICES=0 per rank: the masked-device branch
+        port += 1
+        r, err = run(n, scaling, "gloo", port, masked=True)
+        if r is not None:
+            out["runs"].append(r)
+        else:
+            out["refusals"].append({"n_gpus": n, "scaling": scaling, "backend": "gloo", "devices_masked_per_rank": True, "error_tail": err})
     print(json.dumps(out, indent=1))
 
 
