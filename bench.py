@@ -677,7 +677,7 @@ def large_systems(ctx, abi, workloads, np):
     res = db.get_results()
     conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
     out["hinged_triangles_64_x_256"] = {"ms_per_step": ms, "converged_systems_per_sec": conv / (ms * 1e-3), "converged_fraction": conv / 256,
-                                        "kernel": "sp_lm_team_kernel: one workgroup per System, the whole LM loop in one launch"}
+                                        "kernel": "mf_lm_solo_kernel (fx_front.h): one workgroup per System, the whole LM loop in one launch, the factor by fronts of up to 15 columns in DPP rows"}
     db.free()
     return out
 

@@ -1,4 +1,4 @@
-// Host <-> device plumbing shared by fx_abi.cpp and fx_kernels.hip (not part of the public ABI).
+// Host <-> device plumbing shared by the host sources (fx_analyze / fx_programs / fx_upload / fx_solve / fx_entry .cpp) and the kernels (not part of the public ABI).
 #pragma once
 #ifdef FX_HOST_ONLY
 #include "fx_hip_shim.h"
@@ -59,14 +59,14 @@ struct QrPlans {
     uint32_t* qrw_prog_off = nullptr;
     uint32_t* qrw_words = nullptr;
     uint32_t n_qrw = 0, qrw_nx = 0, qrw_free = 0, qrw_vars = 0, qrw_rows = 0;
-    // the grouped build's program (fx_abi.cpp: build_qrg_program), for a batch of one structure; null otherwise
+    // the grouped build's program (fx_programs.cpp: build_qrg_program), for a batch of one structure; null otherwise
     uint32_t* qrg = nullptr;
     uint32_t qrg_words = 0, qrg_small = 0, qrg_nx = 0, qrg_n = 0, qrg_m = 0, qrg_ng = 0;
 };
 constexpr uint32_t MODE_UNITS = 4;  // LmParams::mode bit: solve block by block
 constexpr uint32_t MODE_LBFGS = 8;  // LmParams::mode bit: Optimizer::LBfgs instead of Levenberg-Marquardt
 
-// The program of the grouped kernel's one-structure build (fx_grouped_c.hip; written by fx_abi.cpp: build_gc_program): byte
+// The program of the grouped kernel's one-structure build (fx_grouped_c.hip; written by fx_programs.cpp: build_gc_program): byte
 // offsets of its tables of fixed size; the right-hand-side list and, behind it, the product list follow at PE
 template <int NC, int RC> struct GcTable {  // NC columns per lane, RC chunks of 16 rows: Systems of at most NV = 16 NC variables and NR = 16 RC expressions
     static constexpr uint32_t NV = 16u * NC, NR = 16u * RC;
@@ -143,7 +143,7 @@ struct DeviceBatch {
     int16_t* g_colof;         // [total] variable -> free column of the block in flight
     // FX_STEP_QR plans, built on first use (null until then)
     QrPlans qr_none, qr_units;
-    // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_abi.cpp: build_gc_program): null unless the
+    // the program of the grouped kernel's one-structure build (fx_grouped_c.hip; fx_programs.cpp: build_gc_program): null unless the
     // batch is uniform with one component of at most 48 free variables
     uint32_t* gc_tab;
     uint32_t gc_words, gc_nslots, gc_ng;  // words of the program (the f64 builds' part); slots of Jt J's pattern (+ the zero slot), compact Jacobian entries

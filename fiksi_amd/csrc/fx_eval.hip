@@ -202,7 +202,7 @@ hipError_t launch_eval(const DeviceBatch& b, const double* x, bool want_jacobian
             r = t;
         }
         period = b.u_nexprs / g;
-        while (period % 4u) period *= 2u;  // lcm with the rotation of the sorted order (fx_abi.cpp: build_eval_plan)
+        while (period % 4u) period *= 2u;  // lcm with the rotation of the sorted order (fx_analyze.cpp: build_eval_plan)
     }
     if (want_jacobian && plain_stores) {
         hipLaunchKernelGGL((eval_rows_kernel<true, false>), grid, block, 0, stream, b, x, period);

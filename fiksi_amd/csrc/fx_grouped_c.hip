@@ -5,7 +5,7 @@
 // build takes 392 and 40 KB and runs one wavefront per SIMD, with the VALU busy half of the time).
 //
 // What makes it fit is that nothing about the structure is per System any more. The host writes one PROGRAM for the batch
-// (fx_abi.cpp: build_gc_program; every System has one component, at most 32 variables and 32 expressions — two matrix columns per
+// (fx_programs.cpp: build_gc_program; every System has one component, at most 32 variables and 32 expressions — two matrix columns per
 // lane; 16 / 16: one column, four wavefronts per SIMD; 48 / 48, the reference's own bench sketch: three columns, a wavefront on
 // every SIMD; an over-constrained structure — up to twice the shape's rows — the same bodies with twice the row chunks), the
 // wavefront copies it into LDS once, and the four Systems share it:
@@ -67,7 +67,7 @@ __device__ __forceinline__ void grouped_c_body(const DeviceBatch& b, const LmPar
     const int gbase = lane & ~(RS - 1);
     const int myrow = lane / RS;
     // The program and the queue at hand. A batch of one structure has one of each; a batch of several structures brings a
-    // program, a member list and a queue head per structure CLASS (b.gc_classes; fx_abi.cpp: launch_class_solves): a wavefront
+    // program, a member list and a queue head per structure CLASS (b.gc_classes; fx_solve.cpp: launch_class_solves): a wavefront
     // starts on the class its place in the grid falls into — the grid is dealt in proportion to the classes' sizes — and, when
     // that queue is empty and its Systems are done, loads the next class's program and goes on there: one launch, every
     // wavefront busy until every queue is empty.

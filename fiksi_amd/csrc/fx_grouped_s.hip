@@ -5,7 +5,7 @@
 // of the sparse path (one workgroup per System, a wavefront walking a column at a time through barriers) take 54 us per trial of it.
 //
 // Same algorithm as the other LM kernels (reference: fiksi/src/assemble/mod.rs:46-167, fiksi/src/solve/lm.rs:21-193; the step is
-// the normal-equation step of fx_grouped.hip), everything a walk over the tables of the batch's one PROGRAM (fx_abi.cpp:
+// the normal-equation step of fx_grouped.hip), everything a walk over the tables of the batch's one PROGRAM (fx_programs.cpp:
 // build_gs_program), copied into LDS once per wavefront and shared by its four Systems:
 //   * a System lives in LDS entirely — working point, current point, step, the factor's slots, compact Jacobian rows, residuals,
 //     parameters (5.5 KB for the 66-variable sketch) — and a lane holds a handful of scalars;

@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t tri(uint32_t i, uint32_t j) { return i * (i 
 
 // QR = true is FX_STEP_QR for these components: the reference's Householder QR of [J; sqrt(lambda) I]
 // (solvi/src/decomposition/sparse/qr.rs:226-356) with the operations and the order of the one-wavefront QR kernel
-// (fx_kernels.hip: qr_step), driven by the host's table program (fx_abi.cpp: build_qrg_program, wide form) — the matrix by
+// (fx_kernels.hip: qr_step), driven by the host's table program (fx_programs.cpp: build_qrg_program, wide form) — the matrix by
 // its symbolic patterns in LDS, a lane per ACTIVE column of the Householder step at hand, the tables in global memory; the
 // reference's sequential sums, the correctly rounded atan2. Every bit is the reference algorithm's (tests/test_gpu_qr_step.py).
 template <bool QR>

@@ -187,7 +187,7 @@ def test_two_runs_are_bit_identical_on_mixed_and_random_batches(fiksi, ctx, solv
 @pytest.mark.parametrize("shape", ["ring16", "ring16_gauge", "ring16_inconsistent", "hinged5", "hinged7", "mixed11"])
 def test_four_systems_per_wavefront_is_the_same_bits(fiksi, oracle, ctx, shape):
     """Batches of ONE structure run FX_STEP_QR four Systems to a wavefront (fx_grouped.hip: lm_solve_grouped_qr_kernel, the
-    program of fx_abi.cpp: build_qrg_program — lanes over the active columns of each Householder step, the matrix stored by its
+    program of fx_programs.cpp: build_qrg_program — lanes over the active columns of each Householder step, the matrix stored by its
     symbolic patterns): the same operations in the same order as the one-wavefront QR kernel, so every variable and every
     result field is that kernel's bits (routing 0 / 1), with the lambda ladder on and off, and the oracle's on a sample (the
     correctly rounded atan2 on both sides)."""
