@@ -14,7 +14,10 @@ ctx = fiksi_amd.Context(0)
 g = Lcg(777)
 bad_vals = [np.nan, np.inf, -np.inf, 1e308, -1e308, 0.0, 5e-324, 1e-300]
 base = [workloads.ring16(40), workloads.hinged_triangles(20, 11), workloads.hinged_triangles(6, 16), workloads.hinged_triangles(3, 40),
-        workloads.concat([random_sketch(s).flatten() for s in range(40)]), workloads.concat([mixed_sketch(s, fix_some=bool(s & 1)).flatten() for s in range(20)])]
+        workloads.concat([random_sketch(s).flatten() for s in range(40)]), workloads.concat([mixed_sketch(s, fix_some=bool(s & 1)).flatten() for s in range(20)]),
+        # round 5: the tiny build (eight lanes per System, with its hand-over of stragglers) and the multifrontal build
+        workloads.hinged_triangles(70, 1), workloads.concat([workloads.quadrilateral(bool(s & 1)) for s in range(2)] * 0 + [workloads.quadrilateral(True)] * 67),
+        workloads.large_sketch(300, seed=3), workloads.hinged_triangles(2, 64)]
 modes = [dict(), dict(decomposer=1), dict(solver=1), dict(solver=2), dict(f32=True), dict(optimizer=1), dict(perturb=False)]
 exits = {}
 for it in range(n_iter):
