@@ -224,7 +224,7 @@ class Context:
 
     def set_sparse_fronts(self, enable: bool = True, ranks: int = 0):
         """Systems beyond one wavefront: the multifrontal build where the structure allows it (default), or the column walkers;
-        ranks: lambda trials per launch of a large System alone (0: by the room on the chip, at most 4)."""
+        ranks: lambda trials per launch of a large System alone (0: by the room on the chip, at most 8)."""
         check(lib.fx_ctx_set_sparse_fronts(self._h, 1 if enable else 0, ranks), "fx_ctx_set_sparse_fronts")
 
     def set_batch_hints(self, one_structure: bool = False):

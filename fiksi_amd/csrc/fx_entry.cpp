@@ -177,7 +177,7 @@ FX_CATCH_CODE
 
 int fx_ctx_set_sparse_fronts(fx_ctx* ctx, int enable, uint32_t ranks) try {
     if (!ctx) return fail(FX_ERR_INVALID, "ctx is NULL");
-    if (ranks > 4u) return fail(FX_ERR_INVALID, "ranks must be 0 (by the room on the chip) ... 4");
+    if (ranks > 8u) return fail(FX_ERR_INVALID, "ranks must be 0 (by the room on the chip) ... 8");
     ctx->sparse_fronts = enable ? 1u : 0u;
     ctx->sparse_front_ranks = ranks;
     return FX_OK;

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpB
 // reject: the one the sequential loop would have met first (fx_grouped_rows.h: LadderCode; the grouped kernels' ladder across
 // the rows of a wavefront, here across workgroups). Every counter, every lambda and every accepted point is the
 // sequential loop's; cfg2's 89 trials (16 accepted) take 30-odd launches' worth of time.
-constexpr uint32_t MF_MAX_RANKS = 4;
+constexpr uint32_t MF_MAX_RANKS = 8;
 struct MfRank {  // what rank k's trial found
     double dn2, sse_t;
     uint32_t flag, pad;
@@ -600,10 +600,8 @@ __device__ __forceinline__ void mf_top_body(const SpRows& rows, const SpBlock& B
         const uint32_t v = B.fvar[B.perm[sg.c0 + c]];
         trial.xs[v] = xc[v] + dx;
     }
-    __syncthreads();
-    const double* sparam = rows.sparam + (size_t)blockIdx.y * V.stride;
-    for (uint32_t q = X.erow_ptr[top] + tid; q < X.erow_ptr[top + 1]; q += MF_THREADS)
-        team_eval_row<POSE>(rows, sparam, B.jac, X.erows[q], trial.xs, trial.r, trial.j);
+    // (the top's own rows are evaluated by the parts' workgroups of the next launch, mf_parts_down_kernel: one workgroup going
+    // through them here was 14 of an up launch's 50 us on cfg2)
 }
 
 // grid: (parts, Systems, ranks)
@@ -797,6 +795,10 @@ __global__ __launch_bounds__(MF_THREADS) void mf_parts_down_kernel(SpRows rows, 
         __syncthreads();
         const double* sparam = rows.sparam + (size_t)blockIdx.y * V.stride;
         for (uint32_t q = X.erow_ptr[part] + tid; q < X.erow_ptr[part + 1]; q += MF_THREADS)
+            team_eval_row<POSE>(rows, sparam, B.jac, X.erows[q], trial.xs, trial.r, trial.j);
+        // ... and a share of the top's rows (they read the top's columns only, whose trial point the launch before has written)
+        const uint32_t top = X.nparts;
+        for (uint32_t q = X.erow_ptr[top] + part * MF_THREADS + tid; q < X.erow_ptr[top + 1]; q += gridDim.x * MF_THREADS)
             team_eval_row<POSE>(rows, sparam, B.jac, X.erows[q], trial.xs, trial.r, trial.j);
     }
     if (!mf_last_ticket(tk + MF_MAX_RANKS + rank, gridDim.x, &s_last)) return;

@@ -899,7 +899,9 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     if (fronts && !lbfgs && !refined && cache->blocks.size() == 1 && cache->blocks[0]->mf_up_lds && n_sys < TEAM_PARTS_MAX_GROUP) {
         static const int forced = [] { const char* s = std::getenv("FIKSI_AMD_FRONT_RANKS"); return s ? atoi(s) : 0; }();
         const uint32_t np = cache->blocks[0]->mfp.nparts;
-        mf_ranks = std::max(1u, std::min<uint32_t>(MF_MAX_RANKS, 256u / std::max(1u, np * n_sys)));  // (a workgroup per CU: the ranks side by side)
+        // (a workgroup per CU and half as many again: the parts differ in size, so the second round fills the gaps of the first —
+        // cfg2, 64 parts: 4 ranks 3.52 ms, 6 ranks 2.89, 8 ranks 3.29; large_sketch(1500): 4 ranks 1.89 ms, 8 ranks 1.37)
+        mf_ranks = std::max(1u, std::min<uint32_t>(MF_MAX_RANKS, 384u / std::max(1u, np * n_sys)));
         if (forced >= 1 && forced <= (int)MF_MAX_RANKS) mf_ranks = (uint32_t)forced;
         if (prm.sparse_front_ranks >= 1u && prm.sparse_front_ranks <= MF_MAX_RANKS) mf_ranks = prm.sparse_front_ranks;
     }

@@ -283,8 +283,8 @@ int fx_ctx_set_wide_routing(fx_ctx* ctx, int wide);
  * ranks: a large System alone (its tree cut into parts + top, two launches per trial) leaves most of the chip idle, and the
  * trials that follow a rejected trial of lm.rs:114-190 differ in lambda only — a launch makes `ranks` of them side by side
  * (lambda x reject_factor^k) and the decision reads their verdicts in order: every counter, lambda and accepted point is the
- * sequential loop's, in fewer launches (BASELINE's large sketch: 89 trials in the time of ~30). 0 = as many as the chip has
- * room for (at most 4), 1 = one trial per launch. */
+ * sequential loop's, in fewer launches (BASELINE's large sketch: 89 trials in 31 rounds). 0 = as many as the chip has
+ * room for (at most 8: one and a half workgroups per CU over the parts x ranks), 1 = one trial per launch. */
 int fx_ctx_set_sparse_fronts(fx_ctx* ctx, int enable, uint32_t ranks);
 /* Systems beyond the one-wavefront kernels are grouped by structure, and every launch carries a whole group (fx_sparse_team.h).
  * A batch with SEVERAL structures solves its groups side by side on this many host threads, a stream each (default 8; 0 restores

@@ -96,7 +96,7 @@ def test_what_the_fronts_do_not_cover_keeps_the_walkers(fiksi, oracle, ctx):
 
 
 def test_the_launch_level_lambda_ladder_is_the_sequential_loop(fiksi, ctx):
-    """A large System alone: 1, 2, 3 or 4 lambda trials per launch (fx_ctx_set_sparse_fronts' ranks) — every variable, counter,
+    """A large System alone: 1 ... 8 lambda trials per launch (fx_ctx_set_sparse_fronts' ranks) — every variable, counter,
     exit code and SSE the bits of one trial per launch, also under a trial cap that falls inside a round of ranks."""
     from fiksi_amd import abi, workloads
 
@@ -107,7 +107,7 @@ def test_the_launch_level_lambda_ladder_is_the_sequential_loop(fiksi, ctx):
             ctx.set_sparse_fronts(True, 1)
             v1, r1 = ctx.system_solve_batch(b, o)
             assert int(r1["trials"][0]) > int(r1["accepted"][0]) + 3  # (there ARE rejected trials to run side by side)
-            for ranks in (2, 3, 4, 0):
+            for ranks in (2, 3, 4, 6, 8, 0):
                 ctx.set_sparse_fronts(True, ranks)
                 v, r = ctx.system_solve_batch(b, o)
                 assert np.array_equal(v.view(np.uint64), v1.view(np.uint64)), (kw, ranks)
