@@ -107,3 +107,37 @@ def test_register_refuses_nonsense_and_unregister_of_unknown_memory_is_an_error_
     assert lib.fx_host_unregister(ctx.handle, a.ctypes.data) != 0  # never registered: the runtime's refusal as a code, no crash
     assert lib.fx_host_register(ctx.handle, a.ctypes.data, a.nbytes) == 0
     assert lib.fx_host_unregister(ctx.handle, a.ctypes.data) == 0
+
+
+def test_in_place_with_the_tiny_build_and_across_shards():
+    """The in-place transfers through the other kernel that honours them (fx_grouped_tiny.hip, with its hand-over of stragglers to the
+    16-column build), and through fx_system_solve_batch_multi: every shard's slice of the registered arrays is solved in place."""
+    from helpers import tiny_sketch_batches
+
+    ctx = fiksi_amd.Context(0)
+    for b in (workloads.hinged_triangles(20000, 1), dict(tiny_sketch_batches(17000))["quadrilateral_impossible"]):
+        db = ctx.upload(b)
+        assert db.grouped_build() == 4
+        db.free()
+        _same(_solve(ctx, b, hint=False), _solve(ctx, b, hint=True, register=True))
+    b = workloads.ring16(70000)
+    plain = _solve(ctx, b, hint=False)
+    a = abi.normalize_batch({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in b.items()})
+    res = np.zeros(len(a["var_off"]) - 1, dtype=abi.RESULT_DTYPE)
+    ctxs = [ctx, fiksi_amd.Context(0)]
+    for c in ctxs:
+        c.set_batch_hints(one_structure=True)
+    ctx.host_register(a["vars"], a["expr_param"], res)
+    try:
+        import ctypes as C
+        from fiksi_amd._lib import check, lib
+        handles = (C.c_void_p * 2)(*[c.handle for c in ctxs])
+        total = (C.c_uint64 * 4)()
+        o = abi.solving_opts()
+        check(lib.fx_system_solve_batch_multi(handles, 2, C.byref(abi.as_struct(a)), C.byref(o), res.ctypes.data, total), "fx_system_solve_batch_multi")
+    finally:
+        ctx.host_unregister(a["vars"], a["expr_param"], res)
+        for c in ctxs:
+            c.set_batch_hints(one_structure=False)
+    _same(plain, (a["vars"], res))
+    assert int(total[0]) == 70000
