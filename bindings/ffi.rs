@@ -25,6 +25,7 @@ pub const FX_NO_COMPONENT: u16 = 0xFFFF;
 pub const FX_STEP_CHOLESKY: u32 = 0;          // fx_lm_opts.solver
 pub const FX_STEP_CHOLESKY_REFINED: u32 = 1;
 pub const FX_STEP_QR: u32 = 2;                // the reference's own numerics (bit-identical iterates)
+pub const FX_HINT_ONE_STRUCTURE: u32 = 1;     // fx_ctx_set_batch_hints: every System of a batch has System 0's structure (verified, never trusted)
 
 /// One batch of independent Systems, struct-of-arrays == the numeric state of `fiksi::System` (lib.rs:256-303).
 #[repr(C)] #[derive(Clone, Copy)]
