@@ -159,3 +159,39 @@ def test_cfg5_share_f32_overconstrained(fiksi, oracle, ctx):
     vs, rs = ctx.system_solve_batch(workloads.shard(b, 3, 8), opts)
     lo, hi = n * 3 // 8, n * 4 // 8
     assert np.array_equal(rs, res[lo:hi]) and np.array_equal(vs, v[32 * lo:32 * hi])
+
+
+def test_the_references_one_triangle_bench_sketch_at_full_size_on_the_tiny_build(fiksi, oracle, ctx):
+    """fiksi_bench.rs:46-73 at its smallest size, as a batch of 100 000 with jittered start values: the tiny build
+    (fx_grouped_tiny.hip, asserted by name) — every System converged by the bench's own predicate, every bit equal to the 16-column
+    build at this size (the hand-over of stragglers included), the oracle on a sample of 4 000 with the tight bars, and the same
+    bits again through the host-buffer call on page-locked arrays with the one-structure hint."""
+    from fiksi_amd import abi, workloads
+
+    from helpers import compare_outcomes, tile_with_noise
+    from test_gpu_host_path import _same, _solve
+
+    one = workloads.hinged_triangles(1, 1)
+    b = tile_with_noise(one, N, seed=5, var_noise=0.05, param_noise=0.0)
+    db = ctx.upload(b)
+    assert db.grouped_build() == 4
+    db.system_solve()
+    v, res = db.get_vars().copy(), db.get_results().copy()
+    db.free()
+    assert (res["sse_unscaled"] < 1e-4).mean() > 0.999
+    ctx.set_one_structure_builds(True, tiny=False)
+    try:
+        db = ctx.upload(b)
+        assert db.grouped_build() == 1
+        db.system_solve()
+        v1, res1 = db.get_vars().copy(), db.get_results().copy()
+        db.free()
+    finally:
+        ctx.set_one_structure_builds(True)
+    assert np.array_equal(v.view(np.uint64), v1.view(np.uint64)) and res.tobytes() == res1.tobytes()
+    pick = np.sort(np.random.default_rng(3).choice(N, size=4000, replace=False))
+    sample = workloads.concat([workloads.shard(b, int(s), N) for s in pick])
+    v_o, res_o = oracle.solve_batch(sample, mode=3, nthreads=8)
+    same, verdict = compare_outcomes(sample, v.reshape(N, 6)[pick].ravel(), res[pick], v_o, res_o, oracle, tight=True)
+    assert same >= 0.99 and verdict == 1.0, (same, verdict)
+    _same((v, res), _solve(ctx, b, hint=True, register=True))
