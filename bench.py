@@ -604,6 +604,8 @@ def other_workloads(ctx, abi, workloads, np, n_sys: int):
     conv = int(np.count_nonzero(res["sse_unscaled"] < 1e-4))
     out["ring16_two_structures"] = {"systems": n_sys, "ms_per_step": ms2, "converged_systems_per_sec": conv / (ms2 * 1e-3),
                                     "converged_fraction": conv / n_sys, "grouped_build": db.grouped_build()}
+    # ... and with the reference's own numerics (FX_STEP_QR): the grouped QR build once per structure class (fx_solve.cpp: launch_class_qr)
+    out["ring16_two_structures"]["ms_per_step_qr_reference_numerics"] = _time_solves(ctx, db, abi.solving_opts(solver=2), reps=2)
     db.free()
     # ... and with every System's structure its own (random chords and angle sites): no one-structure program, no structure class —
     # the general build of the grouped kernel, the rate a batch of unrelated sketches gets

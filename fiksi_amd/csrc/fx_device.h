@@ -234,6 +234,8 @@ hipError_t launch_solve_grouped_c(const DeviceBatch& b, const LmParams& p, hipSt
 size_t grouped_c_lds_bytes(const DeviceBatch& b, uint32_t element_size);
 // ... and its sparse build for batches of one structure of 33 ... 255 free variables with a small factor (fx_grouped_s.hip)
 bool grouped_s_applies(const DeviceBatch& b, const LmParams& p);
+bool grouped_qr_class_applies(const DeviceBatch& b, const LmParams& p);
+hipError_t launch_grouped_qr_class(const DeviceBatch& b, const LmParams& p, hipStream_t stream);
 // fx_grouped_tiny.hip: the one-structure build for Systems of at most eight variables and expressions (eight lanes per System)
 bool grouped_tiny_applies(const DeviceBatch& b, const LmParams& p);
 hipError_t launch_solve_tiny(const DeviceBatch& b, const LmParams& p, hipStream_t stream);

@@ -1457,11 +1457,14 @@ static hipError_t launch_grouped_t(const DeviceBatch& b, const LmParams& p, uint
 }
 
 // FX_STEP_QR on a batch of one structure: the program of ensure_qr_plans is there, and four Systems fit a wavefront's LDS
-static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLayout* out) {
+// (as_class: a launch over ONE structure class of a batch of several — the members come through b.order, the program is the
+// class's; the batch's maxima size the LDS layout, the class's own structure may be smaller)
+static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLayout* out, bool as_class = false) {
     const QrPlans& Q = b.qr_none;
-    if (p.lm.solver != FX_STEP_QR || !Q.qrg || !b.uniform || b.u_ncomp != 1u || p.lm.precision == 32 || p.prof) return false;
+    if (p.lm.solver != FX_STEP_QR || !Q.qrg || p.lm.precision == 32 || p.prof) return false;
+    if (as_class ? (b.uniform || !b.order || !b.sys_class) : (!b.uniform || b.u_ncomp != 1u)) return false;
     if ((p.mode & (MODE_UNITS | MODE_LBFGS)) || b.max_free > 32u || b.max_rows > 64u || b.max_vars > 64u || !b.work_counter) return false;
-    if (Q.qrg_n != b.max_free || Q.qrg_m != b.max_rows) return false;
+    if (as_class ? (Q.qrg_n > b.max_free || Q.qrg_m > b.max_rows) : (Q.qrg_n != b.max_free || Q.qrg_m != b.max_rows)) return false;
     GroupLayout L = make_group_layout(32u, b.max_vars, b.max_rows, 8u, 0u, 0u, Q.qrg_small, Q.qrg_nx, Q.qrg_ng);
     if ((size_t)L.tab_bytes + 4u * (size_t)L.stride > 160u * 1024u / 2u) return false;  // two wavefronts per CU at least
     {  // the whole program in LDS when that costs no wavefront (FIKSI_AMD_QR_TABLES=lds|global forces either: measurements)
@@ -1480,9 +1483,9 @@ static bool grouped_qr_applies(const DeviceBatch& b, const LmParams& p, GroupLay
     return true;
 }
 
-static hipError_t launch_grouped_qr(const DeviceBatch& b, const LmParams& p, hipStream_t stream) {
+static hipError_t launch_grouped_qr(const DeviceBatch& b, const LmParams& p, hipStream_t stream, bool as_class = false) {
     GroupLayout L;
-    if (!grouped_qr_applies(b, p, &L)) return hipErrorInvalidValue;
+    if (!grouped_qr_applies(b, p, &L, as_class)) return hipErrorInvalidValue;
     const uint32_t per_wave = L.tab_bytes + 4u * L.stride;
     static const bool trace = getenv("FIKSI_AMD_TRACE") != nullptr;
     if (trace)
@@ -1509,6 +1512,11 @@ static hipError_t launch_grouped_qr(const DeviceBatch& b, const LmParams& p, hip
     hipLaunchKernelGGL(lm_solve_grouped_qr_kernel, dim3(waves), dim3(64), per_wave, stream, b, pl, L, b.work_counter);
     return hipGetLastError();
 }
+
+// FX_STEP_QR on one structure class of a batch of several structures: b.qr_none.qrg* the class's program, b.order / b.n_systems its
+// member list, b.work_counter a queue head of its own (fx_solve.cpp: launch_class_qr)
+bool grouped_qr_class_applies(const DeviceBatch& b, const LmParams& p) { return grouped_qr_applies(b, p, nullptr, true); }
+hipError_t launch_grouped_qr_class(const DeviceBatch& b, const LmParams& p, hipStream_t stream) { return launch_grouped_qr(b, p, stream, true); }
 
 static uint32_t grouped_columns(const DeviceBatch& b, bool units) {
     const uint32_t f = units ? b.max_unit_free : b.max_free;

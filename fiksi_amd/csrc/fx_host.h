@@ -316,6 +316,16 @@ struct fx_dbatch {
     uint32_t cl_rc = 0;
     uint32_t cl_nc = 0, cl_max_words = 0, cl_max_slots = 0, cl_max_ng = 0, cl_systems = 0;  // the classes' common build, the largest program, their Systems in all
     uint32_t rest_off = 0, rest_count = 0;
+    std::vector<uint32_t> class_first;  // the first System of each class (its structure stands for the class)
+    // FX_STEP_QR on such a batch: the grouped QR build's program per class (ensure_qr_plans; prog == null: the class's structure does
+    // not qualify), and sys_large with the members of the classes that have one marked — the one-wavefront QR kernel, launched over
+    // the whole batch for everybody else, passes them by
+    struct QrClassProg {
+        uint32_t* prog = nullptr;
+        uint32_t words = 0, small_words = 0, ng = 0, nx = 0, n = 0, m = 0;
+    };
+    std::vector<QrClassProg> qr_class;
+    uint8_t* qr_skip = nullptr;
     // host copy of the batch, kept only when some System needs the sparse path
     std::vector<uint32_t> h_var_off, h_expr_off, h_expr_idx;
     std::vector<double> h_vars, h_expr_param;

@@ -25,6 +25,8 @@ bool grouped_c_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped_c(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 size_t grouped_c_lds_bytes(const DeviceBatch&, uint32_t) { return 0; }
 bool grouped_s_applies(const DeviceBatch&, const LmParams&) { return false; }
+bool grouped_qr_class_applies(const DeviceBatch&, const LmParams&) { return false; }
+hipError_t launch_grouped_qr_class(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 bool grouped_tiny_applies(const DeviceBatch&, const LmParams&) { return false; }
 hipError_t launch_solve_grouped_s(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_solve_walk(const DeviceBatch&, const LmParams&, hipStream_t) { return hipErrorNoDevice; }

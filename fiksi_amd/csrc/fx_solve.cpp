@@ -11,6 +11,33 @@ namespace fxh {
 // all of them — a wavefront works through the queue of its class, then loads the next class's program and helps there
 // (fx_grouped_c.hip) —, and the general build over everyone else. Results are each System's own: the bits of the general build.
 // Returns false when the batch or the options do not qualify (nothing launched).
+// The member lists of a batch's structure classes (and of the rest), each longest-first as a whole batch would be (fx_presort.hip):
+// the scout pass once, a ranking per list. *lists: where they are (the unsorted ones when the presort is off or the batch small).
+static int presorted_class_lists(fx_ctx* ctx, fx_dbatch* db, uint32_t** lists) {
+    fx::DeviceBatch& d = db->d;
+    *lists = db->cl_lists;
+    if (!ctx->presort || d.n_systems < ctx->presort_min_systems) return FX_OK;
+    const uint32_t n = d.n_systems;
+    if (!db->ps_keys) {
+        db->ps_temp_bytes = fx::presort_temp_bytes(n);
+        int r2 = dev_alloc_copy(ctx, db, &db->ps_keys, (const float*)nullptr, 2 * (size_t)n);
+        if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_ids, (const uint32_t*)nullptr, 2 * (size_t)n);
+        if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_temp, (const unsigned char*)nullptr, db->ps_temp_bytes);
+        if (r2) return r2;
+    }
+    std::vector<uint32_t> offs, counts;
+    for (const fx::GcClass& cl : db->classes) {
+        offs.push_back(cl.list_off);
+        counts.push_back(cl.count);
+    }
+    offs.push_back(db->rest_off);
+    counts.push_back(db->rest_count);
+    hipError_t e0 = fx::launch_presort_lists(d, db->ps_keys, db->cl_lists, offs.data(), counts.data(), (uint32_t)offs.size(), db->ps_ids + n, ctx->stream);
+    if (e0 != hipSuccess) return fail(FX_ERR_HIP, "presort launch failed: %s", hipGetErrorString(e0));
+    *lists = db->ps_ids + n;
+    return FX_OK;
+}
+
 static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p, int* rc) {
     fx::DeviceBatch& d = db->d;
     *rc = FX_OK;
@@ -31,31 +58,12 @@ static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& 
     if (!fx::grouped_c_applies(dc, p)) return false;  // (f32 beyond the 32-column shape, the stamped build, ...: the general build for all)
     // every list longest-first, as a whole batch would be (fx_presort.hip): the scout pass once, a ranking per list
     uint32_t* lists = db->cl_lists;
-    if (ctx->presort && d.n_systems >= ctx->presort_min_systems) {
-        const uint32_t n = d.n_systems;
-        if (!db->ps_keys) {
-            db->ps_temp_bytes = fx::presort_temp_bytes(n);
-            int r2 = dev_alloc_copy(ctx, db, &db->ps_keys, (const float*)nullptr, 2 * (size_t)n);
-            if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_ids, (const uint32_t*)nullptr, 2 * (size_t)n);
-            if (!r2) r2 = dev_alloc_copy(ctx, db, &db->ps_temp, (const unsigned char*)nullptr, db->ps_temp_bytes);
-            if (r2) {
-                *rc = r2;
-                return true;
-            }
-        }
-        std::vector<uint32_t> offs, counts;
-        for (const fx::GcClass& cl : db->classes) {
-            offs.push_back(cl.list_off);
-            counts.push_back(cl.count);
-        }
-        offs.push_back(db->rest_off);
-        counts.push_back(db->rest_count);
-        hipError_t e0 = fx::launch_presort_lists(d, db->ps_keys, db->cl_lists, offs.data(), counts.data(), (uint32_t)offs.size(), db->ps_ids + n, ctx->stream);
-        if (e0 != hipSuccess) {
-            *rc = fail(FX_ERR_HIP, "presort launch failed: %s", hipGetErrorString(e0));
+    {
+        const int r2 = presorted_class_lists(ctx, db, &lists);
+        if (r2) {
+            *rc = r2;
             return true;
         }
-        lists = db->ps_ids + n;
         dc.order = lists;
     }
     hipError_t e = fx::launch_solve_grouped_c(dc, p, ctx->stream);
@@ -70,11 +78,62 @@ static bool launch_class_solves(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& 
     return true;
 }
 
+// FX_STEP_QR on a batch of several structures: the grouped QR build (four Systems per wavefront, fx_grouped.hip) once per big
+// structure class that has a program (ensure_qr_plans), over the class's member list; then the one-wavefront QR kernel over the
+// whole batch, which passes those Systems by (DeviceBatch::sys_large = fx_dbatch::qr_skip). Same operations per System either way.
+static bool launch_class_qr(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p, int* rc) {
+    fx::DeviceBatch& d = db->d;
+    *rc = FX_OK;
+    static const bool on = [] { const char* e = std::getenv("FIKSI_AMD_QR_CLASSES"); return !e || atoi(e) != 0; }();
+    if (!on || p.lm.solver != FX_STEP_QR || db->qr_class.empty() || !db->qr_skip || d.order || d.uniform || !p.grouped_one_structure || p.route_grouped == 0)
+        return false;
+    bool any = false;
+    uint32_t* lists = db->cl_lists;
+    if ((*rc = presorted_class_lists(ctx, db, &lists)) != FX_OK) return true;
+    for (size_t k = 0; k < db->qr_class.size(); ++k) {
+        const fx_dbatch::QrClassProg& c = db->qr_class[k];
+        if (!c.prog) continue;
+        fx::DeviceBatch dc = d;
+        dc.qr_none.qrg = c.prog;
+        dc.qr_none.qrg_words = c.words;
+        dc.qr_none.qrg_small = c.small_words;
+        dc.qr_none.qrg_ng = c.ng;
+        dc.qr_none.qrg_nx = c.nx;
+        dc.qr_none.qrg_n = c.n;
+        dc.qr_none.qrg_m = c.m;
+        dc.order = lists + db->classes[k].list_off;
+        dc.n_systems = db->classes[k].count;
+        dc.work_counter = d.work_counter + 1 + (uint32_t)k;
+        if (!fx::grouped_qr_class_applies(dc, p)) {
+            if (any) {
+                *rc = fail(FX_ERR_INTERNAL, "FX_STEP_QR: a structure class with a program does not qualify for the grouped build");
+                return true;
+            }
+            return false;  // (the first class decides for all: the layout depends on the batch's maxima only)
+        }
+        // (one after the other on the context's stream: side by side on two streams the two persistent kernels halve each other's
+        // share of the chip from the start — 25.7 against 22.1 ms on 100 000 ring16 sketches of two structures)
+        hipError_t e = fx::launch_grouped_qr_class(dc, p, ctx->stream);
+        if (e != hipSuccess) {
+            *rc = fail(FX_ERR_HIP, "grouped QR launch over a structure class failed: %s", hipGetErrorString(e));
+            return true;
+        }
+        any = true;
+    }
+    if (!any) return false;
+    fx::DeviceBatch dq = d;
+    dq.sys_large = db->qr_skip;
+    hipError_t e = fx::launch_solve(dq, p, ctx->stream);
+    if (e != hipSuccess) *rc = fail(FX_ERR_HIP, "solve kernel launch failed: %s", hipGetErrorString(e));
+    return true;
+}
+
 int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     fx::DeviceBatch& d = db->d;
     {
         int rc = FX_OK;
         if (launch_class_solves(ctx, db, p, &rc)) return rc;
+        if (launch_class_qr(ctx, db, p, &rc)) return rc;
     }
     // (a batch solved in place on the caller's arrays has no start values on the device yet for the scout pass to rank by)
     // (... and the tiny build has no queue to hand Systems out from: eight consecutive Systems per wavefront)

@@ -561,6 +561,45 @@ int ensure_qr_plans(fx_ctx* ctx, fx_dbatch* db, bool units) {
         q.qrw_vars = w_vars;
         q.qrw_rows = w_rows;
     }
+    // a batch of SEVERAL structures: the same program per big structure class (the classes of the one-structure Cholesky build,
+    // upload_planned) — a launch of the grouped build per class over its member list (fx_solve.cpp: launch_class_qr)
+    if (!rc && !units && !d.uniform && !db->classes.empty() && db->qr_class.empty() && !sys_class.empty() && db->class_first.size() == db->classes.size()) {
+        std::vector<fx_dbatch::QrClassProg> cls(db->classes.size());
+        std::vector<uint8_t> skip(sys_large.begin(), sys_large.end());
+        bool any = false;
+        for (size_t k = 0; k < db->classes.size() && !rc; ++k) {
+            const uint32_t s = db->class_first[k];
+            if (s >= n || sys_large[s] || sys_ncomp[s] != 1u) continue;
+            const uint32_t v0 = var_off[s], nvt = var_off[s + 1] - v0, e0 = expr_off[s], net = expr_off[s + 1] - e0;
+            std::vector<uint32_t> rows, free_;
+            for (uint32_t i = 0; i < nvt; ++i)
+                if ((var_info[v0 + i] & fx::VAR_COMP_MASK) == 0 && !(var_info[v0 + i] & fx::VAR_FIXED_BIT)) free_.push_back(i);
+            for (uint32_t i = 0; i < net; ++i)
+                if (expr_comp[e0 + i] == 0) rows.push_back(i);
+            QrgHostProgram cp;
+            if (!build_qrg_program(expr_tag.data() + e0, expr_idx.data() + 4 * (size_t)e0, rows.data(), (uint32_t)rows.size(), free_.data(), (uint32_t)free_.size(), nvt,
+                                   cp) ||
+                !cp.ok)
+                continue;
+            rc = dev_alloc_copy(ctx, db, &cls[k].prog, cp.words.data(), cp.words.size());
+            cls[k].words = (uint32_t)cp.words.size();
+            cls[k].small_words = cp.words[14];
+            cls[k].ng = cp.ng;
+            cls[k].nx = cp.nx;
+            cls[k].n = cp.n;
+            cls[k].m = cp.m;
+            any = true;
+        }
+        if (!rc && any) {
+            std::vector<uint8_t> has(n, 0);  // (a class is named by its first System)
+            for (size_t k = 0; k < cls.size(); ++k)
+                if (cls[k].prog) has[db->class_first[k]] = 1;
+            for (uint32_t s = 0; s < n; ++s)
+                if (!skip[s] && has[sys_class[s]]) skip[s] = 4;
+            rc = dev_alloc_copy(ctx, db, &db->qr_skip, skip.data(), skip.size());
+            if (!rc) db->qr_class = std::move(cls);
+        }
+    }
     if (!rc && prog.ok) {
         rc = dev_alloc_copy(ctx, db, &q.qrg, prog.words.data(), prog.words.size());
         q.qrg_words = (uint32_t)prog.words.size();
@@ -842,6 +881,7 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
             cl_words_h.insert(cl_words_h.end(), cp.words.begin(), cp.words.end());
             class_slot[f] = (uint32_t)db->classes.size();
             db->classes.push_back(cl);
+            db->class_first.push_back(f);  // (of this batch or chunk)
         }
         if (!db->classes.empty()) {
             uint32_t at = 0;

@@ -225,6 +225,37 @@ def test_four_systems_per_wavefront_is_the_same_bits(fiksi, oracle, ctx, shape):
     _assert_identical(sub, out[("1", True)][0][: len(v_o)], out[("1", True)][1][:n], v_o, res_o)
 
 
+def test_structure_classes_run_four_systems_per_wavefront_too(fiksi, oracle, ctx):
+    """A batch of SEVERAL structures under FX_STEP_QR: every big structure class (2 048 Systems and more) gets the grouped QR
+    build's program and a launch over its member list (fx_solve.cpp: launch_class_qr), everybody else — a small class, a sketch
+    of another shape — the one-wavefront QR kernel, which passes the classes' Systems by. Every variable and result field is the
+    one-wavefront kernel's bits (routing 0), and the oracle's on a sample drawn across the classes and the rest."""
+    from fiksi_amd import abi, workloads
+
+    b = workloads.concat([workloads.ring16_two_structures(4400), workloads.hinged_triangles(300, 5), workloads.ring16(2100, fix_gauge=True)])
+    o = abi.solving_opts(solver=2)
+    out = {}
+    try:
+        for routing in (-1, 0):
+            ctx.set_routing(routing)
+            db = ctx.upload(b)
+            db.system_solve(o)
+            out[routing] = (db.get_vars().copy(), db.get_results().copy())
+            db.free()
+        vh, rh = ctx.system_solve_batch(b, o)  # (the host-buffer call: its chunks carry their own classes)
+    finally:
+        ctx.set_routing(-1)
+    assert np.array_equal(_bits(out[-1][0]), _bits(out[0][0])) and out[-1][1].tobytes() == out[0][1].tobytes()
+    assert np.array_equal(_bits(vh), _bits(out[0][0])) and rh.tobytes() == out[0][1].tobytes()
+    n = len(b["var_off"]) - 1
+    pick = np.sort(np.random.default_rng(11).choice(n, size=96, replace=False))
+    sample = workloads.concat([workloads.shard(b, int(s), n) for s in pick])
+    with oracle.atan2_mode("correctly_rounded"):
+        v_o, res_o = oracle.solve_batch(sample, mode=3, nthreads=8)
+    v_s = np.concatenate([out[-1][0][int(b["var_off"][s]):int(b["var_off"][s + 1])] for s in pick])
+    _assert_identical(sample, v_s, out[-1][1][pick], v_o, res_o)
+
+
 @pytest.mark.parametrize("wide_routing", [-1, 1])
 def test_components_of_65_to_128_columns_keep_the_reference_numerics(fiksi, oracle, ctx, wide_routing):
     """FX_STEP_QR beyond one wavefront (round 4): Systems whose components have at most 128 columns and 256 rows run the
