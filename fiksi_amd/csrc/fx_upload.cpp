@@ -842,7 +842,11 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
     // build — columns per lane) get a program each
     std::vector<uint32_t> cl_words_h, cl_lists_h;
     if (!d.uniform && sys_class && p.n_large == 0 && p.max_free >= 1u && p.max_free <= 48u) {
-        constexpr uint32_t CLASS_MIN = 2048u, MAX_CLASSES = 8u;
+        constexpr uint32_t MAX_CLASSES = 8u;
+        // a class from 256 members on — when the classes hold three quarters of the batch: a launch over the classes plus a launch
+        // of the general build over a large rest is two slow ends instead of one (six structures x 1 500 Systems with one class of
+        // 3 000: 1.00 ms, 0.68 with all six as classes; tools/probes/class_min_probe.py)
+        static const uint32_t CLASS_MIN = [] { const char* e = std::getenv("FIKSI_AMD_CLASS_MIN"); return e ? (uint32_t)atoi(e) : 256u; }();
         std::vector<uint32_t> count(n_sys, 0u);  // (a class is named by its first System)
         for (uint32_t s = 0; s < n_sys; ++s) count[sys_class[s]] += 1u;
         std::vector<std::pair<uint32_t, uint32_t>> big;  // (members, first System)
@@ -882,6 +886,16 @@ int upload_planned(fx_ctx* ctx, const fx_batch* batch, const HostPlan& p, uint32
             class_slot[f] = (uint32_t)db->classes.size();
             db->classes.push_back(cl);
             db->class_first.push_back(f);  // (of this batch or chunk)
+        }
+        {
+            uint64_t covered = 0;
+            for (const auto& cl : db->classes) covered += cl.count;
+            if (4u * covered < 3u * (uint64_t)n_sys) {  // (too much of the batch outside the classes: the general build for all)
+                db->classes.clear();
+                db->class_first.clear();
+                cl_words_h.clear();
+                db->cl_max_words = db->cl_max_words_all = db->cl_max_slots = db->cl_max_ng = 0;
+            }
         }
         if (!db->classes.empty()) {
             uint32_t at = 0;

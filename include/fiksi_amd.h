@@ -360,7 +360,8 @@ int fx_debug_solve_route(fx_ctx* ctx, fx_dbatch* db, const fx_solving_opts* opts
  * SIMD for that shape; same bits), 2 = the sparse build for batches of one structure with a component of 33 ... 255 free
  * variables and a small Cholesky factor (fx_grouped_s.hip: the factorisation as a level schedule over tables in LDS; the limits:
  * fx_ctx_set_one_structure_builds).
- * 3 = a batch of SEVERAL structures whose big structure classes (2 048 Systems and more, up to eight) run build 1 in one launch,
+ * 3 = a batch of SEVERAL structures whose big structure classes (256 Systems and more, up to eight, when they hold three quarters of
+ * the batch between them) run build 1 in one launch,
  * everyone else the general build. 4 = build 1's arithmetic for structures of at most eight variables and eight expressions
  * (fx_grouped_tiny.hip: eight lanes per System, eight Systems per wavefront; same bits as build 1;
  * fx_ctx_set_one_structure_builds(ctx, 2) keeps such batches on build 1). A context created under FIKSI_AMD_GROUPED_C=0 takes

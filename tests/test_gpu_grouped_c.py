@@ -72,9 +72,16 @@ def test_which_batches_take_the_one_structure_build(fiksi, ctx, ctx_general):
                  "ring16_inconsistent_f32", "hinged_5_f32", "hinged_3", "hinged_4", "hinged_5", "hinged_7", "ring20_chords", "ring23_chords"):
         assert taken[name] == 1, taken
     assert taken["hinged_1"] == 4, taken  # (six variables, three expressions: eight lanes per System, fx_grouped_tiny.hip)
-    # not of one structure, and no class of 2 048 Systems: the general build; f32 has the 32-column instantiation only
+    # not of one structure: classes of 256 Systems and more take this build (3) when they hold three quarters of the batch, else the
+    # general build for everybody; f32 has the 32-column instantiation only
     db = ctx.upload(workloads.ring16_two_structures(2000))
-    assert db.grouped_build() == 0
+    assert db.grouped_build() == 3
+    db.free()
+    db = ctx.upload(workloads.concat([workloads.ring16(300), workloads.ring16_all_different(1000)]))
+    assert db.grouped_build() == 0  # (one class of 300 among 1 300 Systems)
+    db.free()
+    db = ctx.upload(workloads.ring16_two_structures(400))
+    assert db.grouped_build() == 0  # (classes of 200)
     db.free()
     db = ctx.upload(workloads.hinged_triangles(2000, 3))
     assert db.grouped_build(abi.solving_opts(f32=True)) == 0
@@ -130,7 +137,7 @@ def test_resident_batch_solved_again_and_in_chunks(fiksi, ctx, ctx_general):
 
 
 def test_batches_of_several_structures_run_their_big_classes_on_this_build(fiksi, ctx, ctx_general):
-    """A few sketches, many parameter sets each: every structure class of 2 048 Systems and more gets a program, and ONE launch
+    """A few sketches, many parameter sets each: every structure class of 256 Systems and more gets a program, and ONE launch
     works through all of them (a wavefront loads the next class's program when its own class's queue is empty); the Systems of
     small classes take the general build. Every bit as in the general build alone — resident, through the host-buffer call, with
     and without the longest-first order within the classes, with the ladder off / everywhere."""

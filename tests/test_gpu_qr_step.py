@@ -226,7 +226,7 @@ def test_four_systems_per_wavefront_is_the_same_bits(fiksi, oracle, ctx, shape):
 
 
 def test_structure_classes_run_four_systems_per_wavefront_too(fiksi, oracle, ctx):
-    """A batch of SEVERAL structures under FX_STEP_QR: every big structure class (2 048 Systems and more) gets the grouped QR
+    """A batch of SEVERAL structures under FX_STEP_QR: every big structure class (256 Systems and more, three quarters of the batch between them) gets the grouped QR
     build's program and a launch over its member list (fx_solve.cpp: launch_class_qr), everybody else — a small class, a sketch
     of another shape — the one-wavefront QR kernel, which passes the classes' Systems by. Every variable and result field is the
     one-wavefront kernel's bits (routing 0), and the oracle's on a sample drawn across the classes and the rest."""
