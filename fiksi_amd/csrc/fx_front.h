@@ -396,7 +396,8 @@ template <bool POSE, int MODE>
 __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpBlock B, SpVals V, SpAccum* __restrict__ accum, fx_lm_opts o,
                                                                 uint32_t flags, double* __restrict__ vars_base, const uint64_t* __restrict__ out_off,
                                                                 const uint32_t* __restrict__ blob, uint32_t blob_words, uint32_t red_n, uint32_t trows,
-                                                                double* __restrict__ u_glob_base, size_t u_stride, unsigned long long* prof) {
+                                                                double* __restrict__ u_glob_base, size_t u_stride, unsigned long long* prof,
+                                                                fx_result* __restrict__ results, uint32_t n_group) {
     constexpr bool LG = MODE >= 1, UG = MODE >= 2;
     // prof (diagnostics, FIKSI_AMD_TEAM_PROF=1; else null): workgroup 0 adds up the 100 MHz ticks of its phases
     const bool stamp = prof && blockIdx.x == 0 && threadIdx.x == 0;
@@ -481,6 +482,41 @@ __global__ __launch_bounds__(MF_THREADS) void mf_lm_solo_kernel(SpRows rows, SpB
         ac.exit_code = st.exit_code;
         ac.sse0 += st.sse_start;
         ac.sse += st.sse;
+    }
+    // The System's only block (results != null; every expression of the System is a row of it): the closing check on the unscaled
+    // variables and the result record right here — spg_finish_kernel's statements, its 1 024 strided partial sums and its tree
+    // (team_sumsq's narrow form), so the same bits — instead of one more launch (6 us of a lone 258-variable sketch's 154).
+    if (results) {
+        __syncthreads();  // (the epilogue's stores to the output slice)
+        const double* x = vars_base + out_off[sys];
+        const double* uparam = rows.param + (size_t)sys * V.stride;
+        double* tmp = V.r0;
+        for (uint32_t e = tid; e < rows.net; e += MF_THREADS) {
+            const int tag = rows.tag[e] & 0x7F;
+            const ushort4 f4 = reinterpret_cast<const ushort4*>(rows.idx)[e];
+            const uint16_t ff[4] = {f4.x, f4.y, f4.z, f4.w};
+            uint32_t vars8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            expand_vars<POSE>(tag, ff, vars8);
+            double v[8], g[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = x[vars8[q]];
+            tmp[e] = eval_expression<double, false, false, POSE>(tag, v, uparam[e], g);
+        }
+        __syncthreads();
+        const double sse_u = team_sumsq<MF_NW>(tmp, rows.net, s_red, red_n);
+        if (tid == 0) {
+            const SpAccum ac = accum[sys];  // (this thread's own stores above)
+            fx_result res{};
+            res.accepted = ac.accepted;
+            res.trials = ac.trials;
+            res.exit = ac.exit_code;
+            res.ncomp = ac.ncomp;
+            res.scale = V.scal[0];
+            res.sse0 = ac.sse0;
+            res.sse = ac.sse;
+            res.sse_unscaled = sse_u;
+            results[out_off[2 * (size_t)n_group + sys]] = res;
+        }
     }
 }
 

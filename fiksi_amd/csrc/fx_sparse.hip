@@ -812,10 +812,10 @@ hipError_t raise_mf_lds_limits() {
 }
 hipError_t launch_mf_solo(bool pose, uint32_t n, size_t lds_bytes, hipStream_t stream, const SpRows& rows, const SpBlock& B, const SpVals& V, SpAccum* accum,
                           const fx_lm_opts& o, uint32_t flags, double* vars_base, const uint64_t* off, const uint32_t* blob, uint32_t blob_words, uint32_t red_n, uint32_t trows,
-                          int mode, double* u_glob, size_t u_stride, unsigned long long* prof) {
+                          int mode, double* u_glob, size_t u_stride, unsigned long long* prof, fx_result* results) {
     hipError_t e = raise_mf_lds_limits();
     if (e != hipSuccess) return e;
-#define FX_MF_SOLO(P, G) hipLaunchKernelGGL((mf_lm_solo_kernel<P, G>), dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows, u_glob, u_stride, prof)
+#define FX_MF_SOLO(P, G) hipLaunchKernelGGL((mf_lm_solo_kernel<P, G>), dim3(n), dim3(MF_THREADS), lds_bytes, stream, rows, B, V, accum, o, flags, vars_base, off, blob, blob_words, red_n, trows, u_glob, u_stride, prof, results, n)
     if (pose) {
         if (mode == 2) FX_MF_SOLO(true, 2);
         else if (mode == 1) FX_MF_SOLO(true, 1);
@@ -973,6 +973,7 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
             hipLaunchKernelGGL(sp_init_kernel, grid_for2(std::max(nvt, net), n), dim3(256), 0, stream, d_vars0, nvt, rows, V.scal, V.xs0, V.xs1,
                                do_scale, stride);
         }
+        bool finish_done = false;  // (mf_lm_solo_kernel has written the result records itself)
         uint32_t rng = 42u;  // Rng::from_seed(42), shared by the components (:47)
         for (const CompOnDevice& comp : cache->comps) {
             // ---- the component's perturbation (:91-124), before any of its blocks
@@ -1001,9 +1002,13 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
                         if (pool.err != hipSuccess) return pool.err;
                         (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), stream);
                     }
+                    // (the System's only block, every expression a row of it: the closing check and the record in the same launch)
+                    const bool fuse_finish = fused_prologue && comp.n_blocks == 1u && blk.dev.m == net && !single_pass;
                     e = launch_mf_solo(rows.has_pose != 0, n, blk.mf_solo_lds, stream, rows, blk.dev, V, d_accum, o, flags, d.vars, d_off, blk.mf_solo_blob,
-                                       blk.mf_solo_words, blk.mf_solo_red, blk.mf_solo_rows, blk.mf_solo_mode, slab + o_cf, stride, d_prof);
+                                       blk.mf_solo_words, blk.mf_solo_red, blk.mf_solo_rows, blk.mf_solo_mode, slab + o_cf, stride, d_prof,
+                                       fuse_finish ? d.results : nullptr);
                     if (e != hipSuccess) return e;
+                    finish_done = fuse_finish;
                     if (team_prof) {
                         unsigned long long h[16];
                         (void)hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, stream);
@@ -1154,7 +1159,8 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
             }
         }
         // ---- post-solve check on the unscaled variables, the result records
-        if (rows.has_pose)
+        if (finish_done) {
+        } else if (rows.has_pose)
             hipLaunchKernelGGL(spg_finish_kernel<true>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, stride, V.scal, d_accum, d.vars, d_off, n, d.results);
         else
             hipLaunchKernelGGL(spg_finish_kernel<false>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, stride, V.scal, d_accum, d.vars, d_off, n, d.results);
