@@ -49,7 +49,7 @@ SparsePlanCache* sparse_cache_new() { return nullptr; }
 void sparse_cache_free(SparsePlanCache*) {}
 bool sparse_cache_ready(const SparsePlanCache*) { return false; }
 void sparse_cache_keep_slab(SparsePlanCache*, size_t) {}
-hipError_t sparse_solve_group(const fx_batch*, const DeviceBatch&, const uint32_t*, uint32_t, const LmParams&, hipStream_t, SparsePlanCache*) {
+hipError_t sparse_solve_group(const fx_batch*, const DeviceBatch&, const uint32_t*, uint32_t, const LmParams&, hipStream_t, SparsePlanCache*, bool) {
     return hipErrorNoDevice;
 }
 }  // namespace fx

@@ -20,8 +20,10 @@ bool sparse_cache_ready(const SparsePlanCache* c);  // filled by a completed sol
 void sparse_cache_keep_slab(SparsePlanCache* c, size_t bytes);
 // Levenberg-Marquardt or L-BFGS (prm.mode) for Systems systems[0 .. n) of the host batch `b`, which all have the structure of the first one
 // (fixed flags, tags, fields, components): one plan, every launch covers the whole group, results and solved variables
-// go straight to the resident batch `d` (d.vars, d.results). Synchronises `stream` before it returns.
+// go straight to the resident batch `d` (d.vars, d.results). Synchronises `stream` before it returns — unless stay_async is set (the
+// caller's next work goes to the same stream) and the plan is a resident batch's that has seen this group before: such a solve
+// uploads nothing and gives nothing back, and returns with its launches in flight.
 hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uint32_t* systems, uint32_t n, const LmParams& prm,
-                              hipStream_t stream, SparsePlanCache* cache);
+                              hipStream_t stream, SparsePlanCache* cache, bool stay_async = false);
 
 }  // namespace fx

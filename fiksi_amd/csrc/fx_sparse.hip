@@ -438,6 +438,11 @@ struct SparsePlanCache {
     std::vector<std::unique_ptr<BlockOnDevice>> blocks;  // in visiting order
     uint32_t max_m = 0, max_nv = 0, max_nnz_j = 0, max_nnz_a = 0, max_nnz_l = 0, max_fslots = 0, max_bslots = 0;
     uint32_t max_mf_l = 0, max_mf_gu = 0;            // the multifrontal build's global storage (fx_front.h)
+    // a resident batch's group (sparse_cache_keep_slab(SIZE_MAX)): where its Systems sit in the batch's arrays, on the device — the
+    // same every solve, so uploaded once (the host copy stays for as long as the copy may be in flight)
+    std::vector<uint32_t> off_systems;
+    std::vector<uint64_t> off_host;
+    uint64_t* d_off = nullptr;
     Arena values;                                    // the group solves' value slabs, kept between calls (one solve at a time)
     size_t keep_values = size_t(256) << 20;          // ... up to this many bytes (sparse_cache_keep_slab)
     bool ready = false;
@@ -857,7 +862,7 @@ void trace_block(const BlockOnDevice& blk, uint32_t trials, double ms) {
 // host: a group of Systems of ONE structure — Levenberg-Marquardt or L-BFGS, everything on the device
 // ------------------------------------------------------------------------------------------------
 hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uint32_t* systems, uint32_t n_sys, const LmParams& prm,
-                              hipStream_t stream, SparsePlanCache* cache) {
+                              hipStream_t stream, SparsePlanCache* cache, bool stay_async) {
     if (!n_sys) return hipSuccess;
     const bool trace = std::getenv("FIKSI_AMD_TRACE") != nullptr;  // diagnostics on stderr
     const bool team_prof = std::getenv("FIKSI_AMD_TEAM_PROF") != nullptr;
@@ -934,14 +939,40 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
             (void)hipMemsetAsync(Ld.rk, 0, (size_t)n * MF_MAX_RANKS * sizeof(MfRank), stream);
             (void)hipMemsetAsync(Ld.tickets, 0, (size_t)n * (2 * MF_MAX_RANKS + 2) * sizeof(uint32_t), stream);
         }
-        std::vector<uint64_t> h_off(3 * (size_t)n);  // [out / vars0 offset | parameter offset | system id] per System
-        for (uint32_t k = 0; k < n; ++k) {
-            h_off[k] = b->var_off[systems[g0 + k]];
-            h_off[n + k] = b->expr_off[systems[g0 + k]];
-            h_off[2 * (size_t)n + k] = systems[g0 + k];
+        // [out / vars0 offset | parameter offset | system id] per System. A resident batch's group, solved whole: uploaded once and kept
+        // with the plan — such a solve then has nothing of the host's in flight and nothing to give back, and ends without a wait
+        // (stay_async: the caller's next work is on this stream too)
+        const bool keep_off = stay_async && n == n_sys && cache->keep_values == SIZE_MAX && !team_prof && !trace;
+        bool off_cached = keep_off && cache->d_off && cache->off_systems.size() == n && std::equal(systems, systems + n, cache->off_systems.begin());
+        std::vector<uint64_t> h_off;
+        uint64_t* d_off = nullptr;
+        if (off_cached) {
+            d_off = cache->d_off;
+        } else {
+            h_off.resize(3 * (size_t)n);
+            for (uint32_t k = 0; k < n; ++k) {
+                h_off[k] = b->var_off[systems[g0 + k]];
+                h_off[n + k] = b->expr_off[systems[g0 + k]];
+                h_off[2 * (size_t)n + k] = systems[g0 + k];
+            }
+            if (keep_off) {  // (this solve still waits at its end: the next one finds the copy done)
+                hipError_t e2 = hipSuccess;
+                cache->off_systems.clear();
+                cache->d_off = static_cast<uint64_t*>(cache->arena.take(h_off.size() * sizeof(uint64_t), e2));
+                if (!cache->d_off) return e2;
+                cache->off_host = h_off;
+                e2 = hipMemcpyAsync(cache->d_off, cache->off_host.data(), h_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream);
+                if (e2 != hipSuccess) {
+                    cache->d_off = nullptr;
+                    return e2;
+                }
+                cache->off_systems.assign(systems, systems + n);
+                d_off = cache->d_off;
+            } else {
+                d_off = pool.up(h_off);
+                if (pool.err != hipSuccess) return pool.err;
+            }
         }
-        uint64_t* d_off = pool.up(h_off);
-        if (pool.err != hipSuccess) return pool.err;
 
         SpRows rows;
         rows.tag = d.expr_tag + b->expr_off[s0];
@@ -1165,7 +1196,8 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         else
             hipLaunchKernelGGL(spg_finish_kernel<false>, dim3(n), dim3(TEAM_THREADS), 0, stream, rows, stride, V.scal, d_accum, d.vars, d_off, n, d.results);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the slice's slab is handed to the next one
+        // the slice's slab is handed to the next one, the host's offsets die with this frame — unless neither is the case
+        if (e == hipSuccess && !off_cached) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
     }
     // the slab stays with the plan for the next solve of this structure — up to a bound for the context's own plans (one
