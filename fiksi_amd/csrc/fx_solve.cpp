@@ -319,7 +319,7 @@ int solve_large_systems(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     if (n_workers <= 1) {
         for (size_t g = 0; g < groups.size(); ++g) {
             hipError_t e = fx::sparse_solve_group(&hb, db->d, groups[g].systems.data(), (uint32_t)groups[g].systems.size(), p, ctx->stream,
-                                                  group_plan[g], /*stay_async=*/db->resident);
+                                                  group_plan[g], /*stay_async=*/group_plan[g] != nullptr);
             if (e != hipSuccess)
                 return fail(FX_ERR_HIP, "sparse path failed on the group of system %u: %s", groups[g].systems[0], hipGetErrorString(e));
         }

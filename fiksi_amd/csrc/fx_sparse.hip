@@ -942,7 +942,8 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
         // [out / vars0 offset | parameter offset | system id] per System. A resident batch's group, solved whole: uploaded once and kept
         // with the plan — such a solve then has nothing of the host's in flight and nothing to give back, and ends without a wait
         // (stay_async: the caller's next work is on this stream too)
-        const bool keep_off = stay_async && n == n_sys && cache->keep_values == SIZE_MAX && !team_prof && !trace;
+        // (a context's own plan — one-shot calls — as well, as long as its slab stays under the bound it may keep: trimming needs the wait)
+        const bool keep_off = stay_async && n == n_sys && cache->values.bytes() <= cache->keep_values && !team_prof && !trace;
         bool off_cached = keep_off && cache->d_off && cache->off_systems.size() == n && std::equal(systems, systems + n, cache->off_systems.begin());
         std::vector<uint64_t> h_off;
         uint64_t* d_off = nullptr;
@@ -1204,7 +1205,7 @@ hipError_t sparse_solve_group(const fx_batch* b, const DeviceBatch& d, const uin
     // big one-shot group must not pin a gigabyte of HBM per cached structure until the context goes); a resident batch's
     // plans keep theirs whole until the batch is freed (20 000 Systems of 66 variables: 272 MB, and giving it back and
     // asking for it again cost 12 ms per solve of 3.8 ms)
-    cache->values.trim(cache->keep_values);
+    cache->values.trim(cache->keep_values);  // (a solve that returned with its launches in flight is under the bound: nothing to trim)
     return hipSuccess;
 }
 
