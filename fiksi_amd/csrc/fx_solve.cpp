@@ -130,6 +130,10 @@ static bool launch_class_qr(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p, i
 
 int launch_solve_scheduled(fx_ctx* ctx, fx_dbatch* db, const fx::LmParams& p) {
     fx::DeviceBatch& d = db->d;
+    // (every System beyond one wavefront — one System::solve on a large sketch is such a batch: the one-wavefront kernels would be
+    // launched to find nothing of theirs; solve_beyond_one_wavefront has them all)
+    // (SinglePass: the launch below also starts the block walker of large Systems whose blocks fit one wavefront)
+    if (db->n_large && db->n_large == d.n_systems && !(p.mode & fx::MODE_UNITS)) return FX_OK;
     {
         int rc = FX_OK;
         if (launch_class_solves(ctx, db, p, &rc)) return rc;
